@@ -1,0 +1,407 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Runs ONLY in the build container.
+
+Imports the real reference (`/root/reference`, read-only, never copied) on CPU, drives it
+and the restatement in oracle/graph.py + oracle/step.py on identical seeded inputs and
+closed-form weights (oracle/fill.py), asserts they agree, and writes the reference's
+numbers as small fixtures under tests/golden/.  The reference's own test-suite holds no
+golden vectors for this path, so these fixtures are the parity pin.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden [--skip-step128]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "attribute-guided-image-generation-from-layout_amd")
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)          # reference `models.*`  (must precede PKG: same top-level name)
+import models.generator_obj_att as ref_g64          # noqa: E402
+import models.generator_obj_att128 as ref_g128      # noqa: E402
+import models.discriminator as ref_d                # noqa: E402
+import models.bilinear as ref_b                     # noqa: E402
+from models.spade.networks.normalization import SPADE as RefSPADE   # noqa: E402
+
+sys.path.insert(1, ROOT)
+from oracle import graph as OG, step as OS           # noqa: E402
+from oracle.fill import fill_state                   # noqa: E402
+
+import importlib.util                                # noqa: E402
+_spec = importlib.util.spec_from_file_location("agl_synth", os.path.join(PKG, "agl", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+TOL = 2e-6
+
+
+def maxdiff(a, b):
+    return float((a.detach() - b.detach()).abs().max()) if a.numel() else 0.0
+
+
+def check(name, a, b, tol=TOL):
+    d = maxdiff(a, b)
+    scale = max(1.0, float(b.detach().abs().max()) if b.numel() else 1.0)
+    print(f"  {name:46s} max|diff| {d:.3e}  (scale {scale:.2e})")
+    assert d <= tol * scale, f"oracle != reference for {name}: {d}"
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+def filled(module):
+    module.load_state_dict(fill_state(module.state_dict()))
+    return module
+
+
+def sub(state, prefix=""):
+    return OS.as_params({prefix + k: v for k, v in state.items()})
+
+
+# =========================================================================== per-op fixtures
+def ops_small():
+    print("[ops_small]")
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    # ---- crop: sorted / unsorted box->image map, boxes touching and exceeding borders
+    feats = rn(3, 4, 20, 24)
+    boxes = torch.tensor([[0.1, 0.2, 0.6, 0.7], [0.0, 0.0, 1.0, 1.0], [0.5, 0.5, 1.0, 1.0],
+                          [-0.2, 0.1, 0.4, 1.3], [0.3, 0.3, 0.31, 0.32], [0.9, 0.05, 0.4, 0.6],
+                          [0.25, 0.0, 0.75, 0.5]], dtype=torch.float32)
+    for tag, o2i in (("sorted", torch.tensor([0, 0, 1, 1, 1, 2, 2])), ("unsorted", torch.tensor([2, 0, 1, 0, 2, 1, 0]))):
+        for HH, WW in ((8, 8), (5, 7), (32, 32)):
+            f1 = feats.clone().requires_grad_(True)
+            y_ref = ref_b.crop_bbox_batch(f1, boxes, o2i, HH, WW)
+            gy = rn(*y_ref.shape)
+            y_ref.backward(gy)
+            f2 = feats.clone().requires_grad_(True)
+            y_or = OG.crop_boxes(f2, boxes, o2i, HH, WW)
+            y_or.backward(gy)
+            check(f"crop {tag} {HH}x{WW} fwd", y_or, y_ref)
+            check(f"crop {tag} {HH}x{WW} dfeats", f2.grad, f1.grad)
+            k = f"crop_{tag}_{HH}x{WW}"
+            out[k + "_y"], out[k + "_gy"], out[k + "_dfeats"] = np32(y_ref), np32(gy), np32(f1.grad)
+        out[f"crop_{tag}_o2i"] = o2i.numpy()
+    out["crop_feats"], out["crop_boxes"] = np32(feats), np32(boxes)
+
+    # ---- ConditionalBatchNorm2d: train forward, grads, running stats after 1 and 3 calls
+    cbn = filled(ref_g64.ConditionalBatchNorm2d(6, 5))
+    P = sub(cbn.state_dict(), "n.")
+    x = rn(7, 6, 5, 4)
+    y_lab = torch.tensor([0, 4, 2, 2, 1, 3, 0])
+    gy = rn(7, 6, 5, 4)
+    xr = x.clone().requires_grad_(True)
+    yr = cbn(xr, y_lab)
+    yr.backward(gy)
+    xo = x.clone().requires_grad_(True)
+    yo = OG.cond_bn(P, "n.", xo, y_lab, True)
+    yo.backward(gy)
+    check("condbn fwd", yo, yr)
+    check("condbn dx", xo.grad, xr.grad)
+    check("condbn dembed", P["n.embed.weight"].grad, cbn.embed.weight.grad)
+    out.update(cbn_x=np32(x), cbn_labels=y_lab.numpy(), cbn_gy=np32(gy), cbn_y=np32(yr), cbn_dx=np32(xr.grad),
+               cbn_dembed=np32(cbn.embed.weight.grad), cbn_embed=np32(cbn.embed.weight),
+               cbn_rm0=np32(fill_state(cbn.state_dict())["bn.running_mean"]),
+               cbn_rv0=np32(fill_state(cbn.state_dict())["bn.running_var"]),
+               cbn_rm1=np32(cbn.bn.running_mean), cbn_rv1=np32(cbn.bn.running_var))
+    for _ in range(2):
+        cbn(x * 1.5 + 0.3, y_lab)
+        OG.cond_bn(P, "n.", x * 1.5 + 0.3, y_lab, True)
+    check("condbn running_var after 3", P["n.bn.running_var"], cbn.bn.running_var)
+    out.update(cbn_rm3=np32(cbn.bn.running_mean), cbn_rv3=np32(cbn.bn.running_var))
+
+    # ---- SPADE (C=16; S=8 and S=16)
+    for S in (8, 16):
+        sp = filled(RefSPADE(16, 64))
+        P = sub(sp.state_dict(), "s.")
+        x, seg, gy = rn(3, 16, S, S), rn(3, 64, 8, 8), rn(3, 16, S, S)
+        xr, sr = x.clone().requires_grad_(True), seg.clone().requires_grad_(True)
+        yr = sp(xr, sr)
+        yr.backward(gy)
+        xo, so = x.clone().requires_grad_(True), seg.clone().requires_grad_(True)
+        yo = OG.spade(P, "s.", xo, so, True)
+        yo.backward(gy)
+        check(f"spade S={S} fwd", yo, yr)
+        check(f"spade S={S} dx", xo.grad, xr.grad)
+        check(f"spade S={S} dseg", so.grad, sr.grad, 1e-5)
+        check(f"spade S={S} dWgamma", P["s.mlp_gamma.weight"].grad, sp.mlp_gamma.weight.grad, 1e-5)
+        k = f"spade{S}_"
+        out.update({k + "x": np32(x), k + "seg": np32(seg), k + "gy": np32(gy), k + "y": np32(yr),
+                    k + "dx": np32(xr.grad), k + "dseg": np32(sr.grad),
+                    k + "dWshared": np32(sp.mlp_shared[0].weight.grad), k + "dWgamma": np32(sp.mlp_gamma.weight.grad),
+                    k + "dbbeta": np32(sp.mlp_beta.bias.grad), k + "rv1": np32(sp.param_free_norm.running_var)})
+
+    # ---- LayoutConvLSTM, ragged runs P=[3,1,9,5], small widths
+    cl = filled(ref_g64.LayoutConvLSTM(8, 12, [8, 4, 4], (5, 5)))
+    P = sub(cl.state_dict(), "c.")
+    o2i = torch.tensor([0] * 3 + [1] + [2] * 9 + [3] * 5)
+    x, gy = rn(18, 12, 8, 8), rn(4, 4, 8, 8)
+    xr = x.clone().requires_grad_(True)
+    yr = cl(xr, o2i)
+    yr.backward(gy)
+    xo = x.clone().requires_grad_(True)
+    yo = OG.conv_lstm_fuse(P, "c.", xo, o2i, (8, 4, 4))
+    yo.backward(gy)
+    check("convlstm fwd", yo, yr)
+    check("convlstm dx", xo.grad, xr.grad)
+    check("convlstm dW0", P["c.cell_list.0.conv.weight"].grad, cl.cell_list[0].conv.weight.grad, 1e-5)
+    out.update(clstm_x=np32(x), clstm_o2i=o2i.numpy(), clstm_gy=np32(gy), clstm_y=np32(yr), clstm_dx=np32(xr.grad),
+               clstm_dW0=np32(cl.cell_list[0].conv.weight.grad), clstm_db2=np32(cl.cell_list[2].conv.bias.grad),
+               clstm_dW2=np32(cl.cell_list[2].conv.weight.grad))
+
+    # ---- D blocks with spectral norm (incl. the in-place ReLU aliasing of ResidualBlock)
+    for tag, mod, down in (("opt_down", ref_d.OptimizedBlock(3, 8, downsample=True), True),
+                           ("opt_flat", ref_d.OptimizedBlock(3, 8, downsample=False), False)):
+        m = ref_d.add_sn(mod)
+        m.load_state_dict(fill_state(m.state_dict()))
+        P = sub(m.state_dict(), "main.0.")
+        x, gy = rn(2, 3, 8, 8), rn(2, 8, 4 if down else 8, 4 if down else 8)
+        xr = x.clone().requires_grad_(True)
+        yr = m(xr)
+        yr.backward(gy)
+        xo = x.clone().requires_grad_(True)
+        yo = OG.d_first_block(P, "main.0.", xo, down, True)
+        yo.backward(gy)
+        check(f"D {tag} fwd", yo, yr)
+        check(f"D {tag} dx", xo.grad, xr.grad, 1e-5)
+        check(f"D {tag} dW", P["main.0.resi.2.weight_orig"].grad, m.resi[2].weight_orig.grad, 1e-5)
+        out.update({f"d{tag}_x": np32(x), f"d{tag}_gy": np32(gy), f"d{tag}_y": np32(yr), f"d{tag}_dx": np32(xr.grad),
+                    f"d{tag}_dW2": np32(m.resi[2].weight_orig.grad), f"d{tag}_dWsc": np32(m.sc.weight_orig.grad),
+                    f"d{tag}_u0": np32(m.resi[0].weight_u)})
+    m = ref_d.add_sn(ref_d.ResidualBlock(8, 16, downsample=True))
+    m.load_state_dict(fill_state(m.state_dict()))
+    P = sub(m.state_dict(), "main.1.")
+    x, gy = rn(2, 8, 8, 8), rn(2, 16, 4, 4)
+    xr = x.clone().requires_grad_(True)
+    yr = m(xr * 1.0)          # * 1.0: the in-place ReLU may not hit a leaf
+    yr.backward(gy)
+    xo = x.clone().requires_grad_(True)
+    yo = OG.d_res_block(P, "main.1.", xo, True)
+    yo.backward(gy)
+    check("D res fwd (aliased shortcut)", yo, yr)
+    check("D res dx", xo.grad, xr.grad, 1e-5)
+    out.update(dres_x=np32(x), dres_gy=np32(gy), dres_y=np32(yr), dres_dx=np32(xr.grad),
+               dres_dW3=np32(m.resi[3].weight_orig.grad), dres_dWsc=np32(m.sc.weight_orig.grad))
+    for k in range(2, 8):      # SN state after k forwards
+        with torch.no_grad():
+            m(x.clone())
+            OG.d_res_block(P, "main.1.", x.clone(), True)
+        if k in (3, 7):
+            check(f"SN u after {k} forwards", P["main.1.resi.3.weight_u"], m.resi[3].weight_u)
+            out[f"dres_u3_after{k}"] = np32(m.resi[3].weight_u)
+            out[f"dres_v3_after{k}"] = np32(m.resi[3].weight_v)
+
+    # ---- whole discriminators at conv_dim = 8
+    for tag, mod, fn, shape in (
+            ("dimg", ref_d.ImageDiscriminator(conv_dim=8), lambda P, x: OG.image_discriminator(P, x, True), (3, 3, 64, 64)),
+            ("dobj", ref_d.ObjectDiscriminator(conv_dim=8, n_class=10), lambda P, x: OG.object_discriminator(P, x, True)[1], (3, 3, 32, 32)),
+            ("datt", ref_d.AttributeDiscriminator(conv_dim=8, n_attribute=12), lambda P, x: OG.attribute_discriminator(P, x, True, False), (3, 3, 32, 32)),
+            ("datt128", ref_d.AttributeDiscriminator128(conv_dim=8, n_attribute=12), lambda P, x: OG.attribute_discriminator(P, x, True, True), (2, 3, 64, 64))):
+        m = ref_d.add_sn(mod)
+        m.load_state_dict(fill_state(m.state_dict()))
+        P = sub(m.state_dict())
+        x = rn(*shape)
+        xr = x.clone().requires_grad_(True)
+        yr = m(xr)
+        yr = yr[1] if isinstance(yr, tuple) else yr
+        gy = rn(*yr.shape)
+        yr.backward(gy)
+        xo = x.clone().requires_grad_(True)
+        yo = fn(P, xo)
+        yo.backward(gy)
+        check(f"{tag}(conv_dim=8) fwd", yo, yr, 1e-5)
+        check(f"{tag}(conv_dim=8) dx", xo.grad, xr.grad, 1e-5)
+        out.update({f"{tag}_x": np32(x), f"{tag}_gy": np32(gy), f"{tag}_y": np32(yr), f"{tag}_dx": np32(xr.grad)})
+    np.savez_compressed(os.path.join(OUT, "ops_small.npz"), **out)
+    print(f"  wrote ops_small.npz ({len(out)} arrays)")
+
+
+# =========================================================================== full step
+class ReferenceBackend:
+    """The imported reference nn.Modules behind the backend interface of oracle.step.run_step."""
+
+    def __init__(self, gmod, res128, obj_size, n_classes, n_attr, z_dim):
+        self.gmod, self.obj_size = gmod, obj_size
+        self.netG = filled(gmod.Generator(num_embeddings=n_classes, obj_att_dim=64, z_dim=z_dim, clstm_layers=3,
+                                          obj_size=obj_size, attribute_dim=n_attr))
+        att_cls = ref_d.AttributeDiscriminator128 if res128 else ref_d.AttributeDiscriminator
+        self.netDi = ref_d.add_sn(ref_d.ImageDiscriminator(conv_dim=64))
+        self.netDo = ref_d.add_sn(ref_d.ObjectDiscriminator(n_class=n_classes))
+        self.netDa = ref_d.add_sn(att_cls(n_attribute=n_attr))
+        for m in (self.netDi, self.netDo, self.netDa):
+            m.load_state_dict(fill_state(m.state_dict()))
+        mk = lambda m: torch.optim.Adam(m.parameters(), OS.LR, list(OS.BETAS))
+        self.opts = [mk(self.netG), mk(self.netDi), mk(self.netDo), mk(self.netDa)]
+
+    def crop(self, feats, boxes, o2i):
+        return ref_b.crop_bbox_batch(feats, boxes, o2i, self.obj_size)
+
+    def gen(self, b, eps):
+        it = iter(eps)
+        saved = self.gmod.get_z_random
+        self.gmod.get_z_random = lambda n, d, random_type="gauss": next(it).clone()   # pin the CPU randn draws
+        try:
+            return self.netG(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                             b["masks_shift"], b["boxes_shift"], b["attribute_est"])
+        finally:
+            self.gmod.get_z_random = saved
+
+    def d_img(self, x):
+        return self.netDi(x)
+
+    def d_obj(self, x, objs):
+        return self.netDo(x, objs)
+
+    def d_att(self, x):
+        return self.netDa(x)
+
+    def zero_d(self):
+        self.netDi.zero_grad(); self.netDo.zero_grad(); self.netDa.zero_grad()
+
+    def zero_g(self):
+        self.netG.zero_grad()
+
+    def step_d(self):
+        for o in self.opts[1:]:
+            o.step()
+
+    def step_g(self):
+        self.opts[0].step()
+
+    def states(self):
+        return {"G": self.netG.state_dict(), "D_img": self.netDi.state_dict(), "D_obj": self.netDo.state_dict(),
+                "D_att": self.netDa.state_dict()}
+
+    def named_grads(self):
+        return {"G": dict(self.netG.named_parameters()), "D_img": dict(self.netDi.named_parameters()),
+                "D_obj": dict(self.netDo.named_parameters()), "D_att": dict(self.netDa.named_parameters())}
+
+
+def _checksums(state):
+    """Per-tensor (sum, abs-sum) in float64, in state_dict order."""
+    return np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in state.values()], np.float64)
+
+
+def full_step(tag, res, n_images, ppi, n_steps):
+    print(f"[step {tag}] {res}px N={n_images} objs/img={ppi}")
+    res128 = res == 128
+    obj_size = 64 if res128 else 32
+    gmod = ref_g128 if res128 else ref_g64
+    batch_np = synth.make_batch(n_images, res, seed=1234, objs_per_image=ppi)
+    b = {k: T(v) for k, v in batch_np.items()}
+    O = b["objs"].shape[0]
+    pos_weight = T(synth.make_pos_weight())
+    rb = ReferenceBackend(gmod, res128, obj_size, synth.NUM_OBJECT_CLASSES, synth.NUM_ATTRIBUTES, 64)
+    st = rb.states()
+    ob = OS.OracleBackend(st["G"], st["D_img"], st["D_obj"], st["D_att"], res128=res128, obj_size=obj_size)
+    out = dict(objs_per_image=np.asarray(ppi), pos_weight=np32(pos_weight), res=np.int64(res))
+    out.update({"batch_" + k: v for k, v in batch_np.items()})
+    g = torch.Generator().manual_seed(99)
+    for s in range(n_steps):
+        eps_d = [torch.randn(O, 64, generator=g) for _ in range(3)]
+        eps_g = [torch.randn(O, 64, generator=g) for _ in range(3)]
+        grads_ref, grads_or = {}, {}
+
+        def grab_ref(which):
+            def f(be):
+                for net in which:
+                    grads_ref[net] = {k: p.grad.detach().clone() for k, p in be.named_grads()[net].items()}
+            return f
+
+        def grab_or(which):
+            def f(be):
+                for net in which:
+                    grads_or[net] = {k: v.grad.detach().clone() for k, v in be.states()[net].items() if v.requires_grad}
+            return f
+
+        t0 = time.time()
+        l_ref, o_ref = OS.run_step(rb, b, pos_weight, eps_d, eps_g, on_d_backward=grab_ref(["D_img", "D_obj", "D_att"]),
+                                   on_g_backward=grab_ref(["G"]))
+        t1 = time.time()
+        l_or, o_or = OS.run_step(ob, b, pos_weight, eps_d, eps_g, on_d_backward=grab_or(["D_img", "D_obj", "D_att"]),
+                                 on_g_backward=grab_or(["G"]))
+        print(f"  step {s}: reference {t1 - t0:.1f}s, oracle {time.time() - t1:.1f}s")
+        for k in l_ref:
+            d = abs(l_ref[k] - l_or[k])
+            print(f"  loss {k:28s} ref {l_ref[k]: .6f}  oracle {l_or[k]: .6f}  |d| {d:.2e}")
+            assert d <= 1e-5 * max(1.0, abs(l_ref[k])), k
+        names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift",
+                 "mu", "logvar", "z_rand_rec", "z_rand_shift"]
+        for n, a, r in zip(names, o_or, o_ref):
+            check(f"G out {n}", a, r, 1e-5)
+        worst = 0.0
+        for net in grads_ref:
+            for k, gr in grads_ref[net].items():
+                go = grads_or[net][k]
+                rel = float((go - gr).norm() / (gr.norm() + 1e-12))
+                worst = max(worst, rel)
+                assert rel <= 2e-4, (net, k, rel)
+        print(f"  worst per-tensor grad rel-L2 diff oracle vs reference: {worst:.2e}")
+        st_ref, st_or = rb.states(), ob.states()
+        for net in st_ref:
+            for k, v in st_ref[net].items():
+                if v.is_floating_point():
+                    d = maxdiff(st_or[net][k], v)
+                    assert d <= 2e-5 * max(1.0, float(v.abs().max())), (net, k, d)
+        p = f"s{s}_"
+        out[p + "eps_d"] = np.stack([np32(e) for e in eps_d])
+        out[p + "eps_g"] = np.stack([np32(e) for e in eps_g])
+        out[p + "loss_names"] = np.array(list(l_ref.keys()))
+        out[p + "loss_values"] = np.array([l_ref[k] for k in l_ref], np.float64)
+        for n, r in zip(names, o_ref):
+            if n.startswith("crops"):
+                out[p + "out_" + n + "_sum"] = np.array([float(r.double().sum()), float(r.double().abs().sum())])
+                out[p + "out_" + n + "_head"] = np32(r[:2])
+            else:
+                out[p + "out_" + n] = np32(r)
+        for net in grads_ref:
+            out[p + f"gradnorm_{net}"] = np.array([float(gr.double().norm()) for gr in grads_ref[net].values()])
+            out[p + f"gradnames_{net}"] = np.array(list(grads_ref[net].keys()))
+        for net in st_ref:
+            out[p + f"state_{net}"] = _checksums(st_ref[net])
+            out[p + f"statenames_{net}"] = np.array(list(st_ref[net].keys()))
+        # a few full tensors after the optimiser step, for element-wise checks
+        out[p + "G_decoder_c4_bias"] = np32(st_ref["G"]["decoder.c4.bias"])
+        out[p + "G_spade3_running_var"] = np32(st_ref["G"]["decoder.spade_3.param_free_norm.running_var"])
+        out[p + "G_bn4_running_mean"] = np32(st_ref["G"]["layout_encoder.bn4.bn.running_mean"])
+        out[p + "Dimg_classifier_u"] = np32(st_ref["D_img"]["classifier.weight_u"])
+        out[p + "Dobj_main4_resi3_u"] = np32(st_ref["D_obj"]["main.4.resi.3.weight_u"])
+        out[p + "Datt_main0_resi0_bias"] = np32(st_ref["D_att"]["main.0.resi.0.bias"])
+    np.savez_compressed(os.path.join(OUT, f"step{tag}.npz"), **out)
+    print(f"  wrote step{tag}.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-ops", action="store_true")
+    ap.add_argument("--skip-step64", action="store_true")
+    ap.add_argument("--skip-step128", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    if not a.skip_ops:
+        ops_small()
+    if not a.skip_step64:
+        full_step("64", 64, 4, [3, 9, 5, 7], 2)          # BASELINE config 1
+    if not a.skip_step128:
+        full_step("128", 128, 2, [4, 6], 1)
+
+
+if __name__ == "__main__":
+    main()
