@@ -1,0 +1,155 @@
+"""Spectral-normalised ResNet discriminators (image / object / attribute) on the HIP kernels.
+
+Names, constructor arguments and state_dict layout follow reference models/discriminator.py
+(:29-60 OptimizedBlock, :63-99 ResidualBlock, :102-181 AttributeDiscriminator[128], :184-230
+ImageDiscriminator, :233-278 ObjectDiscriminator, :15-22 add_sn).  Differences are legal algebraic
+fusions only: bias+ReLU in the conv epilogue, the block-leading in-place ReLU folded into the conv
+gathers (so the shortcut also reads relu(x), as the reference's aliasing makes it), the 1x1 shortcut
+conv applied after the 2x2 average pool and accumulated straight into the residual branch, and one
+batched spectral-norm kernel sequence per forward call.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import nn as A
+
+
+def add_sn(m):
+    """Reference add_sn (discriminator.py:15-22): children first, then the module itself."""
+    for name, c in m.named_children():
+        m.add_module(name, add_sn(c))
+    if isinstance(m, (nn.Conv2d, nn.Linear)):
+        return A.apply_spectral_norm(m)
+    if isinstance(m, (nn.ConvTranspose2d, nn.Embedding)):
+        raise NotImplementedError("spectral norm on ConvTranspose2d/Embedding is not on the reference path")
+    return m
+
+
+def _w(W, mod):
+    return None if W is None else W.get(id(mod))
+
+
+class OptimizedBlock(nn.Module):
+    def __init__(self, dim_in, dim_out, downsample=False):
+        super().__init__()
+        self.downsample = downsample
+        self.resi = nn.Sequential(A.Conv2d(dim_in, dim_out, kernel_size=3, stride=1, padding=1, bias=True),
+                                  nn.ReLU(inplace=True),
+                                  A.Conv2d(dim_out, dim_out, kernel_size=3, stride=1, padding=1, bias=True))
+        self.learnable_sc = (dim_in != dim_out) or downsample
+        if self.learnable_sc:
+            self.sc = A.Conv2d(dim_in, dim_out, kernel_size=1, padding=0, bias=True)
+
+    def forward(self, x, W=None):
+        h = self.resi[0](x, relu=True, weight=_w(W, self.resi[0]))
+        h = self.resi[2](h, weight=_w(W, self.resi[2]))
+        s = x
+        if self.downsample:
+            h = F.avg_pool2(h)
+            s = F.avg_pool2(x)
+        return self.sc(s, addend=h, weight=_w(W, self.sc))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, dim_in, dim_out, downsample=False):
+        super().__init__()
+        self.downsample = downsample
+        self.resi = nn.Sequential(nn.ReLU(inplace=True),
+                                  A.Conv2d(dim_in, dim_in, kernel_size=3, stride=1, padding=1, bias=True),
+                                  nn.ReLU(inplace=True),
+                                  A.Conv2d(dim_in, dim_out, kernel_size=3, stride=1, padding=1, bias=True))
+        self.learnable_sc = (dim_in != dim_out) or downsample
+        if self.learnable_sc:
+            self.sc = A.Conv2d(dim_in, dim_out, kernel_size=1, padding=0, bias=True)
+
+    def forward(self, x, W=None):
+        if not self.learnable_sc:
+            raise NotImplementedError("identity-shortcut blocks are not on the reference path")
+        h = self.resi[1](x, in_relu=True, relu=True, weight=_w(W, self.resi[1]))
+        h = self.resi[3](h, weight=_w(W, self.resi[3]))
+        if self.downsample:
+            h = F.avg_pool2(h)
+            return self.sc(F.avg_pool2(x, in_relu=True), addend=h, weight=_w(W, self.sc))
+        return self.sc(x, in_relu=True, addend=h, weight=_w(W, self.sc))
+
+
+class _Discriminator(nn.Module):
+    def _sn_modules(self):
+        return [m for m in self.modules() if getattr(m, "has_sn", False)]
+
+    def _weights(self):
+        mods = self._sn_modules()
+        if not mods:
+            return None
+        ws = F.spectral_norm_weights([m.weight_orig for m in mods], [m.weight_u for m in mods],
+                                     [m.weight_v for m in mods], self.training)
+        return {id(m): w for m, w in zip(mods, ws)}
+
+    def _trunk(self, x, W):
+        A._need_device(x)
+        h = x
+        for blk in self.main:
+            h = blk(h, W)
+        return F.sum_hw(h, in_relu=True)
+
+
+class ImageDiscriminator(_Discriminator):
+    def __init__(self, conv_dim=64):
+        super().__init__()
+        self.ch = conv_dim
+        c = conv_dim
+        self.relu = nn.ReLU(inplace=True)
+        self.main = nn.Sequential(OptimizedBlock(3, c, downsample=True), ResidualBlock(c, c * 2, downsample=True),
+                                  ResidualBlock(c * 2, c * 4, downsample=True), ResidualBlock(c * 4, c * 8, downsample=True),
+                                  ResidualBlock(c * 8, c * 16, downsample=True))
+        self.classifier = A.Linear(c * 16, 1, bias=False)
+
+    def forward(self, x):
+        W = self._weights()
+        f = self._trunk(x, W)
+        return self.classifier(f, weight=_w(W, self.classifier)).view(-1)
+
+
+class ObjectDiscriminator(_Discriminator):
+    def __init__(self, conv_dim=64, n_class=0, downsample_first=False, n_attribute=128):
+        super().__init__()
+        c = conv_dim
+        self.relu = nn.ReLU(inplace=True)
+        self.main = nn.Sequential(OptimizedBlock(3, c, downsample=downsample_first), ResidualBlock(c, c * 2, downsample=True),
+                                  ResidualBlock(c * 2, c * 4, downsample=True), ResidualBlock(c * 4, c * 8, downsample=True),
+                                  ResidualBlock(c * 8, c * 16, downsample=True))
+        self.classifier_src = A.Linear(c * 16, 1)
+        self.classifier_cls = A.Linear(c * 16, n_class)
+
+    def forward(self, x, y=None):
+        W = self._weights()
+        f = self._trunk(x, W)
+        src = self.classifier_src(f, weight=_w(W, self.classifier_src)).view(-1)
+        return src, self.classifier_cls(f, weight=_w(W, self.classifier_cls))
+
+
+class AttributeDiscriminator(_Discriminator):
+    n_extra = 0
+
+    def __init__(self, conv_dim=64, downsample_first=False, n_attribute=128):
+        super().__init__()
+        c = conv_dim
+        self.relu = nn.ReLU(inplace=True)
+        blocks = [OptimizedBlock(3, c, downsample=downsample_first), ResidualBlock(c, c * 2, downsample=True),
+                  ResidualBlock(c * 2, c * 4, downsample=True), ResidualBlock(c * 4, c * 8, downsample=True),
+                  ResidualBlock(c * 8, c * 16, downsample=True)]
+        blocks += [ResidualBlock(c * 16, c * 16, downsample=True) for _ in range(self.n_extra)]
+        self.main = nn.Sequential(*blocks)
+        self.classifier_att = A.Linear(c * 16, n_attribute)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        W = self._weights()
+        return self.classifier_att(self._trunk(x, W), weight=_w(W, self.classifier_att))
+
+
+class AttributeDiscriminator128(AttributeDiscriminator):
+    n_extra = 1

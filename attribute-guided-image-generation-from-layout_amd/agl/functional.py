@@ -1,0 +1,379 @@
+"""Differentiable ops of the G+D path: torch.autograd.Function shells around the HIP kernels.
+
+autograd is used as plumbing only (graph bookkeeping); every forward and backward body is a
+sequence of libagl.so launches (agl.lib).  Reference call sites are cited per op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+BN_EPS, BN_MOMENTUM, SN_EPS = 1e-5, 0.1, 1e-12
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- convolution
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu):
+        x, w = _c(x), _c(w)
+        if addend is not None:
+            assert not relu, "addend with fused ReLU is not supported"
+            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, False, out=addend, accumulate=True)
+            ctx.mark_dirty(addend)
+        else:
+            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, relu)
+        ctx.cfg = (stride, pad, up, in_relu, relu, bias is not None, addend is not None)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, up, in_relu, relu, has_bias, has_add = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        g = L.relu_bwd(dy, y) if relu else dy
+        ks = w.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if up:
+                H, W = x.shape[2] << up, x.shape[3] << up
+                dxu = L.conv2d_bwd_data(g, w, (H, W), stride, pad)
+                dx = L.upsample_bwd(dxu, up)
+                assert not in_relu
+            else:
+                dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if in_relu else None)
+        if ctx.needs_input_grad[1]:
+            dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = L.channel_sum(g)
+        dadd = dy if (has_add and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dadd, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, up=0, in_relu=False, relu=False, addend=None):
+    """nn.Conv2d forward (+ optional fused input ReLU / nearest up-sampling of x, output ReLU, and
+    accumulation into `addend`, which is consumed in place)."""
+    return _Conv2d.apply(x, w, bias, addend, stride, padding, up, in_relu, relu)
+
+
+def linear(x, w, bias=None, relu=False):
+    """nn.Linear as a 1x1 convolution over (rows, features, 1, 1)."""
+    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), bias, relu=relu)
+    return y.reshape(y.shape[0], y.shape[1])
+
+
+class _ConvT4s2(torch.autograd.Function):
+    """nn.ConvTranspose2d(k=4, s=2, p=1, bias=False) (generator_obj_att.py:532-540): the forward is the
+    input-gradient pass of the matching stride-2 convolution, run one 2x2-tap phase per output parity."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _c(x), _c(w)
+        ctx.save_for_backward(x, w)
+        return L.conv2d_bwd_data(x, w, (2 * x.shape[2], 2 * x.shape[3]), 2, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = L.conv2d_fwd(dy, w, None, 2, 1) if ctx.needs_input_grad[0] else None
+        dw = L.conv2d_bwd_weight(x, dy, 4, 2, 1) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv_transpose2d_k4s2p1(x, w):
+    return _ConvT4s2.apply(x, w)
+
+
+# --------------------------------------------------------------------------- normalisation
+class _NormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training):
+        x = _c(x)
+        if training:
+            mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
+        else:
+            mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
+        p0c = _c(p0) if p0 is not None else None
+        y = L.norm_apply_fwd(x, mean, rstd, mode, p0c, p1, labels, _c(residual) if residual is not None else None, relu)
+        ctx.cfg = (mode, relu, training, residual is not None)
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, p0c, p1, labels)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, relu, training, has_res = ctx.cfg
+        x, y, mean, rstd, p0, p1, labels = ctx.saved_tensors
+        dy = _c(dy)
+        dp0 = dp1 = None
+        if mode == 1:
+            dp0, dp1 = torch.empty_like(p0), torch.empty_like(p1)
+        elif mode == 2:
+            dp0 = torch.zeros_like(p0)
+        elif mode == 3:
+            dp0 = torch.empty_like(p0)
+        dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1)
+        dres = None
+        if has_res and ctx.needs_input_grad[3]:
+            dres = L.relu_bwd(dy, y) if relu else dy
+        return dx, dp0, dp1, dres, None, None, None, None, None, None, None
+
+
+def batch_norm(x, rmean, rvar, nbt, weight=None, bias=None, relu=False, residual=None, training=True):
+    """nn.BatchNorm2d / nn.BatchNorm1d (+ReLU, +residual add)."""
+    mode = 1 if weight is not None else 0
+    return _NormAct.apply(x, weight, bias, residual, None, rmean, rvar, nbt, mode, relu, training)
+
+
+def cond_batch_norm(x, table, labels, rmean, rvar, nbt, relu=False, training=True):
+    """ConditionalBatchNorm2d (generator_obj_att.py:31-44): gamma|beta rows of `table` picked by labels."""
+    return _NormAct.apply(x, table, None, None, labels, rmean, rvar, nbt, 2, relu, training)
+
+
+def spade_modulate(x, gb, rmean, rvar, nbt, relu=False, training=True):
+    """SPADE apply (normalization.py:97,106): y = BN(x) * (1 + gamma) + beta with gb = [gamma; beta]."""
+    return _NormAct.apply(x, gb, None, None, None, rmean, rvar, nbt, 3, relu, training)
+
+
+# --------------------------------------------------------------------------- crop
+class _Crop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, boxes, o2i, HH, WW, align):
+        feats, boxes = _c(feats), _c(boxes)
+        ctx.cfg = (tuple(feats.shape), align)
+        ctx.save_for_backward(boxes, o2i)
+        return L.crop_fwd(feats, boxes, o2i, HH, WW, align)
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, align = ctx.cfg
+        boxes, o2i = ctx.saved_tensors
+        return L.crop_bwd(_c(dout), boxes, o2i, shape, align), None, None, None, None, None
+
+
+def crop_boxes(feats, boxes, box_to_img_dev, HH, WW=None, align_corners=False):
+    return _Crop.apply(feats, boxes, box_to_img_dev, HH, HH if WW is None else WW, align_corners)
+
+
+# --------------------------------------------------------------------------- pooling / resampling
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, in_relu):
+        x = _c(x)
+        ctx.in_relu = in_relu
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(x if in_relu else None)
+        return L.avgpool2_fwd(x, in_relu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return L.avgpool2_bwd(_c(dy), x if ctx.in_relu else ctx.shape, ctx.in_relu), None
+
+
+def avg_pool2(x, in_relu=False):
+    return _AvgPool2.apply(x, in_relu)
+
+
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return L.upsample_fwd(_c(x), k)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return L.upsample_bwd(_c(dy), ctx.k), None
+
+
+def upsample_nearest(x, log2_factor):
+    return _Upsample.apply(x, log2_factor)
+
+
+class _SumHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, in_relu, scale):
+        x = _c(x)
+        ctx.cfg = (in_relu, scale)
+        ctx.save_for_backward(x)
+        return L.sum_hw_fwd(x, in_relu, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        in_relu, scale = ctx.cfg
+        (x,) = ctx.saved_tensors
+        return L.sum_hw_bwd(_c(dy), x, in_relu, scale), None, None
+
+
+def sum_hw(x, in_relu=False, scale=1.0):
+    """(N,C,H,W) -> (N,C): scale * sum over H,W of (relu)(x)."""
+    return _SumHW.apply(x, in_relu, scale)
+
+
+class _Reparam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _c(mu), _c(logvar), _c(eps)
+        ctx.save_for_backward(logvar, eps)
+        z = torch.empty_like(mu)
+        L.call("agl_reparam_fwd", L.ptr(mu), L.ptr(logvar), L.ptr(eps), L.ptr(z), mu.numel(), L.stream())
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = _c(dz)
+        dlv = torch.empty_like(dz)
+        L.call("agl_reparam_bwd", L.ptr(dz), L.ptr(logvar), L.ptr(eps), L.ptr(dlv), dz.numel(), L.stream())
+        return dz, dlv, None
+
+
+def reparameterize(mu, logvar, eps):
+    return _Reparam.apply(mu, logvar, eps)
+
+
+class _MaskOuter(torch.autograd.Function):
+    """u (O,C) x zero-padded mask (O,1,R,R) -> (O,C,R+2p,R+2p): LayoutEncoder's rank-1 input pushed
+    through its 1x1/pad-1 convolution without building the (O,128,R,R) tensor."""
+
+    @staticmethod
+    def forward(ctx, u, mask, pad):
+        u, mask = _c(u), _c(mask)
+        O, Cc = u.shape
+        R = mask.shape[-1]
+        ctx.pad = pad
+        ctx.save_for_backward(mask)
+        y = torch.empty((O, Cc, R + 2 * pad, R + 2 * pad), dtype=torch.float32, device=u.device)
+        L.call("agl_mask_outer_fwd", L.ptr(u), L.ptr(mask), L.ptr(y), O, Cc, R, pad, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _c(dy)
+        O, Cc = dy.shape[0], dy.shape[1]
+        du = torch.empty((O, Cc), dtype=torch.float32, device=dy.device)
+        L.call("agl_mask_outer_bwd", L.ptr(dy), L.ptr(mask), L.ptr(du), O, Cc, mask.shape[-1], ctx.pad, L.stream())
+        return du, None, None
+
+
+def mask_outer(u, mask, pad=1):
+    return _MaskOuter.apply(u, mask, pad)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return L.axpby(_c(a), _c(b), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _GatherRows(torch.autograd.Function):
+    """Row gather (nn.Embedding lookup); backward is a fixed-order row accumulation."""
+
+    @staticmethod
+    def forward(ctx, table, rows):
+        table = _c(table)
+        ctx.n = table.shape[0]
+        ctx.save_for_backward(rows)
+        return L.gather_rows(table, rows)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rows,) = ctx.saved_tensors
+        dout = _c(dout)
+        # dtable[rows[r]] += dout[r]: reuse the conditional-norm channel kernel shape via index_add on device memory
+        dt = torch.zeros((ctx.n,) + tuple(dout.shape[1:]), dtype=dout.dtype, device=dout.device)
+        dt.index_add_(0, rows, dout)
+        return dt, None
+
+
+def embedding(table, rows):
+    return _GatherRows.apply(table, rows)
+
+
+# --------------------------------------------------------------------------- spectral norm
+class _SpectralNormWeights(torch.autograd.Function):
+    """All spectrally-normalised weights of one discriminator for ONE forward call
+    (torch.nn.utils.spectral_norm semantics: one power iteration per training forward)."""
+
+    @staticmethod
+    def forward(ctx, training, us, vs, *ws):
+        dev = ws[0].device
+        n = len(ws)
+        sizes = [w.numel() for w in ws]
+        rows = [w.shape[0] for w in ws]
+        cols = [s // r for s, r in zip(sizes, rows)]
+        arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        u_used = torch.empty(sum(rows), dtype=torch.float32, device=dev)
+        v_used = torch.empty(sum(cols), dtype=torch.float32, device=dev)
+        lib = L.load()
+        tmp_off, tot = [], 0
+        for r, c in zip(rows, cols):                      # every layer gets its own scratch slice
+            tmp_off.append(tot)
+            tot += lib.agl_sn_tmp_floats(r, c)
+        tmp = torch.empty(tot, dtype=torch.float32, device=dev)
+        descs = (L.SnLayer * n)()
+        outs, held, o, ro, co = [], [], 0, 0, 0
+        for i, w in enumerate(ws):
+            wc = _c(w)
+            held.append(wc)
+            d = descs[i]
+            d.w, d.u, d.v = L.ptr(wc), L.ptr(us[i]), L.ptr(vs[i])
+            d.w_sn = arena.data_ptr() + 4 * o
+            d.sigma = sigma.data_ptr() + 4 * i
+            d.tmp = tmp.data_ptr() + 4 * tmp_off[i]
+            d.u_used = u_used.data_ptr() + 4 * ro
+            d.v_used = v_used.data_ptr() + 4 * co
+            d.g, d.dw = None, None
+            d.rows, d.cols = rows[i], cols[i]
+            outs.append(arena[o:o + sizes[i]].view(w.shape))
+            o, ro, co = o + sizes[i], ro + rows[i], co + cols[i]
+        L.call("agl_sn_forward", C.cast(descs, C.c_void_p), n, int(training), SN_EPS, L.stream())
+        ctx.descs, ctx.keep = descs, (arena, sigma, u_used, v_used, tmp)
+        ctx.shapes = [tuple(w.shape) for w in ws]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        descs = ctx.descs
+        arena = ctx.keep[0]
+        n = len(gs)
+        dws = torch.empty_like(arena)
+        held, o = [], 0
+        for i, g in enumerate(gs):
+            if g is None:
+                g = torch.zeros(ctx.shapes[i], dtype=torch.float32, device=arena.device)
+            g = _c(g)
+            held.append(g)
+            descs[i].g = g.data_ptr()
+            descs[i].dw = dws.data_ptr() + 4 * o
+            o += g.numel()
+        L.call("agl_sn_backward", C.cast(descs, C.c_void_p), n, L.stream())
+        outs, o = [], 0
+        for i in range(n):
+            sz = held[i].numel()
+            outs.append(dws[o:o + sz].view(ctx.shapes[i]))
+            o += sz
+        return (None, None, None) + tuple(outs)
+
+
+def spectral_norm_weights(weights: Sequence[torch.Tensor], us: Sequence[torch.Tensor], vs: Sequence[torch.Tensor],
+                          training: bool = True) -> List[torch.Tensor]:
+    return list(_SpectralNormWeights.apply(training, list(us), list(vs), *weights))

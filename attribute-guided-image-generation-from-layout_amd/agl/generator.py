@@ -1,0 +1,319 @@
+"""The SPADE-conditioned generator (64 px and 128 px variants) on the HIP kernels.
+
+Module / attribute names follow the reference so `state_dict()` keys and `.parameters()` order match
+(models/generator_obj_att.py:603-647 and models/generator_obj_att128.py:635-679); forward bodies are
+sequences of agl.functional ops (fused conv / norm+ReLU / SPADE / ConvLSTM kernels).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import nn as A
+from .convlstm import SequencePlan, layout_conv_lstm
+
+
+def get_z_random(batch_size, z_dim, random_type="gauss"):
+    """Reference helper (generator_obj_att.py:10-15): drawn on the CPU generator, like the reference."""
+    if random_type == "uni":
+        return torch.rand(batch_size, z_dim) * 2.0 - 1.0
+    return torch.randn(batch_size, z_dim)
+
+
+class ConditionalBatchNorm2d(nn.Module):
+    """generator_obj_att.py:31-44; statistics + per-object gamma/beta (+ReLU) in fused kernels."""
+
+    def __init__(self, num_features, num_classes):
+        super().__init__()
+        self.num_features = num_features
+        self.bn = A.BatchNorm2d(num_features, affine=False)
+        self.embed = nn.Embedding(num_classes, num_features * 2)
+        self.embed.weight.data[:, :num_features].normal_(1, 0.02)
+        self.embed.weight.data[:, num_features:].zero_()
+
+    def forward(self, x, y, relu=False):
+        bn = self.bn
+        return F.cond_batch_norm(x, self.embed.weight, y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 relu, self.training)
+
+
+class ResidualBlock(nn.Module):
+    """generator_obj_att.py:47-60: x + BN(conv3(ReLU(BN(conv3(x)))))."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.main = nn.Sequential(
+            A.Conv2d(dim_in, dim_out, kernel_size=3, stride=1, padding=1, bias=False),
+            A.BatchNorm2d(dim_out, affine=True, track_running_stats=True),
+            nn.ReLU(inplace=True),
+            A.Conv2d(dim_out, dim_out, kernel_size=3, stride=1, padding=1, bias=False),
+            A.BatchNorm2d(dim_out, affine=True, track_running_stats=True))
+
+    def forward(self, x):
+        m = self.main
+        t = m[1](m[0](x), relu=True)
+        return m[4](m[3](t), residual=x)
+
+
+class ConvLSTMCell(nn.Module):
+    """Parameter holder for one ConvLSTM layer (generator_obj_att.py:63-118); the math runs in
+    agl.convlstm over whole sequences."""
+
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size, bias):
+        super().__init__()
+        self.height, self.width = input_size
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.kernel_size = kernel_size
+        self.padding = kernel_size[0] // 2, kernel_size[1] // 2
+        self.bias = bias
+        self.conv = A.Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size=kernel_size, padding=self.padding, bias=bias)
+
+
+class LayoutConvLSTM(nn.Module):
+    """generator_obj_att.py:232-346."""
+
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size, bias=True, return_all_layers=False):
+        super().__init__()
+        hidden_dim = list(hidden_dim) if isinstance(hidden_dim, (list, tuple)) else [hidden_dim]
+        if not (isinstance(kernel_size, tuple) or (isinstance(kernel_size, list) and all(isinstance(e, tuple) for e in kernel_size))):
+            raise ValueError('`kernel_size` must be tuple or list of tuples')
+        ks = kernel_size if isinstance(kernel_size, list) else [kernel_size] * len(hidden_dim)
+        if len(ks) != len(hidden_dim):
+            raise ValueError('Inconsistent list length.')
+        assert all(k == (5, 5) for k in ks) and bias, "the HIP sequence kernel covers the 5x5, biased cells the path uses"
+        self.height = self.width = input_size
+        self.input_dim, self.hidden_dim, self.kernel_size = input_dim, hidden_dim, ks
+        self.num_layers, self.bias, self.return_all_layers = len(hidden_dim), bias, return_all_layers
+        self.cell_list = nn.ModuleList(
+            [ConvLSTMCell((input_size, input_size), input_dim if i == 0 else hidden_dim[i - 1], hidden_dim[i], ks[i], bias)
+             for i in range(self.num_layers)])
+
+    def forward(self, obj_tensor, obj_to_img, hidden_state=None, plan: Optional[SequencePlan] = None):
+        if hidden_state is not None:
+            raise NotImplementedError()
+        if plan is None:
+            plan = SequencePlan(obj_to_img, obj_tensor.device)
+        return layout_conv_lstm(obj_tensor, plan, self.hidden_dim, [c.conv.weight for c in self.cell_list],
+                                [c.conv.bias for c in self.cell_list])
+
+
+class CropEncoder(nn.Module):
+    """generator_obj_att.py:367-422."""
+
+    def __init__(self, conv_dim=64, z_dim=8, class_num=10):
+        super().__init__()
+        assert class_num > 0, "the path uses the class-conditional branch"
+        d = conv_dim
+        self.c1 = A.Conv2d(3, d, kernel_size=7, stride=1, padding=3, bias=False)
+        self.bn1 = ConditionalBatchNorm2d(d, class_num)
+        self.c2 = A.Conv2d(d, d * 2, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn2 = ConditionalBatchNorm2d(d * 2, class_num)
+        self.c3 = A.Conv2d(d * 2, d * 4, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn3 = ConditionalBatchNorm2d(d * 4, class_num)
+        self.c4 = A.Conv2d(d * 4, d * 8, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn4 = ConditionalBatchNorm2d(d * 8, class_num)
+        self.conv5 = A.Conv2d(d * 8, d * 16, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn5 = ConditionalBatchNorm2d(d * 16, class_num)
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.fc_mu = A.Linear(d * 16, z_dim)
+        self.fc_logvar = A.Linear(d * 16, z_dim)
+
+    def forward(self, imgs, objs=None, eps=None):
+        x = imgs
+        for conv, bn in ((self.c1, self.bn1), (self.c2, self.bn2), (self.c3, self.bn3), (self.c4, self.bn4),
+                         (self.conv5, self.bn5)):
+            x = bn(conv(x), objs, relu=True)
+        x = F.sum_hw(x, False, 1.0 / (x.shape[2] * x.shape[3]))
+        mu, logvar = self.fc_mu(x), self.fc_logvar(x)
+        if eps is None:
+            eps = get_z_random(mu.size(0), mu.size(1))
+        z = F.reparameterize(mu, logvar, eps.to(mu.device))
+        return z, mu, logvar
+
+
+class GlobalEncoder(nn.Module):
+    """generator_obj_att.py:425-446."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = A.Conv2d(64, 128, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn1 = A.BatchNorm2d(128)
+        self.c2 = A.Conv2d(128, 128, kernel_size=4, stride=2, padding=1, bias=False)
+
+    def forward(self, h):
+        return F.sum_hw(self.c2(self.bn1(self.c1(h), relu=True)))
+
+
+class LayoutEncoder(nn.Module):
+    """generator_obj_att.py:449-513; the 128 px variant adds AdaptiveAvgPool2d(8) (generator_obj_att128.py:486,505)."""
+
+    def __init__(self, conv_dim=64, z_dim=8, obj_att_dim=64, class_num=10, resi_num=6, clstm_layers=3, att_dim=64,
+                 pool_to_8=False):
+        super().__init__()
+        hidden = {1: [64], 2: [64, 64], 3: [128, 64, 64]}[clstm_layers]
+        self.clstm = LayoutConvLSTM(8, 512, hidden, (5, 5))
+        self.residual = nn.Sequential(*[ResidualBlock(64, 64) for _ in range(resi_num)])
+        d = conv_dim
+        self.c0 = A.Conv2d(obj_att_dim + z_dim, d, kernel_size=1, stride=1, padding=1, bias=False)
+        self.bn1 = ConditionalBatchNorm2d(d, class_num)
+        self.c2 = A.Conv2d(d, d * 2, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn2 = ConditionalBatchNorm2d(d * 2, class_num)
+        self.c3 = A.Conv2d(d * 2, d * 4, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn3 = ConditionalBatchNorm2d(d * 4, class_num)
+        self.c4 = A.Conv2d(d * 4, d * 8, kernel_size=4, stride=2, padding=1, bias=False)
+        self.bn4 = ConditionalBatchNorm2d(d * 8, class_num)
+        if pool_to_8:
+            self.pool = nn.AdaptiveAvgPool2d(8)
+        self.pool_to_8 = pool_to_8
+
+    def forward(self, objs_att, masks, obj_to_img, z, objs, plan: Optional[SequencePlan] = None):
+        v = torch.cat((objs_att, z), dim=1)
+        assert self.c0.kernel_size == (1, 1) and self.c0.padding == (1, 1)
+        u = F.linear(v, self.c0.weight.view(self.c0.out_channels, -1))   # c0 on the rank-1 tensor v (x) mask
+        h = self.bn1(F.mask_outer(u, masks, 1), objs, relu=True)
+        h = self.bn2(self.c2(h), objs, relu=True)
+        h = self.bn3(self.c3(h), objs, relu=True)
+        h = self.bn4(self.c4(h), objs)
+        if self.pool_to_8:
+            assert h.shape[2] == 16, "AdaptiveAvgPool2d(8) is an exact 2x2 mean on the 16x16 map of the 128 px model"
+            h = F.avg_pool2(h)
+        h = self.clstm(h, obj_to_img, plan=plan)
+        return self.residual(h)
+
+
+class SPADE(nn.Module):
+    """models/spade/networks/normalization.py:66-108 with param_free_norm = BatchNorm2d (:70,77-78).
+    gamma and beta come from ONE 128->2C convolution whose output feeds the fused normalise-modulate(-ReLU)
+    kernel; the nearest up-sampling of the 8x8 segmentation map is folded into the first conv's gather."""
+
+    def __init__(self, norm_nc, label_nc):
+        super().__init__()
+        self.param_free_norm = A.BatchNorm2d(norm_nc, affine=False)
+        nhidden = 128
+        self.mlp_shared = nn.Sequential(A.Conv2d(label_nc, nhidden, kernel_size=3, padding=1), nn.ReLU())
+        self.mlp_gamma = A.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
+        self.mlp_beta = A.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
+
+    def forward(self, x, segmap, relu=False):
+        f = x.shape[2] // segmap.shape[2]
+        up = f.bit_length() - 1
+        assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
+        actv = self.mlp_shared[0](segmap, relu=True, up=up)
+        w = torch.cat((self.mlp_gamma.weight, self.mlp_beta.weight), dim=0)
+        b = torch.cat((self.mlp_gamma.bias, self.mlp_beta.bias), dim=0)
+        gb = F.conv2d(actv, w, b, 1, 1)
+        n = self.param_free_norm
+        return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training)
+
+
+class Decoder(nn.Module):
+    """generator_obj_att.py:516-572; 128 px tail generator_obj_att128.py:549-557, :587-604."""
+
+    def __init__(self, nf=64, conv_dim=64, res128=False):
+        super().__init__()
+        self.sw, self.sh, self.h_dim = 8, 8, 64
+        d = conv_dim
+        self.c0_new = A.Conv2d(d + 128, d * 4, kernel_size=3, stride=1, padding=1, bias=False)
+        self.spade_0 = SPADE(d * 4, self.h_dim)
+        self.dc1 = A.ConvTranspose2d(d * 4, d * 4, kernel_size=4, stride=2, padding=1, bias=False)
+        self.spade_1 = SPADE(d * 4, self.h_dim)
+        self.dc2 = A.ConvTranspose2d(d * 4, d * 2, kernel_size=4, stride=2, padding=1, bias=False)
+        self.spade_2 = SPADE(d * 2, self.h_dim)
+        self.dc3 = A.ConvTranspose2d(d * 2, d, kernel_size=4, stride=2, padding=1, bias=False)
+        self.spade_3 = SPADE(d, self.h_dim)
+        self.c4 = A.Conv2d(d, 3, kernel_size=7, stride=1, padding=3, bias=True)
+        self.res128 = res128
+        if res128:
+            self.c5 = A.Conv2d(3, d * 2, kernel_size=7, stride=1, padding=3, bias=False)
+            self.spade_4 = SPADE(d * 2, self.h_dim)
+            self.c6 = A.Conv2d(d * 2, d * 2, kernel_size=5, stride=1, padding=2, bias=False)
+            self.spade_5 = SPADE(d * 2, self.h_dim)
+            self.c7 = A.Conv2d(d * 2, 3, kernel_size=7, stride=1, padding=3, bias=True)
+
+    def forward(self, hidden, global_h, z=None):
+        seg = hidden
+        g = global_h.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 8, 8)
+        h = self.c0_new(torch.cat((hidden, g), dim=1))
+        h = self.spade_0(h, seg, relu=True)
+        h = self.spade_1(self.dc1(h), seg, relu=True)
+        h = self.spade_2(self.dc2(h), seg, relu=True)
+        h = self.spade_3(self.dc3(h), seg, relu=True)
+        h = self.c4(h)
+        if not self.res128:
+            return h
+        h = self.c5(h, up=1)                                   # nearest x2 folded into the 7x7 conv's gather
+        h = self.spade_4(h, seg, relu=True)
+        h = self.spade_5(self.c6(h), seg, relu=True)
+        return self.c7(h)
+
+
+class AttributeEncoder(nn.Module):
+    """generator_obj_att.py:575-600."""
+
+    def __init__(self, attribute_dim=106, embedding_dim=64, class_num=10):
+        super().__init__()
+        self.embedding = A.Embedding(class_num, embedding_dim)
+        self.c0 = A.Linear(attribute_dim + embedding_dim, 128)
+        self.bn0 = A.BatchNorm1d(128)
+        self.c1 = A.Linear(128, 64)
+        self.bn1 = A.BatchNorm1d(64)
+        self.c2 = A.Linear(64, 64)
+
+    def forward(self, objs, attribute):
+        a = torch.cat((self.embedding(objs), attribute), dim=1)
+        a = self.bn0(self.c0(a), relu=True)
+        a = self.bn1(self.c1(a), relu=True)
+        return self.c2(a)
+
+
+class Generator(nn.Module):
+    """Drop-in for models.generator_obj_att.Generator / models.generator_obj_att128.Generator.
+
+    forward(imgs, objs, boxes, masks, obj_to_img [CPU int64], z_rand, attribute, masks_shift, boxes_shift,
+    attribute_est) -> the reference's 11-tuple.  `eps` (optional, three (O,z) tensors) pins the crop
+    encoder's random draws; by default they are drawn on the CPU generator exactly like the reference.
+    """
+
+    def __init__(self, num_embeddings, obj_att_dim=64, z_dim=8, obj_size=64, clstm_layers=3, attribute_dim=128,
+                 res128=False):
+        super().__init__()
+        self.obj_size = obj_size
+        self.crop_encoder = CropEncoder(z_dim=z_dim, class_num=num_embeddings)
+        self.layout_encoder = LayoutEncoder(z_dim=z_dim, obj_att_dim=obj_att_dim, class_num=num_embeddings,
+                                            clstm_layers=clstm_layers, pool_to_8=res128)
+        self.decoder = Decoder(res128=res128)
+        self.global_encoder = GlobalEncoder()
+        self.attribute_encoder = AttributeEncoder(attribute_dim=attribute_dim, embedding_dim=obj_att_dim,
+                                                  class_num=num_embeddings)
+
+    def forward(self, imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est,
+                eps: Optional[Sequence[torch.Tensor]] = None):
+        A._need_device(imgs)
+        dev = imgs.device
+        e = list(eps) if eps is not None else [None, None, None]
+        o2i_dev = obj_to_img.to(dev)
+        plan = SequencePlan(obj_to_img, dev)
+        s = self.obj_size
+        crops_input = F.crop_boxes(imgs, boxes, o2i_dev, s)
+        z_rec, mu, logvar = self.crop_encoder(crops_input, objs, e[0])
+        objs_att = self.attribute_encoder(objs, attribute)
+        objs_att_est = self.attribute_encoder(objs, attribute_est)
+        h_rec = self.layout_encoder(objs_att_est, masks, obj_to_img, z_rec, objs, plan)
+        h_rand = self.layout_encoder(objs_att, masks, obj_to_img, z_rand, objs, plan)
+        h_shift = self.layout_encoder(objs_att, masks_shift, obj_to_img, z_rand, objs, plan)
+        g_rec = self.global_encoder(h_rec)
+        g_rand = self.global_encoder(h_rand)
+        g_shift = self.global_encoder(h_shift)
+        img_rec = self.decoder(h_rec, g_rec)
+        img_rand = self.decoder(h_rand, g_rand)
+        img_shift = self.decoder(h_shift, g_shift)
+        crops_rand = F.crop_boxes(img_rand, boxes, o2i_dev, s)
+        _, z_rand_rec, _ = self.crop_encoder(crops_rand, objs, e[1])
+        crops_input_rec = F.crop_boxes(img_rec, boxes, o2i_dev, s)
+        crops_shift = F.crop_boxes(img_shift, boxes_shift, o2i_dev, s)
+        _, z_rand_shift, _ = self.crop_encoder(crops_shift, objs, e[2])
+        return (crops_input, crops_input_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift, mu, logvar,
+                z_rand_rec, z_rand_shift)

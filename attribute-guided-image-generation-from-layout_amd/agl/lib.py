@@ -1,0 +1,335 @@
+"""ctypes binding of libagl.so (include/agl.h) plus tensor-level wrappers without autograd.
+
+PyTorch is used here only as the owner of device memory and of the current HIP stream: every
+wrapper allocates its outputs with torch.empty, passes raw device pointers + the current stream
+handle through the C ABI and returns the tensors.  There is NO fallback: if libagl.so is missing,
+or an operand is not a contiguous fp32 (int64 for indices) tensor on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagl.so")
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> (restype, argtypes); must mirror include/agl.h (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "agl_version": (_I, []),
+    "agl_last_error": (C.c_char_p, []),
+    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
+    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
+    "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
+    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
+    "agl_lstm_gates_bwd": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "agl_axpby": (_I, [_P, _P, _F, _F, _P, _L, _P]),
+    "agl_gather_rows": (_I, [_P, _P, _P, _L, _L, _I, _P]),
+    "agl_scatter_rows": (_I, [_P, _P, _P, _L, _L, _P]),
+    "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_upsample_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "agl_upsample_nearest_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_sum_hw_fwd": (_I, [_P, _P, _L, _I, _I, _F, _P]),
+    "agl_sum_hw_bwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P]),
+    "agl_channel_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "agl_reparam_fwd": (_I, [_P, _P, _P, _P, _L, _P]),
+    "agl_reparam_bwd": (_I, [_P, _P, _P, _P, _L, _P]),
+    "agl_mask_outer_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "agl_mask_outer_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "agl_sn_layer_desc_bytes": (_L, []),
+    "agl_sn_tmp_floats": (_L, [_I, _I]),
+    "agl_sn_forward": (_I, [_P, _I, _I, _F, _P]),
+    "agl_sn_backward": (_I, [_P, _I, _P]),
+    "agl_bce_logits_const": (_I, [_P, _L, _F, _F, _P, _P, _P]),
+    "agl_bce_logits_posw": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
+    "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
+    "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P]),
+    "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "agl_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+
+class SnLayer(C.Structure):
+    """Mirror of struct AglSnLayer (include/agl.h)."""
+    _fields_ = [("w", _P), ("u", _P), ("v", _P), ("w_sn", _P), ("sigma", _P), ("tmp", _P), ("u_used", _P),
+                ("v_used", _P), ("g", _P), ("dw", _P), ("rows", _I), ("cols", _I)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libagl.so (built in-tree by `make -C csrc` / __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
+                          f"(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc). "
+                          f"This package has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    assert lib.agl_sn_layer_desc_bytes() == C.sizeof(SnLayer), "AglSnLayer layout mismatch"
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.agl_last_error().decode()}")
+
+
+# --------------------------------------------------------------------------- helpers
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("agl: operand is not on a HIP device (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"agl: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("agl: operand must be contiguous")
+    return t.data_ptr()
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (all launches are ordered on the current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_out_size(h, ks, stride, pad, up=0):
+    return ((h << up) + 2 * pad - ks) // stride + 1
+
+
+# --------------------------------------------------------------------------- raw ops (no autograd)
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False):
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, ks, ks2 = w.shape
+    assert Cin_w == Cin and ks == ks2, (x.shape, w.shape)
+    OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    else:
+        assert tuple(out.shape) == (N, Cout, OH, OW)
+    call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), N, Cin, H, W, Cout, ks, stride, pad, up,
+         int(in_relu), int(relu), int(accumulate), stream())
+    return out
+
+
+def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accumulate=False):
+    """dx (N,Cin,IH,IW) from dy (N,Cout,OH,OW), w (Cout,Cin,ks,ks).  Also ConvTranspose2d forward."""
+    N, Cout, OH, OW = dy.shape
+    Cout_w, Cin, ks, _ = w.shape
+    assert Cout_w == Cout, (dy.shape, w.shape)
+    IH, IW = in_hw
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N, Cin, IH, IW), dtype=torch.float32, device=dy.device)
+    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), N, Cin, IH, IW, Cout, OH, OW, ks,
+         stride, pad, 0, int(accumulate), stream())
+    return out
+
+
+def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False):
+    N, Cout, OH, OW = dy.shape
+    _, Cin, H, W = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dy.device)
+    need = load().agl_conv2d_bwd_weight_ws_bytes(N, Cin, Cout, ks, OH, OW)
+    if accumulate:
+        need = max(need, Cout * Cin * ks * ks * 4)
+    ws = workspace(need, dy.device) if need else None
+    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up, int(in_relu),
+         int(accumulate), stream())
+    return out
+
+
+def channel_sum(x, out=None, accumulate=False):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    if out is None:
+        out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    call("agl_channel_sum", ptr(x), ptr(out), N, Cc, HW, int(accumulate), stream())
+    return out
+
+
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    nb = load().agl_bn_stats_ws_bytes(N, Cc, HW)
+    ws = workspace(nb, x.device)
+    call("agl_bn_stats", ptr(x), N, Cc, HW, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+         ptr(nbt, torch.int64), ws.data_ptr(), ws.numel(), stream())
+    return mean, rstd
+
+
+def bn_stats_eval(running_mean, running_var, eps):
+    mean = torch.empty_like(running_mean)
+    rstd = torch.empty_like(running_mean)
+    call("agl_bn_stats_eval", ptr(running_mean), ptr(running_var), running_mean.numel(), eps, ptr(mean), ptr(rstd), stream())
+    return mean, rstd
+
+
+def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty_like(x)
+    call("agl_norm_apply_fwd", ptr(x), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1), ptr(labels, torch.int64),
+         ptr(residual), int(relu), ptr(y), N, Cc, HW, stream())
+    return y
+
+
+def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    nb = load().agl_norm_bwd_ws_bytes(N, Cc)
+    ws = workspace(nb, x.device)
+    call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
+         ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
+         ws.data_ptr(), ws.numel(), stream())
+    return dx
+
+
+def crop_fwd(feats, boxes, o2i, HH, WW, align=False):
+    N, Cc, H, W = feats.shape
+    B = boxes.shape[0]
+    out = torch.empty((B, Cc, HH, WW), dtype=torch.float32, device=feats.device)
+    call("agl_crop_fwd", ptr(feats), ptr(boxes), ptr(o2i, torch.int64), ptr(out), N, B, Cc, H, W, HH, WW, int(align), stream())
+    return out
+
+
+def crop_bwd(dout, boxes, o2i, feat_shape, align=False):
+    N, Cc, H, W = feat_shape
+    B, _, HH, WW = dout.shape
+    dfeats = torch.zeros(feat_shape, dtype=torch.float32, device=dout.device)
+    call("agl_crop_bwd", ptr(dout), ptr(boxes), ptr(o2i, torch.int64), ptr(dfeats), N, B, Cc, H, W, HH, WW, int(align), stream())
+    return dfeats
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    call("agl_relu_bwd", ptr(dy), ptr(y), ptr(dx), dy.numel(), stream())
+    return dx
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    call("agl_axpby", ptr(a), ptr(b), alpha, beta, ptr(out), a.numel(), stream())
+    return out
+
+
+def gather_rows(src, rows, out=None, accumulate=False):
+    R = rows.numel()
+    ln = src.numel() // src.shape[0]
+    if out is None:
+        out = torch.empty((R,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    call("agl_gather_rows", ptr(src), ptr(rows, torch.int64), ptr(out), R, ln, int(accumulate), stream())
+    return out
+
+
+def scatter_rows(src, rows, out):
+    ln = src.numel() // src.shape[0]
+    call("agl_scatter_rows", ptr(src), ptr(rows, torch.int64), ptr(out), rows.numel(), ln, stream())
+    return out
+
+
+def avgpool2_fwd(x, in_relu=False):
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    call("agl_avgpool2_fwd", ptr(x), ptr(y), N * Cc, H, W, int(in_relu), stream())
+    return y
+
+
+def avgpool2_bwd(dy, x_or_shape, in_relu=False, out=None, accumulate=False):
+    x = x_or_shape if isinstance(x_or_shape, torch.Tensor) else None
+    shape = x.shape if x is not None else x_or_shape
+    N, Cc, H, W = shape
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=dy.device)
+    call("agl_avgpool2_bwd", ptr(dy), ptr(x), ptr(out), N * Cc, H, W, int(in_relu), int(accumulate), stream())
+    return out
+
+
+def upsample_fwd(x, k):
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, H << k, W << k), dtype=torch.float32, device=x.device)
+    call("agl_upsample_nearest_fwd", ptr(x), ptr(y), N * Cc, H, W, k, stream())
+    return y
+
+
+def upsample_bwd(dy, k, out=None, accumulate=False):
+    N, Cc, OH, OW = dy.shape
+    H, W = OH >> k, OW >> k
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dy.device)
+    call("agl_upsample_nearest_bwd", ptr(dy), ptr(out), N * Cc, H, W, k, int(accumulate), stream())
+    return out
+
+
+def sum_hw_fwd(x, in_relu=False, scale=1.0):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+    call("agl_sum_hw_fwd", ptr(x), ptr(y), N * Cc, HW, int(in_relu), scale, stream())
+    return y
+
+
+def sum_hw_bwd(dy, x, in_relu=False, scale=1.0):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    call("agl_sum_hw_bwd", ptr(dy), ptr(x), ptr(dx), N * Cc, HW, int(in_relu), scale, stream())
+    return dx
+
+
+def lstm_gates_fwd(ccx, rows, cch, c_prev, h, c, gates, B, hid, S):
+    call("agl_lstm_gates_fwd", ptr(ccx), ptr(rows, torch.int64), ptr(cch), ptr(c_prev), ptr(h), ptr(c), ptr(gates),
+         B, hid, S, stream())
+
+
+def lstm_gates_bwd(dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S):
+    call("agl_lstm_gates_bwd", ptr(dh_a), ptr(dh_b), Bb, ptr(dc_next), Bc, ptr(gates), ptr(c_prev), ptr(c), ptr(dcc),
+         ptr(dc_prev), B, hid, S, stream())
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    call("agl_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream())

@@ -1,0 +1,495 @@
+// Convolution family for gfx950 (MI355X): fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.
+//
+// One generic LDS-tiled kernel (igemm_f32) serves the three convolution passes; a small
+// "problem" struct per pass tells it how to gather A and B elements and where an output
+// element goes:
+//   forward      C[co][pix]  = sum_k  W[co][k]            * im2col(x)[k][pix]   (k = ci,kh,kw)
+//   bwd-data     C[ci][pix'] = sum_k  W[co][ci][kh][kw]   * dy-gather[k][pix']  (k = co,th,tw; one
+//                launch z-slice per stride phase, so stride-2 k4 convs do 2x2 taps, not 4x4)
+//   bwd-weight   C[co][kcol] = sum_r  dy[co][r]           * im2col(x)[r][kcol]  (r = n,oh,ow; split
+//                over z with per-split slabs reduced deterministically afterwards)
+// ConvTranspose2d(k4,s2,p1) forward is the bwd-data pass of the matching strided conv.
+//
+// Tile: BMxBN outputs per 256-thread workgroup (4 waves), BK=16 reduction slice, two LDS
+// buffers with register prefetch of the next slice, 32x32x2 f32 MFMA accumulators in VGPRs.
+// LDS images are [k][row] (row-fast gathers) or [row][k] padded to 17 (k-fast gathers) so both
+// the staging writes and the 32-lane fragment reads stay (nearly) bank-conflict free.
+#include "agl_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+template <int KS> struct KDiv {  // k -> (c, kh, kw) for a KSxKS window
+  __device__ static __forceinline__ void split(int k, int& c, int& kh, int& kw) {
+    c = k / (KS * KS);
+    int r = k - c * (KS * KS);
+    kh = r / KS;
+    kw = r - kh * KS;
+  }
+};
+
+// ------------------------------------------------------------------ forward
+template <int KS>
+struct FwdProb {
+  static constexpr bool A_KFAST = true;   // weights: k contiguous
+  static constexpr bool B_KFAST = false;  // im2col: pixels contiguous
+  const float* x; const float* w; const float* bias; float* y;
+  int N, Cin, H, W, Cout, OH, OW, stride, pad, up;  // up: log2 nearest-upsample of x folded into the gather
+  int relu, accumulate, in_relu;
+  int M, Nc, kbeg, kend;
+  int HW, OHW, K;
+
+  __device__ bool setup(int) { return true; }
+
+  struct RowA { const float* p; bool ok; };
+  struct KA { int k; bool ok; };
+  __device__ RowA row_a(int m) const { return {w + (long)m * K, m < M}; }
+  __device__ KA k_a(int k) const { return {k, k < kend}; }
+  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? r.p[k.k] : 0.f; }
+
+  struct RowB { const float* p; int ih0, iw0; bool ok; };
+  struct KB { int coff, kh, kw; bool ok; };
+  __device__ RowB row_b(int n) const {
+    RowB r; r.ok = n < Nc;
+    int nn = r.ok ? n : 0;
+    int img = nn / OHW, pix = nn - img * OHW;
+    int oh = pix / OW, ow = pix - oh * OW;
+    r.p = x + (long)img * Cin * HW; r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
+    return r;
+  }
+  __device__ KB k_b(int k) const {
+    KB s; s.ok = k < kend; int c;
+    KDiv<KS>::split(s.ok ? k : 0, c, s.kh, s.kw); s.coff = c * HW;
+    return s;
+  }
+  __device__ float load_b(const RowB& r, const KB& k) const {
+    int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
+    bool ok = r.ok && k.ok && (unsigned)ih < (unsigned)(H << up) && (unsigned)iw < (unsigned)(W << up);
+    float v = ok ? r.p[k.coff + (ih >> up) * W + (iw >> up)] : 0.f;
+    return in_relu ? fmaxf(v, 0.f) : v;
+  }
+  struct Col { long off; bool ok; };
+  __device__ Col col(int n) const {
+    Col c; c.ok = n < Nc; int nn = c.ok ? n : 0;
+    int img = nn / OHW, pix = nn - img * OHW;
+    c.off = (long)img * Cout * OHW + pix; return c;
+  }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) {
+      long o = c.off + (long)m * OHW;
+      if (bias) v += bias[m];
+      if (accumulate) v += y[o];
+      if (relu) v = fmaxf(v, 0.f);
+      y[o] = v;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ backward data (and ConvTranspose forward)
+template <int KS, int S>
+struct BwdDataProb {
+  static constexpr bool A_KFAST = false;
+  static constexpr bool B_KFAST = false;
+  static constexpr int TS = KS / S;  // taps per axis per phase
+  const float* dy; const float* w; float* dx; const float* bias; const float* pos_mask;
+  int N, Cin, IH, IW, Cout, OH, OW, pad;
+  int accumulate, relu;
+  int M, Nc, kbeg, kend;
+  int IHW, OHW, ph, pw, kh0, kw0, ohb, owb, IHp, IWp;
+
+  __device__ bool setup(int z) {
+    ph = z / S; pw = z - ph * S;
+    IHp = (IH - ph + S - 1) / S; IWp = (IW - pw + S - 1) / S;
+    kh0 = (ph + pad) % S; kw0 = (pw + pad) % S;
+    ohb = (ph + pad - kh0) / S; owb = (pw + pad - kw0) / S;
+    Nc = N * IHp * IWp; M = Cin; kbeg = 0; kend = Cout * TS * TS;
+    return Nc > 0;
+  }
+  struct RowA { const float* p; bool ok; };
+  struct KA { int off; bool ok; };
+  __device__ RowA row_a(int m) const { return {w + (long)m * KS * KS, m < M}; }
+  __device__ KA k_a(int k) const {
+    KA s; s.ok = k < kend; int co, th, tw;
+    KDiv<TS>::split(s.ok ? k : 0, co, th, tw);
+    s.off = co * Cin * KS * KS + (kh0 + S * th) * KS + (kw0 + S * tw);
+    return s;
+  }
+  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? r.p[k.off] : 0.f; }
+
+  struct RowB { const float* p; int oh0, ow0; bool ok; };
+  struct KB { int coff, th, tw; bool ok; };
+  __device__ RowB row_b(int n) const {
+    RowB r; r.ok = n < Nc; int nn = r.ok ? n : 0;
+    int per = IHp * IWp;
+    int img = nn / per, q = nn - img * per;
+    int a = q / IWp, b = q - a * IWp;
+    r.p = dy + (long)img * Cout * OHW; r.oh0 = a + ohb; r.ow0 = b + owb;
+    return r;
+  }
+  __device__ KB k_b(int k) const {
+    KB s; s.ok = k < kend; int co;
+    KDiv<TS>::split(s.ok ? k : 0, co, s.th, s.tw); s.coff = co * OHW;
+    return s;
+  }
+  __device__ float load_b(const RowB& r, const KB& k) const {
+    int oh = r.oh0 - k.th, ow = r.ow0 - k.tw;
+    bool ok = r.ok && k.ok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+    return ok ? r.p[k.coff + oh * OW + ow] : 0.f;
+  }
+  struct Col { long off; bool ok; };
+  __device__ Col col(int n) const {
+    Col c; c.ok = n < Nc; int nn = c.ok ? n : 0;
+    int per = IHp * IWp;
+    int img = nn / per, q = nn - img * per;
+    int a = q / IWp, b = q - a * IWp;
+    c.off = (long)img * Cin * IHW + (long)(a * S + ph) * IW + (b * S + pw); return c;
+  }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) {
+      long o = c.off + (long)m * IHW;
+      if (bias) v += bias[m];
+      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+      if (accumulate) v += dx[o];
+      if (relu) v = fmaxf(v, 0.f);
+      dx[o] = v;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ backward weight
+template <int KS>
+struct BwdWeightProb {
+  static constexpr bool A_KFAST = true;  // reduction index r = (n,oh,ow) is the contiguous one
+  static constexpr bool B_KFAST = true;
+  const float* dy; const float* x; float* out;  // out: dw (splits==1) or slab base
+  int N, Cin, H, W, Cout, OH, OW, stride, pad, up, in_relu;
+  int M, Nc, kbeg, kend;
+  int HW, OHW, R, per_split;
+  long slab;
+
+  __device__ bool setup(int z) {
+    kbeg = z * per_split; kend = min(R, kbeg + per_split);
+    out += (long)z * slab;
+    return kbeg < kend;
+  }
+  struct RowA { int off; bool ok; };
+  struct KA { const float* p; bool ok; };
+  __device__ RowA row_a(int m) const { return {m * OHW, m < M}; }
+  __device__ KA k_a(int r) const {
+    KA s; s.ok = r < kend; int rr = s.ok ? r : 0;
+    int img = rr / OHW, pix = rr - img * OHW;
+    s.p = dy + (long)img * Cout * OHW + pix; return s;
+  }
+  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? k.p[r.off] : 0.f; }
+
+  struct RowB { int coff, kh, kw; bool ok; };
+  struct KB { const float* p; int ih0, iw0; bool ok; };
+  __device__ RowB row_b(int n) const {
+    RowB r; r.ok = n < Nc; int c;
+    KDiv<KS>::split(r.ok ? n : 0, c, r.kh, r.kw); r.coff = c * HW; return r;
+  }
+  __device__ KB k_b(int r) const {
+    KB s; s.ok = r < kend; int rr = s.ok ? r : 0;
+    int img = rr / OHW, pix = rr - img * OHW;
+    int oh = pix / OW, ow = pix - oh * OW;
+    s.p = x + (long)img * Cin * HW; s.ih0 = oh * stride - pad; s.iw0 = ow * stride - pad; return s;
+  }
+  __device__ float load_b(const RowB& r, const KB& k) const {
+    int ih = k.ih0 + r.kh, iw = k.iw0 + r.kw;
+    bool ok = r.ok && k.ok && (unsigned)ih < (unsigned)(H << up) && (unsigned)iw < (unsigned)(W << up);
+    float v = ok ? k.p[r.coff + (ih >> up) * W + (iw >> up)] : 0.f;
+    return in_relu ? fmaxf(v, 0.f) : v;
+  }
+  struct Col { int n; bool ok; };
+  __device__ Col col(int n) const { return {n, n < Nc}; }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) out[(long)m * Nc + c.n] = v;
+  }
+};
+
+// ------------------------------------------------------------------ the kernel
+template <class P, int BM, int BN>
+__global__ __launch_bounds__(NT) void igemm_f32(P p) {
+  constexpr int WAVES_M = (BM >= 128) ? 2 : 1;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WTM = BM / (32 * WAVES_M);
+  constexpr int WTN = BN / (32 * WAVES_N);
+  static_assert(WTM >= 1 && WTN >= 1, "tile too small for 4 waves");
+  constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
+  constexpr int A_SZ = P::A_KFAST ? BM * (BK + 1) : BK * BM;
+  constexpr int B_SZ = P::B_KFAST ? BN * (BK + 1) : BK * BN;
+  __shared__ float lds[2 * (A_SZ + B_SZ)];
+  float* As = lds;
+  float* Bs = lds + 2 * A_SZ;
+
+  if (!p.setup(blockIdx.z)) return;
+  const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+  if (bm0 >= p.M || bn0 >= p.Nc) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // hoisted row state (fixed per thread for the whole reduction)
+  constexpr int A_ROWS = P::A_KFAST ? A_PER : 1;
+  constexpr int B_ROWS = P::B_KFAST ? B_PER : 1;
+  typename P::RowA ra_[A_ROWS];
+  typename P::RowB rb_[B_ROWS];
+  if constexpr (P::A_KFAST) {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) ra_[j] = p.row_a(bm0 + tid / BK + (NT / BK) * j);
+  } else {
+    ra_[0] = p.row_a(bm0 + tid % BM);
+  }
+  if constexpr (P::B_KFAST) {
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) rb_[j] = p.row_b(bn0 + tid / BK + (NT / BK) * j);
+  } else {
+    rb_[0] = p.row_b(bn0 + tid % BN);
+  }
+
+  float va[A_PER], vb[B_PER];
+  auto gload = [&](int k0) {
+    if constexpr (P::A_KFAST) {
+      auto ks = p.k_a(k0 + tid % BK);
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) va[j] = p.load_a(ra_[j], ks);
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) va[j] = p.load_a(ra_[0], p.k_a(k0 + tid / BM + (NT / BM) * j));
+    }
+    if constexpr (P::B_KFAST) {
+      auto ks = p.k_b(k0 + tid % BK);
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) vb[j] = p.load_b(rb_[j], ks);
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) vb[j] = p.load_b(rb_[0], p.k_b(k0 + tid / BN + (NT / BN) * j));
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* a = As + buf * A_SZ;
+    float* b = Bs + buf * B_SZ;
+    if constexpr (P::A_KFAST) {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) a[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = va[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) a[(tid / BM + (NT / BM) * j) * BM + tid % BM] = va[j];
+    }
+    if constexpr (P::B_KFAST) {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) b[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = vb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) b[(tid / BN + (NT / BN) * j) * BN + tid % BN] = vb[j];
+    }
+  };
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int arow0 = wm * 32 * WTM + l31, brow0 = wn * 32 * WTN + l31;
+
+  gload(p.kbeg);
+  sstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = p.kbeg; k0 < p.kend; k0 += BK) {
+    const bool more = k0 + BK < p.kend;
+    if (more) gload(k0 + BK);
+    const float* a = As + cur * A_SZ;
+    const float* b = Bs + cur * B_SZ;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float fa[WTM], fb[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+        fa[i] = P::A_KFAST ? a[(arow0 + 32 * i) * (BK + 1) + kk + lh] : a[(kk + lh) * BM + arow0 + 32 * i];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+        fb[j] = P::B_KFAST ? b[(brow0 + 32 * j) * (BK + 1) + kk + lh] : b[(kk + lh) * BN + brow0 + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    auto c = p.col(bn0 + wn * 32 * WTN + 32 * j + l31);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      const int mb = bm0 + wm * 32 * WTM + 32 * i + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p.store(mb + (r & 3) + 8 * (r >> 2), c, acc[i][j][r]);
+    }
+  }
+}
+
+__global__ void slab_reduce(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+template <class P>
+int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name) {
+  AGL_REQUIRE(Nc > 0 && Nc < (1L << 31) && M > 0, "%s: bad GEMM extents M=%d Nc=%ld", name, M, Nc);
+  if (M <= 32) {
+    dim3 g(agl_cdiv(Nc, 256), agl_cdiv(M, 32), Z);
+    hipLaunchKernelGGL((igemm_f32<P, 32, 256>), g, dim3(NT), 0, st, p);
+  } else if (M <= 64) {
+    dim3 g(agl_cdiv(Nc, 128), agl_cdiv(M, 64), Z);
+    hipLaunchKernelGGL((igemm_f32<P, 64, 128>), g, dim3(NT), 0, st, p);
+  } else {
+    dim3 g(agl_cdiv(Nc, 128), agl_cdiv(M, 128), Z);
+    hipLaunchKernelGGL((igemm_f32<P, 128, 128>), g, dim3(NT), 0, st, p);
+  }
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+
+bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
+
+}  // namespace
+
+extern "C" {
+
+int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout,
+                   int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate, void* stream) {
+  AGL_REQUIRE(x && w && y, "agl_conv2d_fwd: null pointer");
+  AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2) && up_log2 >= 0 && up_log2 <= 4,
+              "agl_conv2d_fwd: unsupported ks=%d stride=%d up=%d", ks, stride, up_log2);
+  const int Hl = H << up_log2, Wl = W << up_log2;
+  const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
+  AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_fwd: empty extent");
+  AGL_REQUIRE((long)N * Cin * H * W < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_fwd: tensor too large for 32-bit offsets");
+  hipStream_t st = (hipStream_t)stream;
+#define AGL_FWD(KS_)                                                                                                  \
+  case KS_: {                                                                                                         \
+    FwdProb<KS_> p;                                                                                                   \
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH;      \
+    p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.relu = relu; p.accumulate = accumulate; p.in_relu = in_relu; \
+    p.M = Cout; p.Nc = N * OH * OW; p.K = Cin * KS_ * KS_; p.kbeg = 0; p.kend = p.K; p.HW = H * W; p.OHW = OH * OW;  \
+    return launch_igemm(p, p.M, p.Nc, 1, st, "agl_conv2d_fwd");                                                       \
+  }
+  switch (ks) { AGL_FWD(1) AGL_FWD(3) AGL_FWD(4) AGL_FWD(5) AGL_FWD(7) }
+#undef AGL_FWD
+  return AGL_ERR_ARG;
+}
+
+// dx[N,Cin,IH,IW] = conv2d_backward_input(dy[N,Cout,OH,OW], w[Cout,Cin,ks,ks]).  Also the forward of
+// ConvTranspose2d (weight [C_in_T = Cout][C_out_T = Cin][ks][ks]).
+int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, int N, int Cin, int IH, int IW,
+                        int Cout, int OH, int OW, int ks, int stride, int pad, int relu, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && w && dx, "agl_conv2d_bwd_data: null pointer");
+  AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && ks == 4)), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
+  AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
+  AGL_REQUIRE((IH + 2 * pad - ks) / stride + 1 == OH && (IW + 2 * pad - ks) / stride + 1 == OW,
+              "agl_conv2d_bwd_data: inconsistent extents IH=%d IW=%d OH=%d OW=%d", IH, IW, OH, OW);
+  AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_bwd_data: tensor too large");
+  hipStream_t st = (hipStream_t)stream;
+#define AGL_BWD(KS_, S_)                                                                                            \
+  {                                                                                                                 \
+    BwdDataProb<KS_, S_> p;                                                                                         \
+    p.dy = dy; p.w = w; p.dx = dx; p.bias = bias; p.pos_mask = pos_mask; p.N = N; p.Cin = Cin; p.IH = IH; p.IW = IW; p.Cout = Cout;       \
+    p.OH = OH; p.OW = OW; p.pad = pad; p.accumulate = accumulate; p.relu = relu; p.IHW = IH * IW; p.OHW = OH * OW; \
+    long maxNc = (long)N * ((IH + S_ - 1) / S_) * ((IW + S_ - 1) / S_);                                             \
+    return launch_igemm(p, Cin, maxNc, S_ * S_, st, "agl_conv2d_bwd_data");                                         \
+  }
+  if (stride == 2) AGL_BWD(4, 2)
+  switch (ks) {
+    case 1: AGL_BWD(1, 1)
+    case 3: AGL_BWD(3, 1)
+    case 4: AGL_BWD(4, 1)
+    case 5: AGL_BWD(5, 1)
+    case 7: AGL_BWD(7, 1)
+  }
+#undef AGL_BWD
+  return AGL_ERR_ARG;
+}
+
+// Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every
+// split z < splits owns a non-empty range [z*per, min(R,(z+1)*per)).
+static int bww_splits(int Cout, long Nc, long R, long* per_out) {
+  const int bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+  const int bn = Cout <= 32 ? 256 : 128;
+  long tiles = (long)agl_cdiv(Cout, bm) * agl_cdiv(Nc, bn);
+  long want = (1024 + tiles - 1) / tiles;
+  long maxs = R / 256 > 0 ? R / 256 : 1;
+  long s = want < maxs ? want : maxs;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  long per = (R + s - 1) / s;
+  per = (per + BK - 1) / BK * BK;
+  s = (R + per - 1) / per;
+  if (per_out) *per_out = per;
+  return (int)s;
+}
+
+long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
+  long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
+  int s = bww_splits(Cout, Nc, R, nullptr);
+  return s > 1 ? (long)s * Cout * Nc * 4 : 0;
+}
+
+// dw[Cout,Cin,ks,ks] (+)= sum_{n,oh,ow} dy * im2col(x).  ws: agl_conv2d_bwd_weight_ws_bytes() bytes (may be null if 0).
+int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H, int W,
+                          int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
+  AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
+  AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
+  AGL_REQUIRE((long)N * Cin * H * W < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_bwd_weight: tensor too large");
+  const long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
+  long per = 0;
+  const int splits = bww_splits(Cout, Nc, R, &per);
+  const long need = splits > 1 ? (long)splits * Cout * Nc * 4 : 0;
+  if (need > ws_bytes || (need > 0 && !ws)) {
+    agl_set_error("agl_conv2d_bwd_weight: workspace too small (%ld < %ld)", ws_bytes, need);
+    return AGL_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool direct = splits == 1 && !accumulate;
+  float* target = direct ? dw : (float*)ws;
+  if (!direct && splits == 1) {  // accumulate with a single split: still go through a slab
+    AGL_REQUIRE(ws && ws_bytes >= Cout * Nc * 4, "agl_conv2d_bwd_weight: accumulate needs a slab of Cout*Cin*ks*ks floats");
+  }
+  int rc = AGL_ERR_ARG;
+#define AGL_BWW(KS_)                                                                                              \
+  case KS_: {                                                                                                     \
+    BwdWeightProb<KS_> p;                                                                                         \
+    p.dy = dy; p.x = x; p.out = target; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH;        \
+    p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.in_relu = in_relu; p.M = Cout; p.Nc = (int)Nc; p.HW = H * W;         \
+    p.OHW = OH * OW; p.R = (int)R; p.per_split = (int)per; p.slab = (long)Cout * Nc; p.kbeg = 0; p.kend = 0;    \
+    rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight");                                         \
+  } break;
+  switch (ks) { AGL_BWW(1) AGL_BWW(3) AGL_BWW(4) AGL_BWW(5) AGL_BWW(7) }
+#undef AGL_BWW
+  if (rc != AGL_OK) return rc;
+  if (!direct) {
+    long n = (long)Cout * Nc;
+    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, dw, n, splits, accumulate);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(reduce)");
+  }
+  return AGL_OK;
+}
+
+}  // extern "C"

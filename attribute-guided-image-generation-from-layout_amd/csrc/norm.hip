@@ -1,0 +1,307 @@
+// Batch-statistics normalisation family (HBM-bound): BatchNorm2d/1d statistics, the affine /
+// class-conditional / SPADE modulation (+ReLU, +residual) and their backward passes.
+// Tensors are fp32 NCHW viewed as rows (n,c) of HW contiguous floats.
+//   mode 0: y = xhat                         (no affine)
+//   mode 1: y = xhat*gamma[c] + beta[c]      (nn.BatchNorm affine)
+//   mode 2: y = xhat*T[lab[n]][c] + T[lab[n]][C+c]   (ConditionalBatchNorm2d, table T[V][2C])
+//   mode 3: y = xhat*(1+gb[n][c][hw]) + gb[n][C+c][hw]   (SPADE, gb = [gamma;beta] conv output)
+#include "agl_internal.h"
+
+namespace {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v, float* scratch4) {
+  if constexpr (LPR == 256) {
+    return block_sum_256(v, scratch4);
+  } else {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+}
+
+// ---------------------------------------------------------------- statistics
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int N, int C, int HW, int S,
+                                                        double* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const long total = (long)N * HW;
+  const long chunk = (total + S - 1) / S;
+  const long e0 = s * chunk, e1 = min(total, e0 + chunk);
+  double a = 0.0, b = 0.0;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    int n = (int)(e / HW);
+    int hw = (int)(e - (long)n * HW);
+    float v = x[((long)n * C + c) * HW + hw];
+    a += v;
+    b += (double)v * v;
+  }
+  __shared__ double sc[4];
+  a = block_sum_256(a, sc);
+  b = block_sum_256(b, sc);
+  if (threadIdx.x == 0) {
+    part[((long)c * S + s) * 2 + 0] = a;
+    part[((long)c * S + s) * 2 + 1] = b;
+  }
+}
+
+__global__ void bn_stats_final(const double* __restrict__ part, int C, int S, long M, float eps, float momentum,
+                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                               float* __restrict__ rvar, long long* __restrict__ nbt) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < S; ++s) {
+    a += part[((long)c * S + s) * 2];
+    b += part[((long)c * S + s) * 2 + 1];
+  }
+  double mu = a / (double)M;
+  double var = b / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+  }
+}
+
+// Eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
+__global__ void bn_stats_eval(const float* rmean, const float* rvar, int C, float eps, float* mean, float* rstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rmean[c];
+  rstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+// ---------------------------------------------------------------- forward apply
+struct NormArgs {
+  const float* x; const float* mean; const float* rstd;
+  const float* p0; const float* p1; const long long* labels;
+  int mode, relu, N, C, HW;
+};
+
+__device__ __forceinline__ void row_affine(const NormArgs& a, int n, int c, float& g, float& b) {
+  g = 1.f; b = 0.f;
+  if (a.mode == 1) { g = a.p0[c]; b = a.p1[c]; }
+  else if (a.mode == 2) { const float* t = a.p0 + (long)a.labels[n] * 2 * a.C; g = t[c]; b = t[a.C + c]; }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void norm_apply_fwd(NormArgs a, const float* __restrict__ residual, float* __restrict__ y) {
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  if (row >= a.N * a.C) return;
+  const int n = row / a.C, c = row - n * a.C;
+  const float mu = a.mean[c], rs = a.rstd[c];
+  float g, b;
+  row_affine(a, n, c, g, b);
+  const long base = (long)row * a.HW;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  const float* bet = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + a.C + c) * a.HW : nullptr;
+  for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
+    float xh = (a.x[base + i] - mu) * rs;
+    float v = a.mode == 3 ? xh * (1.f + gam[i]) + bet[i] : xh * g + b;
+    if (residual) v += residual[base + i];
+    if (a.relu) v = fmaxf(v, 0.f);
+    y[base + i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// K1: per row (n,c): a1 = sum g*ge, a2 = sum g*ge*xhat  (ge = 1, or (1+gamma) in mode 3); mode 3 also writes dgb.
+template <int LPR>
+__global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
+                                                     float* __restrict__ rowsum, float* __restrict__ dgb) {
+  __shared__ float sc[4];
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const bool live = row < a.N * a.C;
+  const int rr = live ? row : 0;
+  const int n = rr / a.C, c = rr - n * a.C;
+  const float mu = a.mean[c], rs = a.rstd[c];
+  const long base = (long)rr * a.HW;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  float* dgam = a.mode == 3 ? dgb + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  float* dbet = a.mode == 3 ? dgb + ((long)n * 2 * a.C + a.C + c) * a.HW : nullptr;
+  float s1 = 0.f, s2 = 0.f;
+  if (live) {
+    for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
+      float g = dy[base + i];
+      if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
+      float xh = (a.x[base + i] - mu) * rs;
+      if (a.mode == 3) {
+        dgam[i] = g * xh;
+        dbet[i] = g;
+        g *= 1.f + gam[i];
+      }
+      s1 += g;
+      s2 += g * xh;
+    }
+  }
+  s1 = group_sum<LPR>(s1, sc);
+  s2 = group_sum<LPR>(s2, sc);
+  if (live && threadIdx.x % LPR == 0) {
+    rowsum[2 * (long)row] = s1;
+    rowsum[2 * (long)row + 1] = s2;
+  }
+}
+
+// K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; parameter grads (deterministic, serial over n).
+__global__ void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
+                                  float* __restrict__ dp0, float* __restrict__ dp1) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
+  for (int n = 0; n < a.N; ++n) {
+    float a1 = rowsum[2 * ((long)n * a.C + c)], a2 = rowsum[2 * ((long)n * a.C + c) + 1];
+    float g = 1.f;
+    if (a.mode == 2) {
+      const long t = (long)a.labels[n] * 2 * a.C;
+      g = a.p0[t + c];
+      if (dp0) { dp0[t + c] += a2; dp0[t + a.C + c] += a1; }
+    }
+    S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
+  }
+  if (a.mode == 1) {
+    if (dp0) { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+    S1 *= a.p0[c]; S2 *= a.p0[c];
+  }
+  chansum[2 * c] = (float)S1;
+  chansum[2 * c + 1] = (float)S2;
+}
+
+// K3: dx = rstd * (ge*g - S1/M - xhat*S2/M)
+template <int LPR>
+__global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ chansum, float inv_m, int batch_stats,
+                                                      float* __restrict__ dx) {
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  if (row >= a.N * a.C) return;
+  const int n = row / a.C, c = row - n * a.C;
+  const float mu = a.mean[c], rs = a.rstd[c];
+  float ge, b;
+  row_affine(a, n, c, ge, b);
+  const float m1 = batch_stats ? chansum[2 * c] * inv_m : 0.f, m2 = batch_stats ? chansum[2 * c + 1] * inv_m : 0.f;
+  const long base = (long)row * a.HW;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
+    float g = dy[base + i];
+    if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
+    float xh = (a.x[base + i] - mu) * rs;
+    float gg = a.mode == 3 ? g * (1.f + gam[i]) : g * ge;
+    dx[base + i] = rs * (gg - m1 - xh * m2);
+  }
+}
+
+int pick_lpr(int HW) { return HW <= 4 ? 4 : (HW <= 16 ? 16 : (HW <= 512 ? 64 : 256)); }
+
+}  // namespace
+
+extern "C" {
+
+long agl_bn_stats_ws_bytes(int N, int C, int HW) {
+  (void)N; (void)HW;
+  return (long)C * 64 * 2 * sizeof(double);
+}
+
+// Batch statistics of x[N,C,HW] (training mode): mean[C], rstd[C]; running stats updated like nn.BatchNorm
+// (momentum, unbiased variance) when running_mean != NULL; *num_batches_tracked += 1 when not NULL.
+int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* rstd,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, void* ws, long ws_bytes,
+                 void* stream) {
+  AGL_REQUIRE(x && mean && rstd && N > 0 && C > 0 && HW > 0, "agl_bn_stats: bad argument");
+  const long total = (long)N * HW;
+  int S = (int)((total + 4095) / 4096);
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  if (!ws || ws_bytes < (long)C * S * 2 * (long)sizeof(double)) {
+    agl_set_error("agl_bn_stats: workspace too small");
+    return AGL_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial, dim3(C, S), dim3(256), 0, st, x, N, C, HW, S, (double*)ws);
+  AGL_CHECK_LAUNCH("agl_bn_stats(partial)");
+  hipLaunchKernelGGL(bn_stats_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S, total, eps,
+                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+  AGL_CHECK_LAUNCH("agl_bn_stats(final)");
+  return AGL_OK;
+}
+
+int agl_bn_stats_eval(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
+                      void* stream) {
+  AGL_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "agl_bn_stats_eval: bad argument");
+  hipLaunchKernelGGL(bn_stats_eval, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean, running_var,
+                     C, eps, mean, rstd);
+  AGL_CHECK_LAUNCH("agl_bn_stats_eval");
+  return AGL_OK;
+}
+
+#define AGL_LPR_DISPATCH(KERNEL, ...)                                                                              \
+  do {                                                                                                              \
+    const int lpr_ = pick_lpr(HW);                                                                                  \
+    const int rows_ = N * C;                                                                                        \
+    if (lpr_ == 4) hipLaunchKernelGGL((KERNEL<4>), dim3(agl_cdiv(rows_, 64)), dim3(256), 0, st, __VA_ARGS__);        \
+    else if (lpr_ == 16) hipLaunchKernelGGL((KERNEL<16>), dim3(agl_cdiv(rows_, 16)), dim3(256), 0, st, __VA_ARGS__); \
+    else if (lpr_ == 64) hipLaunchKernelGGL((KERNEL<64>), dim3(agl_cdiv(rows_, 4)), dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<256>), dim3(rows_), dim3(256), 0, st, __VA_ARGS__);                              \
+  } while (0)
+
+static int fill_args(NormArgs& a, const float* x, const float* mean, const float* rstd, int mode, const float* p0,
+                     const float* p1, const long long* labels, int relu, int N, int C, int HW, const char* who) {
+  AGL_REQUIRE(x && mean && rstd && N > 0 && C > 0 && HW > 0, "%s: bad argument", who);
+  AGL_REQUIRE(mode >= 0 && mode <= 3, "%s: bad mode %d", who, mode);
+  AGL_REQUIRE(mode == 0 || p0, "%s: mode %d needs p0", who, mode);
+  AGL_REQUIRE(mode != 1 || p1, "%s: mode 1 needs p1", who);
+  AGL_REQUIRE(mode != 2 || labels, "%s: mode 2 needs labels", who);
+  AGL_REQUIRE((long)N * C * HW < (1L << 31), "%s: tensor too large", who);
+  a.x = x; a.mean = mean; a.rstd = rstd; a.p0 = p0; a.p1 = p1; a.labels = labels;
+  a.mode = mode; a.relu = relu; a.N = N; a.C = C; a.HW = HW;
+  return AGL_OK;
+}
+
+int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                       const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
+                       void* stream) {
+  NormArgs a;
+  int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_apply_fwd");
+  if (rc) return rc;
+  AGL_REQUIRE(y, "agl_norm_apply_fwd: null output");
+  hipStream_t st = (hipStream_t)stream;
+  AGL_LPR_DISPATCH(norm_apply_fwd, a, residual, y);
+  AGL_CHECK_LAUNCH("agl_norm_apply_fwd");
+  return AGL_OK;
+}
+
+long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2) * 4; }
+
+// Backward of (stats +) apply.  batch_stats=1: statistics were computed from x (training); 0: constants (eval).
+// y is the forward output (ReLU mask) and may be NULL when relu==0.
+// dp0/dp1: mode 1 -> dgamma[C], dbeta[C] (overwritten); mode 2 -> dtable[V][2C] (ACCUMULATED into; caller zeroes);
+//          mode 3 -> dp0 = dgb[N][2C][HW] (overwritten).  Either may be NULL to skip parameter gradients (not mode 3).
+int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
+                 const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                 float* dp0, float* dp1, int N, int C, int HW, void* ws, long ws_bytes, void* stream) {
+  NormArgs a;
+  int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
+  if (rc) return rc;
+  AGL_REQUIRE(dy && dx && (!relu || y), "agl_norm_bwd: null pointer");
+  AGL_REQUIRE(mode != 3 || dp0, "agl_norm_bwd: SPADE mode needs dgb output");
+  if (!ws || ws_bytes < agl_norm_bwd_ws_bytes(N, C)) {
+    agl_set_error("agl_norm_bwd: workspace too small");
+    return AGL_ERR_WORKSPACE;
+  }
+  float* rowsum = (float*)ws;
+  float* chansum = rowsum + (long)N * C * 2;
+  hipStream_t st = (hipStream_t)stream;
+  AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
+  AGL_CHECK_LAUNCH("agl_norm_bwd(rows)");
+  hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 64)), dim3(64), 0, st, a, (const float*)rowsum, chansum,
+                     mode == 3 ? nullptr : dp0, dp1);
+  AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
+  const float inv_m = 1.0f / (float)((long)N * HW);
+  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)chansum, inv_m, batch_stats, dx);
+  AGL_CHECK_LAUNCH("agl_norm_bwd(apply)");
+  return AGL_OK;
+}
+
+}  // extern "C"

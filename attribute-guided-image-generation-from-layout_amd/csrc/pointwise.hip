@@ -1,0 +1,500 @@
+// HBM-bound elementwise / gather / small-reduction kernels of the G+D path (fp32, NCHW):
+// bilinear box crop (fwd gather, bwd scatter-add), ConvLSTM gate math, ReLU backward, 2x2 average
+// pool, nearest up-sampling (and its sum-pool adjoint), spatial sums, row gathers, channel sums,
+// the VAE re-parameterisation and fused Adam.
+#include "agl_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int nblocks(long n) { long b = (n + TPB - 1) / TPB; return (int)(b < 1 ? 1 : b); }
+
+// ---------------------------------------------------------------- crop
+// torch.linspace(0,1,steps)[j] and torch.linspace(1,0,steps)[j] as the CPU kernel evaluates them
+// (two half ramps anchored at start / end); models/bilinear.py:272-275.
+__device__ __forceinline__ void lin_weights(int j, int steps, float& w_start, float& w_end) {
+  if (steps == 1) { w_start = 1.f; w_end = 0.f; return; }
+  const float step_up = 1.0f / (float)(steps - 1);
+  const float step_dn = -1.0f / (float)(steps - 1);
+  if (j < steps / 2) {
+    w_end = step_up * (float)j;
+    w_start = 1.0f + step_dn * (float)j;
+  } else {
+    w_end = 1.0f - step_up * (float)(steps - 1 - j);
+    w_start = 0.0f - step_dn * (float)(steps - 1 - j);
+  }
+}
+
+__device__ __forceinline__ float unnormalize(float g, int size, int align) {
+  return align ? (g + 1.f) * 0.5f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) * 0.5f;
+}
+
+struct CropGeom { int x0, y0; float wx1, wy1; };  // north-west tap and the weight of the +1 taps
+
+__device__ __forceinline__ CropGeom crop_geom(const float* box, int i, int j, int HH, int WW, int H, int W, int align) {
+  const float bx0 = 2.f * box[0] - 1.f, by0 = 2.f * box[1] - 1.f, bx1 = 2.f * box[2] - 1.f, by1 = 2.f * box[3] - 1.f;
+  float ws, we;
+  lin_weights(j, WW, ws, we);
+  const float gx = ws * bx0 + we * bx1;
+  lin_weights(i, HH, ws, we);
+  const float gy = ws * by0 + we * by1;
+  const float ix = unnormalize(gx, W, align), iy = unnormalize(gy, H, align);
+  const float fx = floorf(ix), fy = floorf(iy);
+  CropGeom g;
+  g.x0 = (int)fx; g.y0 = (int)fy; g.wx1 = ix - fx; g.wy1 = iy - fy;
+  return g;
+}
+
+__global__ void crop_fwd(const float* __restrict__ feats, const float* __restrict__ boxes, const long long* __restrict__ o2i,
+                         float* __restrict__ out, int B, int C, int H, int W, int HH, int WW, int align) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long total = (long)B * C * HH * WW;
+  if (idx >= total) return;
+  const int j = (int)(idx % WW);
+  long t = idx / WW;
+  const int i = (int)(t % HH); t /= HH;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  const CropGeom g = crop_geom(boxes + 4 * b, i, j, HH, WW, H, W, align);
+  const float* src = feats + ((long)o2i[b] * C + c) * H * W;
+  const bool xa = (unsigned)g.x0 < (unsigned)W, xb = (unsigned)(g.x0 + 1) < (unsigned)W;
+  const bool ya = (unsigned)g.y0 < (unsigned)H, yb = (unsigned)(g.y0 + 1) < (unsigned)H;
+  const float wx0 = 1.f - g.wx1, wy0 = 1.f - g.wy1;
+  float v = 0.f;
+  if (ya && xa) v += src[g.y0 * W + g.x0] * (wx0 * wy0);
+  if (ya && xb) v += src[g.y0 * W + g.x0 + 1] * (g.wx1 * wy0);
+  if (yb && xa) v += src[(g.y0 + 1) * W + g.x0] * (wx0 * g.wy1);
+  if (yb && xb) v += src[(g.y0 + 1) * W + g.x0 + 1] * (g.wx1 * g.wy1);
+  out[idx] = v;
+}
+
+__global__ void crop_bwd(const float* __restrict__ dout, const float* __restrict__ boxes, const long long* __restrict__ o2i,
+                         float* __restrict__ dfeats, int B, int C, int H, int W, int HH, int WW, int align) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long total = (long)B * C * HH * WW;
+  if (idx >= total) return;
+  const int j = (int)(idx % WW);
+  long t = idx / WW;
+  const int i = (int)(t % HH); t /= HH;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  const CropGeom g = crop_geom(boxes + 4 * b, i, j, HH, WW, H, W, align);
+  float* dst = dfeats + ((long)o2i[b] * C + c) * H * W;
+  const bool xa = (unsigned)g.x0 < (unsigned)W, xb = (unsigned)(g.x0 + 1) < (unsigned)W;
+  const bool ya = (unsigned)g.y0 < (unsigned)H, yb = (unsigned)(g.y0 + 1) < (unsigned)H;
+  const float wx0 = 1.f - g.wx1, wy0 = 1.f - g.wy1;
+  const float d = dout[idx];
+  if (ya && xa) atomicAdd(dst + g.y0 * W + g.x0, d * (wx0 * wy0));
+  if (ya && xb) atomicAdd(dst + g.y0 * W + g.x0 + 1, d * (g.wx1 * wy0));
+  if (yb && xa) atomicAdd(dst + (g.y0 + 1) * W + g.x0, d * (wx0 * g.wy1));
+  if (yb && xb) atomicAdd(dst + (g.y0 + 1) * W + g.x0 + 1, d * (g.wx1 * g.wy1));
+}
+
+// ---------------------------------------------------------------- ConvLSTM gates (i, f, o, g order)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void lstm_gates_fwd(const float* __restrict__ ccx, const long long* __restrict__ rows, const float* __restrict__ cch,
+                               const float* __restrict__ c_prev, float* __restrict__ h, float* __restrict__ c,
+                               float* __restrict__ gates, int B, int hid, int S) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long total = (long)B * hid * S;
+  if (idx >= total) return;
+  const int s = (int)(idx % S);
+  long t = idx / S;
+  const int ch = (int)(t % hid);
+  const int b = (int)(t / hid);
+  const long src = (rows ? (long)rows[b] : (long)b) * 4 * hid * S;
+  const long loc = (long)b * 4 * hid * S;
+  float pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long o = (long)(q * hid + ch) * S + s;
+    pre[q] = ccx[src + o] + (cch ? cch[loc + o] : 0.f);
+  }
+  const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), go = sigmoidf_(pre[2]), gg = tanhf(pre[3]);
+  const float cp = c_prev ? c_prev[idx] : 0.f;
+  const float cn = gf * cp + gi * gg;
+  c[idx] = cn;
+  h[idx] = go * tanhf(cn);
+  gates[loc + (long)(0 * hid + ch) * S + s] = gi;
+  gates[loc + (long)(1 * hid + ch) * S + s] = gf;
+  gates[loc + (long)(2 * hid + ch) * S + s] = go;
+  gates[loc + (long)(3 * hid + ch) * S + s] = gg;
+}
+
+// dh_a (+ dh_b over the first Bb rows) and dc_next (first Bc rows) -> dcc (pre-activation grads), dc_prev
+__global__ void lstm_gates_bwd(const float* __restrict__ dh_a, const float* __restrict__ dh_b, int Bb,
+                               const float* __restrict__ dc_next, int Bc, const float* __restrict__ gates,
+                               const float* __restrict__ c_prev, const float* __restrict__ c, float* __restrict__ dcc,
+                               float* __restrict__ dc_prev, int B, int hid, int S) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long total = (long)B * hid * S;
+  if (idx >= total) return;
+  const int s = (int)(idx % S);
+  long t = idx / S;
+  const int ch = (int)(t % hid);
+  const int b = (int)(t / hid);
+  const long loc = (long)b * 4 * hid * S;
+  const float gi = gates[loc + (long)(0 * hid + ch) * S + s], gf = gates[loc + (long)(1 * hid + ch) * S + s];
+  const float go = gates[loc + (long)(2 * hid + ch) * S + s], gg = gates[loc + (long)(3 * hid + ch) * S + s];
+  float dh = dh_a ? dh_a[idx] : 0.f;
+  if (dh_b && b < Bb) dh += dh_b[idx];
+  const float tc = tanhf(c[idx]);
+  float dc = dh * go * (1.f - tc * tc);
+  if (dc_next && b < Bc) dc += dc_next[idx];
+  const float cp = c_prev ? c_prev[idx] : 0.f;
+  dcc[loc + (long)(0 * hid + ch) * S + s] = dc * gg * gi * (1.f - gi);
+  dcc[loc + (long)(1 * hid + ch) * S + s] = dc * cp * gf * (1.f - gf);
+  dcc[loc + (long)(2 * hid + ch) * S + s] = dh * tc * go * (1.f - go);
+  dcc[loc + (long)(3 * hid + ch) * S + s] = dc * gi * (1.f - gg * gg);
+  dc_prev[idx] = dc * gf;
+}
+
+// ---------------------------------------------------------------- small elementwise helpers
+__global__ void relu_bwd_k(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void axpby_k(const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// out[r] = src[rows[r]] for rows of `len` floats (accumulate: out[r] += ...)
+__global__ void gather_rows_k(const float* __restrict__ src, const long long* __restrict__ rows, float* __restrict__ out, long R, long len, int accumulate) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= R * len) return;
+  const long r = i / len, o = i - r * len;
+  const float v = src[(long)rows[r] * len + o];
+  out[i] = accumulate ? out[i] + v : v;
+}
+// out[rows[r]] = src[r]  (rows must be unique)
+__global__ void scatter_rows_k(const float* __restrict__ src, const long long* __restrict__ rows, float* __restrict__ out, long R, long len) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= R * len) return;
+  const long r = i / len, o = i - r * len;
+  out[(long)rows[r] * len + o] = src[i];
+}
+
+// 2x2 average pool, optional ReLU on the input (models/discriminator.py:25-26 and the in-place ReLU of :71)
+__global__ void avgpool2_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int in_relu) {
+  const int OH = H / 2, OW = W / 2;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * OH * OW) return;
+  const int ow = (int)(i % OW);
+  long t = i / OW;
+  const int oh = (int)(t % OH);
+  const long nc = t / OH;
+  const float* p = x + nc * H * W + (long)(2 * oh) * W + 2 * ow;
+  float a = p[0], b = p[1], c = p[W], d = p[W + 1];
+  if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); c = fmaxf(c, 0.f); d = fmaxf(d, 0.f); }
+  y[i] = (a + b + c + d) * 0.25f;
+}
+// dx = 0.25*dy broadcast over the 2x2 window (masked by x>0 when in_relu); accumulate: dx += ...
+__global__ void avgpool2_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long NC, int H, int W, int in_relu, int accumulate) {
+  const int OH = H / 2, OW = W / 2;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * H * W) return;
+  const int w = (int)(i % W);
+  long t = i / W;
+  const int h = (int)(t % H);
+  const long nc = t / H;
+  float v = 0.f;
+  if (h < 2 * OH && w < 2 * OW) v = 0.25f * dy[nc * OH * OW + (long)(h / 2) * OW + w / 2];
+  if (in_relu && !(x[i] > 0.f)) v = 0.f;
+  dx[i] = accumulate ? dx[i] + v : v;
+}
+
+// nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
+__global__ void upsample_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int k) {
+  const int OH = H << k, OW = W << k;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * OH * OW) return;
+  const int ow = (int)(i % OW);
+  long t = i / OW;
+  const int oh = (int)(t % OH);
+  const long nc = t / OH;
+  y[i] = x[nc * H * W + (long)(oh >> k) * W + (ow >> k)];
+}
+__global__ void upsample_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, long NC, int H, int W, int k, int accumulate) {
+  const int OH = H << k, OW = W << k, f = 1 << k;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * H * W) return;
+  const int w = (int)(i % W);
+  long t = i / W;
+  const int h = (int)(t % H);
+  const long nc = t / H;
+  const float* p = dy + nc * OH * OW + (long)(h << k) * OW + (w << k);
+  float s = 0.f;
+  for (int a = 0; a < f; ++a)
+    for (int b = 0; b < f; ++b) s += p[(long)a * OW + b];
+  dx[i] = accumulate ? dx[i] + s : s;
+}
+
+// y[n,c] = scale * sum_hw (relu?)(x[n,c,hw]) ; one wave per row
+__global__ __launch_bounds__(256) void sum_hw_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int HW, int in_relu, float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= NC) return;
+  float s = 0.f;
+  for (int i = threadIdx.x & 63; i < HW; i += 64) {
+    float v = x[row * HW + i];
+    s += in_relu ? fmaxf(v, 0.f) : v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) y[row] = s * scale;
+}
+__global__ void sum_hw_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long NC, int HW, int in_relu, float scale) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * HW) return;
+  float v = dy[i / HW] * scale;
+  if (in_relu && !(x[i] > 0.f)) v = 0.f;
+  dx[i] = v;
+}
+
+// out[c] = sum_{n,hw} x[n,c,hw]   (bias gradients); one block per channel, fixed order -> deterministic
+__global__ __launch_bounds__(256) void channel_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, int accumulate) {
+  __shared__ double sc[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  const long total = (long)N * HW;
+  for (long e = threadIdx.x; e < total; e += 256) {
+    const long n = e / HW, hw = e - n * HW;
+    s += x[(n * C + c) * HW + hw];
+  }
+  s = block_sum_256(s, sc);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// z = eps*exp(0.5*logvar) + mu  (models/generator_obj_att.py:418-420)
+__global__ void reparam_fwd_k(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps, float* __restrict__ z, long n) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) z[i] = eps[i] * expf(0.5f * logvar[i]) + mu[i];
+}
+__global__ void reparam_bwd_k(const float* __restrict__ dz, const float* __restrict__ logvar, const float* __restrict__ eps, float* __restrict__ dlogvar, long n) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) dlogvar[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+}
+
+// torch.optim.Adam (no amsgrad / weight decay), single fused pass over a flat parameter arena
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                       float beta1, float beta2, float step_size, float bc2_sqrt, float eps, float grad_scale) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const float gr = g[i] * grad_scale;
+  const float mi = m[i] + (1.f - beta1) * (gr - m[i]);          // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v[i] * beta2 + (1.f - beta2) * gr * gr;      // mul_(beta2).addcmul_(g, g, 1-beta2)
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;                 // (sqrt(v)/sqrt(bc2)).add_(eps)
+  p[i] = p[i] - step_size * (mi / denom);                       // addcdiv_(m, denom, -step_size)
+}
+
+// Rank-1 layout tensor through the 1x1, pad-1 convolution c0 (generator_obj_att.py:489-494):
+// y[o,c,i,j] = u[o,c] * mask[o,i-pad,j-pad] inside, 0 on the border; u = W_c0 . [obj_att ; z].
+// The (O,128,R,R) tensor of the reference is never materialised.
+__global__ void mask_outer_fwd_k(const float* __restrict__ u, const float* __restrict__ mask, float* __restrict__ y,
+                                 long OC, int C, int R, int pad) {
+  const int RP = R + 2 * pad;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= OC * RP * RP) return;
+  const int x = (int)(i % RP);
+  long t = i / RP;
+  const int yy = (int)(t % RP);
+  const long oc = t / RP;
+  const long o = oc / C;
+  const int my = yy - pad, mx = x - pad;
+  float v = 0.f;
+  if ((unsigned)my < (unsigned)R && (unsigned)mx < (unsigned)R) v = u[oc] * mask[o * R * R + (long)my * R + mx];
+  y[i] = v;
+}
+// du[o,c] = sum_{i,j} dy[o,c,i+pad,j+pad] * mask[o,i,j]   (one wave per (o,c))
+__global__ __launch_bounds__(256) void mask_outer_bwd_k(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                        float* __restrict__ du, long OC, int C, int R, int pad) {
+  const long oc = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (oc >= OC) return;
+  const int RP = R + 2 * pad;
+  const long o = oc / C;
+  const float* d = dy + oc * RP * RP;
+  const float* m = mask + o * R * R;
+  float s = 0.f;
+  for (int e = threadIdx.x & 63; e < R * R; e += 64) {
+    const int i = e / R, j = e - i * R;
+    s += d[(long)(i + pad) * RP + j + pad] * m[e];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) du[oc] = s;
+}
+
+}  // namespace
+
+#define LAUNCH1D(kernel, n, ...)                                                                   \
+  hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(TPB), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" {
+
+int agl_crop_fwd(const float* feats, const float* boxes, const long long* box_to_img, float* out, int N, int B, int C, int H,
+                 int W, int HH, int WW, int align_corners, void* stream) {
+  AGL_REQUIRE(feats && boxes && box_to_img && out, "agl_crop_fwd: null pointer");
+  AGL_REQUIRE(N > 0 && B >= 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "agl_crop_fwd: bad extent");
+  if (B == 0) return AGL_OK;
+  LAUNCH1D(crop_fwd, (long)B * C * HH * WW, feats, boxes, box_to_img, out, B, C, H, W, HH, WW, align_corners);
+  AGL_CHECK_LAUNCH("agl_crop_fwd");
+  return AGL_OK;
+}
+
+// dfeats must be zero-filled (or hold a gradient to accumulate into) by the caller.
+int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C, int H,
+                 int W, int HH, int WW, int align_corners, void* stream) {
+  AGL_REQUIRE(dout && boxes && box_to_img && dfeats, "agl_crop_bwd: null pointer");
+  AGL_REQUIRE(N > 0 && B >= 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "agl_crop_bwd: bad extent");
+  if (B == 0) return AGL_OK;
+  LAUNCH1D(crop_bwd, (long)B * C * HH * WW, dout, boxes, box_to_img, dfeats, B, C, H, W, HH, WW, align_corners);
+  AGL_CHECK_LAUNCH("agl_crop_bwd");
+  return AGL_OK;
+}
+
+int agl_lstm_gates_fwd(const float* ccx, const long long* rows, const float* cch, const float* c_prev, float* h, float* c,
+                       float* gates, int B, int hid, int S, void* stream) {
+  AGL_REQUIRE(ccx && h && c && gates && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_fwd: bad argument");
+  LAUNCH1D(lstm_gates_fwd, (long)B * hid * S, ccx, rows, cch, c_prev, h, c, gates, B, hid, S);
+  AGL_CHECK_LAUNCH("agl_lstm_gates_fwd");
+  return AGL_OK;
+}
+
+int agl_lstm_gates_bwd(const float* dh_a, const float* dh_b, int Bb, const float* dc_next, int Bc, const float* gates,
+                       const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S, void* stream) {
+  AGL_REQUIRE(gates && c && dcc && dc_prev && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_bwd: bad argument");
+  AGL_REQUIRE(Bb <= B && Bc <= B, "agl_lstm_gates_bwd: prefix larger than batch");
+  LAUNCH1D(lstm_gates_bwd, (long)B * hid * S, dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S);
+  AGL_CHECK_LAUNCH("agl_lstm_gates_bwd");
+  return AGL_OK;
+}
+
+int agl_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {
+  AGL_REQUIRE(dy && y && dx && n >= 0, "agl_relu_bwd: bad argument");
+  if (n == 0) return AGL_OK;
+  LAUNCH1D(relu_bwd_k, n, dy, y, dx, n);
+  AGL_CHECK_LAUNCH("agl_relu_bwd");
+  return AGL_OK;
+}
+
+// out = alpha*a + beta*b (b may be NULL)
+int agl_axpby(const float* a, const float* b, float alpha, float beta, float* out, long n, void* stream) {
+  AGL_REQUIRE(a && out && n >= 0, "agl_axpby: bad argument");
+  if (n == 0) return AGL_OK;
+  LAUNCH1D(axpby_k, n, a, b, alpha, beta, out, n);
+  AGL_CHECK_LAUNCH("agl_axpby");
+  return AGL_OK;
+}
+
+int agl_gather_rows(const float* src, const long long* rows, float* out, long R, long len, int accumulate, void* stream) {
+  AGL_REQUIRE(src && rows && out && R >= 0 && len > 0, "agl_gather_rows: bad argument");
+  if (R == 0) return AGL_OK;
+  LAUNCH1D(gather_rows_k, R * len, src, rows, out, R, len, accumulate);
+  AGL_CHECK_LAUNCH("agl_gather_rows");
+  return AGL_OK;
+}
+
+int agl_scatter_rows(const float* src, const long long* rows, float* out, long R, long len, void* stream) {
+  AGL_REQUIRE(src && rows && out && R >= 0 && len > 0, "agl_scatter_rows: bad argument");
+  if (R == 0) return AGL_OK;
+  LAUNCH1D(scatter_rows_k, R * len, src, rows, out, R, len);
+  AGL_CHECK_LAUNCH("agl_scatter_rows");
+  return AGL_OK;
+}
+
+int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream) {
+  AGL_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2, "agl_avgpool2_fwd: bad argument");
+  LAUNCH1D(avgpool2_fwd_k, NC * (H / 2) * (W / 2), x, y, NC, H, W, in_relu);
+  AGL_CHECK_LAUNCH("agl_avgpool2_fwd");
+  return AGL_OK;
+}
+
+int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && dx && (!in_relu || x) && NC > 0 && H >= 2 && W >= 2, "agl_avgpool2_bwd: bad argument");
+  LAUNCH1D(avgpool2_bwd_k, NC * H * W, dy, x, dx, NC, H, W, in_relu, accumulate);
+  AGL_CHECK_LAUNCH("agl_avgpool2_bwd");
+  return AGL_OK;
+}
+
+int agl_upsample_nearest_fwd(const float* x, float* y, long NC, int H, int W, int log2_factor, void* stream) {
+  AGL_REQUIRE(x && y && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5, "agl_upsample_nearest_fwd: bad argument");
+  LAUNCH1D(upsample_fwd_k, NC * ((long)H << log2_factor) * ((long)W << log2_factor), x, y, NC, H, W, log2_factor);
+  AGL_CHECK_LAUNCH("agl_upsample_nearest_fwd");
+  return AGL_OK;
+}
+
+int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, int log2_factor, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && dx && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5, "agl_upsample_nearest_bwd: bad argument");
+  LAUNCH1D(upsample_bwd_k, NC * H * W, dy, dx, NC, H, W, log2_factor, accumulate);
+  AGL_CHECK_LAUNCH("agl_upsample_nearest_bwd");
+  return AGL_OK;
+}
+
+int agl_sum_hw_fwd(const float* x, float* y, long NC, int HW, int in_relu, float scale, void* stream) {
+  AGL_REQUIRE(x && y && NC > 0 && HW > 0, "agl_sum_hw_fwd: bad argument");
+  hipLaunchKernelGGL(sum_hw_fwd_k, dim3(agl_cdiv(NC, 4)), dim3(256), 0, (hipStream_t)stream, x, y, NC, HW, in_relu, scale);
+  AGL_CHECK_LAUNCH("agl_sum_hw_fwd");
+  return AGL_OK;
+}
+
+int agl_sum_hw_bwd(const float* dy, const float* x, float* dx, long NC, int HW, int in_relu, float scale, void* stream) {
+  AGL_REQUIRE(dy && dx && (!in_relu || x) && NC > 0 && HW > 0, "agl_sum_hw_bwd: bad argument");
+  LAUNCH1D(sum_hw_bwd_k, NC * HW, dy, x, dx, NC, HW, in_relu, scale);
+  AGL_CHECK_LAUNCH("agl_sum_hw_bwd");
+  return AGL_OK;
+}
+
+int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+  AGL_REQUIRE(x && out && N > 0 && C > 0 && HW > 0, "agl_channel_sum: bad argument");
+  hipLaunchKernelGGL(channel_sum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW, accumulate);
+  AGL_CHECK_LAUNCH("agl_channel_sum");
+  return AGL_OK;
+}
+
+int agl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream) {
+  AGL_REQUIRE(mu && logvar && eps && z && n > 0, "agl_reparam_fwd: bad argument");
+  LAUNCH1D(reparam_fwd_k, n, mu, logvar, eps, z, n);
+  AGL_CHECK_LAUNCH("agl_reparam_fwd");
+  return AGL_OK;
+}
+
+int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream) {
+  AGL_REQUIRE(dz && logvar && eps && dlogvar && n > 0, "agl_reparam_bwd: bad argument");
+  LAUNCH1D(reparam_bwd_k, n, dz, logvar, eps, dlogvar, n);
+  AGL_CHECK_LAUNCH("agl_reparam_bwd");
+  return AGL_OK;
+}
+
+// One Adam step over a flat arena of n floats; `step` is the 1-based step count.  grad_scale multiplies the
+// gradient first (1/world_size after a sum all-reduce).
+int agl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, float grad_scale, void* stream) {
+  AGL_REQUIRE(p && g && m && v && n > 0 && step >= 1, "agl_adam_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  LAUNCH1D(adam_k, n, p, g, m, v, n, beta1, beta2, step_size, bc2_sqrt, eps, grad_scale);
+  AGL_CHECK_LAUNCH("agl_adam_step");
+  return AGL_OK;
+}
+
+int agl_mask_outer_fwd(const float* u, const float* mask, float* y, int O, int C, int R, int pad, void* stream) {
+  AGL_REQUIRE(u && mask && y && O > 0 && C > 0 && R > 0 && pad >= 0, "agl_mask_outer_fwd: bad argument");
+  const long RP = R + 2 * pad;
+  AGL_REQUIRE((long)O * C * RP * RP < (1L << 31), "agl_mask_outer_fwd: tensor too large");
+  LAUNCH1D(mask_outer_fwd_k, (long)O * C * RP * RP, u, mask, y, (long)O * C, C, R, pad);
+  AGL_CHECK_LAUNCH("agl_mask_outer_fwd");
+  return AGL_OK;
+}
+
+int agl_mask_outer_bwd(const float* dy, const float* mask, float* du, int O, int C, int R, int pad, void* stream) {
+  AGL_REQUIRE(dy && mask && du && O > 0 && C > 0 && R > 0 && pad >= 0, "agl_mask_outer_bwd: bad argument");
+  hipLaunchKernelGGL(mask_outer_bwd_k, dim3(agl_cdiv((long)O * C, 4)), dim3(256), 0, (hipStream_t)stream, dy, mask, du,
+                     (long)O * C, C, R, pad);
+  AGL_CHECK_LAUNCH("agl_mask_outer_bwd");
+  return AGL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+/* agl.h — C ABI of libagl.so: the MI355X (gfx950) kernels behind the G+D train-step hot path of
+ * ubc-vision/attribute-guided-image-generation-from-layout.
+ *
+ * The reference has no FFI of its own: its boundary is the Python nn.Module surface, and every number
+ * is produced by a PyTorch op.  Each entry point below therefore names the torch
+ * call site(s) in the reference it replaces (paths relative to the reference root).  The Python host
+ * (attribute-guided-image-generation-from-layout_amd/agl/lib.py) binds these with ctypes; see
+ * INTEGRATION.md for the binding a maintainer of the reference would add.
+ *
+ * Conventions: all tensors fp32, NCHW, contiguous, device memory borrowed for the duration of the
+ * call; int64 index tensors (`long long`); `stream` is a hipStream_t (NULL = default stream); every
+ * function only enqueues work (no allocation, no synchronisation) and returns 0 on success, non-zero
+ * on a rejected call with a message in agl_last_error().  Workspaces are caller-provided.
+ */
+#ifndef AGL_H
+#define AGL_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int agl_version(void);
+const char* agl_last_error(void);
+
+/* ---- convolutions (fp32 implicit GEMM on MFMA 32x32x2 f32) -------------------------------------
+ * F.conv2d / nn.Conv2d call sites: models/generator_obj_att.py:374-386 (CropEncoder), :474-483
+ * (LayoutEncoder), :93 (ConvLSTMCell), :53,56 (ResidualBlock), :432,435 (GlobalEncoder), :528,544
+ * (Decoder); models/generator_obj_att128.py:549-557 (c5,c6,c7); models/spade/networks/normalization.py:87-91;
+ * models/discriminator.py:37,39,44,72,74,79; nn.Linear (:218,252,253,162,122; generator :392,393,582-586)
+ * is the ks=1, H=W=1 case.  ks in {1,3,4,5,7}; stride in {1,2}.
+ *   up_log2  : x is nearest-upsampled by 2^up_log2 on the fly (F.interpolate(...,'nearest'),
+ *              normalization.py:100 and generator_obj_att128.py:588) — H,W are the stored sizes.
+ *   in_relu  : relu applied to x while gathering (discriminator.py:71 in-place ReLU).
+ *   relu     : relu on the output;  accumulate: y += result (before relu).                        */
+int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout,
+                   int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate, void* stream);
+/* Gradient wrt the input of the conv above; ALSO the forward of nn.ConvTranspose2d(k=4,s=2,p=1)
+ * (generator_obj_att.py:532,536,540) with w stored [C_in_T][C_out_T][4][4].  pos_mask (optional, shaped
+ * like dx): dx is zeroed where pos_mask <= 0 (backward of a fused input ReLU).                      */
+int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, int N,
+                        int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int relu,
+                        int accumulate, void* stream);
+long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
+int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H,
+                          int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
+                          int accumulate, void* stream);
+
+/* ---- batch-statistics normalisation --------------------------------------------------------------
+ * nn.BatchNorm2d/1d in training mode (generator_obj_att.py:35,54,57,433,583,585; normalization.py:78):
+ * per-channel mean / rstd over (N,HW), running stats with momentum and unbiased variance.            */
+long agl_bn_stats_ws_bytes(int N, int C, int HW);
+int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* rstd,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, void* ws, long ws_bytes,
+                 void* stream);
+int agl_bn_stats_eval(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
+                      void* stream);
+/* y = modulate(xhat) (+residual) (relu).  mode 0: none; 1: gamma[C],beta[C] (BatchNorm affine);
+ * 2: table[V][2C] indexed by labels[N] (ConditionalBatchNorm2d, generator_obj_att.py:40-44);
+ * 3: gb[N][2C][HW], y = xhat*(1+gamma)+beta (SPADE, normalization.py:106).                           */
+int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                       const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
+                       void* stream);
+long agl_norm_bwd_ws_bytes(int N, int C);
+int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
+                 const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                 float* dp0, float* dp1, int N, int C, int HW, void* ws, long ws_bytes, void* stream);
+
+/* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
+ * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;
+ * align_corners as in torch (default 0).  Backward scatter-adds into dfeats (caller zero-fills).      */
+int agl_crop_fwd(const float* feats, const float* boxes, const long long* box_to_img, float* out, int N, int B, int C,
+                 int H, int W, int HH, int WW, int align_corners, void* stream);
+int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C,
+                 int H, int W, int HH, int WW, int align_corners, void* stream);
+
+/* ---- ConvLSTM gate math (generator_obj_att.py:105-112), gates stored post-activation in i,f,o,g order */
+int agl_lstm_gates_fwd(const float* ccx, const long long* rows, const float* cch, const float* c_prev, float* h, float* c,
+                       float* gates, int B, int hid, int S, void* stream);
+int agl_lstm_gates_bwd(const float* dh_a, const float* dh_b, int Bb, const float* dc_next, int Bc, const float* gates,
+                       const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S,
+                       void* stream);
+
+/* ---- small data movement / reductions ------------------------------------------------------------ */
+int agl_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream);
+int agl_axpby(const float* a, const float* b, float alpha, float beta, float* out, long n, void* stream);
+int agl_gather_rows(const float* src, const long long* rows, float* out, long R, long len, int accumulate, void* stream);
+int agl_scatter_rows(const float* src, const long long* rows, float* out, long R, long len, void* stream);
+/* F.avg_pool2d(k=2) (discriminator.py:25-26) / nn.AdaptiveAvgPool2d(8) on 16x16 (generator_obj_att128.py:486) */
+int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream);
+int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate,
+                     void* stream);
+int agl_upsample_nearest_fwd(const float* x, float* y, long NC, int H, int W, int log2_factor, void* stream);
+int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, int log2_factor, int accumulate,
+                             void* stream);
+/* torch.sum(h, dim=(2,3)) (discriminator.py:226; generator_obj_att.py:444) and AdaptiveAvgPool2d(1) (:389) */
+int agl_sum_hw_fwd(const float* x, float* y, long NC, int HW, int in_relu, float scale, void* stream);
+int agl_sum_hw_bwd(const float* dy, const float* x, float* dx, long NC, int HW, int in_relu, float scale, void* stream);
+int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream);
+/* z = eps*exp(.5*logvar)+mu (generator_obj_att.py:418-420) */
+int agl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream);
+int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream);
+
+/* y[o,c] = u[o,c] (x) zero-padded mask[o]: the rank-1 layout tensor through LayoutEncoder.c0 (k1,p1)
+ * (generator_obj_att.py:489-494) without materialising the (O,128,R,R) product. */
+int agl_mask_outer_fwd(const float* u, const float* mask, float* y, int O, int C, int R, int pad, void* stream);
+int agl_mask_outer_bwd(const float* dy, const float* mask, float* du, int O, int C, int R, int pad, void* stream);
+
+/* ---- spectral norm (torch.nn.utils.spectral_norm via add_sn, discriminator.py:15-22), batched per net */
+struct AglSnLayer {
+  const float* w; float* u; float* v; float* w_sn; float* sigma; float* tmp; float* u_used; float* v_used;
+  const float* g; float* dw; int rows, cols;
+};
+long agl_sn_layer_desc_bytes(void);
+long agl_sn_tmp_floats(int rows, int cols);
+int agl_sn_forward(const void* host_layers, int n_layers, int power_iter, float eps, void* stream);
+int agl_sn_backward(const void* host_layers, int n_layers, void* stream);
+
+/* ---- losses of train64.py:195-245, 284-354 -----------------------------------------------------------
+ * Single-workgroup, fixed-order reductions.  Each call writes the UNWEIGHTED loss to *loss_out and, when the
+ * gradient pointer is not NULL, coef * d(loss)/d(input) (coef = lambda * mix weight of the training loop). */
+/* mean(BCEWithLogits(x, target)) with a constant target (F.binary_cross_entropy_with_logits vs full_like) */
+int agl_bce_logits_const(const float* x, long n, float target, float coef, float* loss_out, float* dx, void* stream);
+/* mean over annotated rows (rows whose target row-sum != 0; train64.py:241,323) of BCEWithLogits with
+ * pos_weight[A]; dx is written for all rows (zero for unselected ones). rows <= 4096. */
+int agl_bce_logits_posw(const float* x, const float* targets, const float* pos_weight, long rows, int A, float coef,
+                        float* loss_out, float* dx, void* stream);
+/* F.cross_entropy(logits[R][V], labels[R]) */
+int agl_cross_entropy(const float* logits, const long long* labels, long R, int V, float coef, float* loss_out,
+                      float* dlogits, void* stream);
+/* sum_n keep[n] * mean_len |a-b| / denom (train64.py:284-287); keep == NULL means all ones */
+int agl_l1_rows(const float* a, const float* b, const float* keep, long N, long len, float coef, float denom,
+                float* loss_out, float* da, void* stream);
+/* -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) (train64.py:294-295) */
+int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* loss_out, float* dmu, float* dlogvar,
+               void* stream);
+
+/* ---- optimiser (torch.optim.Adam, train64.py:111-114) over a flat fp32 arena ---------------------- */
+int agl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,271 @@
+"""GPU parity of every HIP op (through the C ABI) against the same op evaluated by PyTorch on the CPU
+(the arithmetic the reference runs) and against the reference-generated fixtures in
+tests/golden/ops_small.npz.  Tolerances are fp32: 2e-5 relative-to-max on forward values, 1e-4 on
+gradients (different summation order; atomics in the crop scatter)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f"{what}: rel-to-max err {err:.3e} > {tol:.1e}"
+
+
+def rn(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, ks, stride, pad
+    (2, 3, 32, 32, 64, 7, 1, 3),      # crop encoder c1 / decoder c5 shape class
+    (3, 64, 18, 18, 128, 4, 2, 1),    # k4 s2 even
+    (2, 128, 33, 33, 96, 4, 2, 1),    # k4 s2 odd input (LayoutEncoder c3: 33 -> 16)
+    (5, 192, 8, 8, 256, 3, 1, 1),     # decoder c0_new
+    (4, 72, 8, 8, 48, 5, 1, 2),       # ConvLSTM-like k5
+    (2, 64, 16, 16, 3, 7, 1, 3),      # tiny Cout (decoder c4)
+    (3, 40, 9, 7, 24, 1, 1, 0),       # 1x1
+    (2, 16, 6, 6, 20, 1, 1, 1),       # 1x1 with padding (LayoutEncoder c0)
+    (70, 170, 1, 1, 128, 1, 1, 0),    # Linear as 1x1
+    (1, 3, 10, 12, 8, 3, 1, 1),       # first D conv, ragged
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case):
+    from agl import functional as F
+    N, Cin, H, W, Cout, ks, s, p = case
+    x, w, b = rn(N, Cin, H, W), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = TF.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    yg = F.conv2d(xg, wg, bg, s, p)
+    yg.backward(dev(gy))
+    close(yg, yr, 2e-5, "y")
+    close(xg.grad, xr.grad, 1e-4, "dx")
+    close(wg.grad, wr.grad, 1e-4, "dw")
+    close(bg.grad, br.grad, 1e-4, "db")
+
+
+def test_conv2d_fusions():
+    """input ReLU, output ReLU, folded nearest up-sampling, accumulate-into-addend."""
+    from agl import functional as F
+    x, w, b = rn(3, 12, 8, 8), rn(20, 12, 3, 3, seed=1) * 0.1, rn(20, seed=2)
+    add = rn(3, 20, 16, 16, seed=5)
+    xr, wr, br, ar = (t.clone().requires_grad_(True) for t in (x, w, b, add))
+    yr = TF.conv2d(TF.interpolate(xr, scale_factor=2, mode="nearest"), wr, br, padding=1) + ar * 1.0
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    xg, wg, bg, ag = (dev(t).requires_grad_(True) for t in (x, w, b, add))
+    yg = F.conv2d(xg, wg, bg, 1, 1, up=1, addend=ag * 1.0)
+    yg.backward(dev(gy))
+    for n, a, r in (("y", yg, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad), ("dadd", ag.grad, ar.grad)):
+        close(a, r, 1e-4, "up+addend " + n)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = TF.relu(TF.conv2d(TF.relu(xr), wr, br, padding=1))
+    gy = rn(*yr.shape, seed=4)
+    yr.backward(gy)
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    yg = F.conv2d(xg, wg, bg, 1, 1, in_relu=True, relu=True)
+    yg.backward(dev(gy))
+    for n, a, r in (("y", yg, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad)):
+        close(a, r, 1e-4, "in_relu+relu " + n)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8, 24), (2, 128, 16, 16, 64), (1, 5, 3, 4, 7)])
+def test_conv_transpose(shape):
+    from agl import functional as F
+    N, Cin, H, W, Cout = shape
+    x, w = rn(N, Cin, H, W), rn(Cin, Cout, 4, 4, seed=1) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = TF.conv_transpose2d(xr, wr, None, stride=2, padding=1)
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    yg = F.conv_transpose2d_k4s2p1(xg, wg)
+    yg.backward(dev(gy))
+    close(yg, yr, 2e-5, "y")
+    close(xg.grad, xr.grad, 1e-4, "dx")
+    close(wg.grad, wr.grad, 1e-4, "dw")
+
+
+@pytest.mark.parametrize("shape", [(7, 6, 5, 4), (24, 64, 33, 33), (9, 1024, 2, 2), (50, 128, 1, 1), (3, 16, 40, 40)])
+@pytest.mark.parametrize("mode", ["plain", "affine", "cond", "spade"])
+def test_norm_modes(shape, mode):
+    from agl import functional as F
+    N, Cc, H, W = shape
+    x = rn(N, Cc, H, W) * 1.7 + 0.4
+    gy = rn(N, Cc, H, W, seed=9)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    nbt = torch.zeros((), dtype=torch.long)
+    xr = x.clone().requires_grad_(True)
+    xg = dev(x).requires_grad_(True)
+    rmg, rvg, nbtg = dev(rm.clone()), dev(rv.clone()), dev(nbt.clone())
+    extra = []
+    if mode in ("plain", "affine"):
+        wt, bs = (rn(Cc, seed=4) * 0.3 + 1, rn(Cc, seed=5) * 0.2) if mode == "affine" else (None, None)
+        wr_ = wt.clone().requires_grad_(True) if wt is not None else None
+        br_ = bs.clone().requires_grad_(True) if bs is not None else None
+        res = rn(N, Cc, H, W, seed=6)
+        yr = TF.relu(TF.batch_norm(xr, rm, rv, wr_, br_, True, 0.1, 1e-5)) if mode == "plain" else TF.batch_norm(xr, rm, rv, wr_, br_, True, 0.1, 1e-5) + res
+        wg_ = dev(wt).requires_grad_(True) if wt is not None else None
+        bg_ = dev(bs).requires_grad_(True) if bs is not None else None
+        yg = F.batch_norm(xg, rmg, rvg, nbtg, wg_, bg_, relu=(mode == "plain"), residual=dev(res) if mode == "affine" else None)
+        if wt is not None:
+            extra = [("dweight", wg_, wr_), ("dbias", bg_, br_)]
+    elif mode == "cond":
+        V = 5
+        table = torch.cat([1 + 0.1 * rn(V, Cc, seed=4), 0.1 * rn(V, Cc, seed=5)], dim=1)
+        labels = torch.randint(0, V, (N,), generator=torch.Generator().manual_seed(3))
+        tr = table.clone().requires_grad_(True)
+        gb = TF.embedding(labels, tr)
+        yr = TF.relu(gb[:, :Cc, None, None] * TF.batch_norm(xr, rm, rv, None, None, True, 0.1, 1e-5) + gb[:, Cc:, None, None])
+        tg = dev(table).requires_grad_(True)
+        yg = F.cond_batch_norm(xg, tg, dev(labels), rmg, rvg, nbtg, relu=True)
+        extra = [("dtable", tg, tr)]
+    else:
+        gbt = rn(N, 2 * Cc, H, W, seed=4) * 0.5
+        gr = gbt.clone().requires_grad_(True)
+        yr = TF.relu(TF.batch_norm(xr, rm, rv, None, None, True, 0.1, 1e-5) * (1 + gr[:, :Cc]) + gr[:, Cc:])
+        gg = dev(gbt).requires_grad_(True)
+        yg = F.spade_modulate(xg, gg, rmg, rvg, nbtg, relu=True)
+        extra = [("dgb", gg, gr)]
+    yr.backward(gy)
+    yg.backward(dev(gy))
+    close(yg, yr, 2e-5, "y")
+    close(xg.grad, xr.grad, 2e-4, "dx")
+    for n, a, r in extra:
+        close(a.grad, r.grad, 2e-4, n)
+    close(rmg, rm, 2e-5, "running_mean")
+    close(rvg, rv, 2e-5, "running_var")
+    assert int(nbtg) == 1
+
+
+def test_crop_matches_reference_fixture(golden_dir):
+    from agl import functional as F
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    feats, boxes = torch.from_numpy(g["crop_feats"]), torch.from_numpy(g["crop_boxes"])
+    for tag in ("sorted", "unsorted"):
+        o2i = torch.from_numpy(g[f"crop_{tag}_o2i"])
+        for HH, WW in ((8, 8), (5, 7), (32, 32)):
+            k = f"crop_{tag}_{HH}x{WW}"
+            fg = dev(feats).requires_grad_(True)
+            y = F.crop_boxes(fg, dev(boxes), dev(o2i), HH, WW)
+            y.backward(dev(torch.from_numpy(g[k + "_gy"])))
+            close(y, torch.from_numpy(g[k + "_y"]), 2e-5, k)
+            close(fg.grad, torch.from_numpy(g[k + "_dfeats"]), 1e-4, k + " dfeats")
+
+
+def test_pool_upsample_sum_reparam_maskouter():
+    from agl import functional as F
+    x = rn(3, 5, 8, 12)
+    for in_relu in (False, True):
+        xr, xg = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+        yr = TF.avg_pool2d(TF.relu(xr) if in_relu else xr, 2)
+        gy = rn(*yr.shape, seed=1)
+        yr.backward(gy)
+        yg = F.avg_pool2(xg, in_relu)
+        yg.backward(dev(gy))
+        close(yg, yr, 1e-6, "avgpool")
+        close(xg.grad, xr.grad, 1e-6, "avgpool dx")
+        xr, xg = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+        yr = (TF.relu(xr) if in_relu else xr).sum(dim=(2, 3)) * 0.5
+        gy = rn(*yr.shape, seed=2)
+        yr.backward(gy)
+        yg = F.sum_hw(xg, in_relu, 0.5)
+        yg.backward(dev(gy))
+        close(yg, yr, 1e-5, "sum_hw")
+        close(xg.grad, xr.grad, 1e-6, "sum_hw dx")
+    for k in (1, 3):
+        xr, xg = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+        yr = TF.interpolate(xr, scale_factor=2 ** k, mode="nearest")
+        gy = rn(*yr.shape, seed=3)
+        yr.backward(gy)
+        yg = F.upsample_nearest(xg, k)
+        yg.backward(dev(gy))
+        close(yg, yr, 0, "upsample")
+        close(xg.grad, xr.grad, 1e-5, "upsample dx")
+    mu, lv, eps = rn(6, 9), rn(6, 9, seed=1), rn(6, 9, seed=2)
+    mr, lr_ = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    zr = eps * torch.exp(0.5 * lr_) + mr
+    gz = rn(6, 9, seed=3)
+    zr.backward(gz)
+    mg, lg = dev(mu).requires_grad_(True), dev(lv).requires_grad_(True)
+    zg = F.reparameterize(mg, lg, dev(eps))
+    zg.backward(dev(gz))
+    close(zg, zr, 1e-6, "z"); close(mg.grad, mr.grad, 1e-6, "dmu"); close(lg.grad, lr_.grad, 1e-5, "dlogvar")
+    u, mask = rn(4, 6), (rn(4, 1, 10, 10, seed=1) > 0).float()
+    ur = u.clone().requires_grad_(True)
+    yr = TF.pad(ur[:, :, None, None] * mask, (1, 1, 1, 1))
+    gy = rn(*yr.shape, seed=2)
+    yr.backward(gy)
+    ug = dev(u).requires_grad_(True)
+    yg = F.mask_outer(ug, dev(mask), 1)
+    yg.backward(dev(gy))
+    close(yg, yr, 0, "mask_outer"); close(ug.grad, ur.grad, 1e-5, "mask_outer du")
+
+
+def test_spectral_norm_weights():
+    from agl import functional as F
+    import oracle.graph as OG
+    shapes = [(64, 3, 3, 3), (128, 64, 3, 3), (20, 7, 1, 1), (1, 1024), (179, 1024), (300, 200, 3, 3)]
+    P = {}
+    for i, s in enumerate(shapes):
+        P[f"l{i}.weight_orig"] = (rn(*s, seed=i) * 0.1).requires_grad_(True)
+        P[f"l{i}.weight_u"] = TF.normalize(rn(s[0], seed=10 + i), dim=0)
+        P[f"l{i}.weight_v"] = TF.normalize(rn(int(np.prod(s[1:])), seed=20 + i), dim=0)
+    ws = [dev(P[f"l{i}.weight_orig"].detach()).requires_grad_(True) for i in range(len(shapes))]
+    us = [dev(P[f"l{i}.weight_u"].clone()) for i in range(len(shapes))]
+    vs = [dev(P[f"l{i}.weight_v"].clone()) for i in range(len(shapes))]
+    for it in range(3):
+        outs_g = F.spectral_norm_weights(ws, us, vs, True)
+        outs_r = [OG.sn_weight(P, f"l{i}.", True) for i in range(len(shapes))]
+        for i in range(len(shapes)):
+            close(outs_g[i], outs_r[i], 2e-5, f"w_sn[{i}] iter {it}")
+            close(us[i], P[f"l{i}.weight_u"], 2e-5, f"u[{i}] iter {it}")
+            close(vs[i], P[f"l{i}.weight_v"], 2e-5, f"v[{i}] iter {it}")
+    gs = [rn(*s, seed=30 + i) for i, s in enumerate(shapes)]
+    sum((o * g).sum() for o, g in zip(outs_r, gs)).backward()
+    torch.autograd.backward(outs_g, [dev(g) for g in gs])
+    for i in range(len(shapes)):
+        close(ws[i].grad, P[f"l{i}.weight_orig"].grad, 1e-4, f"dw_orig[{i}]")
+    # eval mode: no power iteration, u/v untouched
+    u_before = us[0].clone()
+    outs_e = F.spectral_norm_weights(ws, us, vs, False)
+    close(outs_e[0], OG.sn_weight(P, "l0.", False), 2e-5, "eval w_sn")
+    assert torch.equal(u_before, us[0])
+
+
+def test_convlstm_matches_reference_fixture(golden_dir):
+    from agl.generator import LayoutConvLSTM
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    from oracle.fill import fill_state
+    m = LayoutConvLSTM(8, 12, [8, 4, 4], (5, 5))
+    m.load_state_dict(fill_state(m.state_dict()))
+    m = m.to(DEV)
+    x = dev(torch.from_numpy(g["clstm_x"])).requires_grad_(True)
+    y = m(x, torch.from_numpy(g["clstm_o2i"]))
+    y.backward(dev(torch.from_numpy(g["clstm_gy"])))
+    close(y, torch.from_numpy(g["clstm_y"]), 2e-5, "convlstm y")
+    close(x.grad, torch.from_numpy(g["clstm_dx"]), 2e-4, "convlstm dx")
+    close(m.cell_list[0].conv.weight.grad, torch.from_numpy(g["clstm_dW0"]), 2e-4, "convlstm dW0")
+    close(m.cell_list[2].conv.weight.grad, torch.from_numpy(g["clstm_dW2"]), 2e-4, "convlstm dW2")
+    close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
