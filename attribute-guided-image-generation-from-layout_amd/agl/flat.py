@@ -1,0 +1,52 @@
+"""Flat fp32 arenas for parameters, gradients and Adam moments.
+
+Each network's parameters become views into ONE contiguous buffer (same for the gradients), so the
+optimiser is a single fused kernel launch and the data-parallel gradient exchange is a single RCCL
+all-reduce on the arena itself — no per-tensor launches, no bucket copies (HBM is plentiful on
+MI355X; launches and small collectives are what cost).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+
+class FlatParams:
+    def __init__(self, modules: Iterable[nn.Module]):
+        self.modules = list(modules)
+        self.params: List[nn.Parameter] = [p for m in self.modules for p in m.parameters()]
+        assert self.params, "no parameters"
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        o = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.p[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.p[o:o + k].view(p.shape)
+                p.grad = self.g[o:o + k].view(p.shape)
+                o += k
+
+    def zero_grad(self):
+        self.g.zero_()
+        for p in self.params:           # re-attach in case autograd replaced a .grad tensor
+            if p.grad is None or p.grad.data_ptr() < self.g.data_ptr() or p.grad.data_ptr() >= self.g.data_ptr() + 4 * self.n:
+                raise RuntimeError("a parameter's .grad left the flat arena")
+
+    def set_requires_grad(self, flag: bool):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+    def adam_step(self, lr, beta1, beta2, eps, grad_scale=1.0):
+        self.step_count += 1
+        L.adam_step(self.p, self.g, self.m, self.v, lr, beta1, beta2, eps, self.step_count, grad_scale)

@@ -1,0 +1,206 @@
+"""One G+D training iteration on the HIP path — the harness counterpart of the reference's training
+loop body (train64.py:160-161 pre-step D_att forward, :191-262 D step, :280-370 G step; train128.py
+is the same with the 128 px modules).  See SURVEY.md §8(H).
+
+What is kept exactly: the order of network calls (so BatchNorm running statistics and spectral-norm
+u/v advance identically), the loss set and weights, Adam(2e-4, (.5,.999)) on all four networks.
+Legal savings taken: the D-step generator forward builds no autograd graph (all its outputs are
+detached in the reference, :195-240); D weight gradients are not computed in the G step (the
+reference zeroes them before use, :254-256); loss values/gradients come from fused kernels; the three
+D optimisers are one fused Adam launch over one flat arena (identical hyper-parameters and step count).
+Host data preparation (attribute estimate loop :162-166, attribute swap :170-188) is the batch
+builder's job (agl.synth); the batch carries attribute / attribute_gt / attribute_est.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import functional as F
+from . import losses as LS
+from .dp import GradSync
+from .flat import FlatParams
+
+LAMBDAS = dict(img_adv=1.0, obj_adv=1.0, obj_cls=1.0, z_rec=8.0, img_rec=1.0, kl=0.01, att_cls=2.0)   # train64.py:439-446
+LR, BETA1, BETA2, ADAM_EPS = 2e-4, 0.5, 0.999, 1e-8                                                   # train64.py:434,111-114
+MIX = (0.4, 0.4, 0.2)
+
+RAW = ["d_img_rec", "d_img_rand", "d_img_shift", "d_img_real", "d_obj_rec", "d_obj_rand", "d_obj_shift", "d_obj_real",
+       "d_obj_cls", "d_att", "g_img_rec", "g_z_rand", "g_z_shift", "g_kl", "g_img_adv_rec", "g_img_adv_rand",
+       "g_img_adv_shift", "g_obj_adv_rec", "g_obj_adv_rand", "g_obj_adv_shift", "g_obj_cls_rec", "g_obj_cls_rand",
+       "g_obj_cls_shift", "g_att_rec", "g_att_rand", "g_att_shift"]
+IDX = {k: i for i, k in enumerate(RAW)}
+
+BATCH_KEYS = ("imgs", "objs", "boxes", "masks", "z", "attribute", "masks_shift", "boxes_shift", "attribute_est",
+              "attribute_gt")
+
+
+def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
+    """numpy batch (agl.synth.make_batch) -> device tensors; obj_to_img stays on the CPU like the reference
+    (train64.py:149-151 does not move it)."""
+    out = {k: torch.from_numpy(batch_np[k]).to(device) for k in BATCH_KEYS}
+    out["obj_to_img"] = torch.from_numpy(batch_np["obj_to_img"])
+    return out
+
+
+class Trainer:
+    def __init__(self, netG, netD_image, netD_object, netD_att, pos_weight: torch.Tensor, *, lambdas: Optional[dict] = None,
+                 group=None):
+        self.netG, self.netDi, self.netDo, self.netDa = netG, netD_image, netD_object, netD_att
+        dev = next(netG.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Trainer needs the networks on a HIP device (no CPU fallback)")
+        self.dev = dev
+        self.lam = dict(LAMBDAS, **(lambdas or {}))
+        self.pos_weight = pos_weight.to(dev).float().contiguous()
+        self.flat_g = FlatParams([netG])
+        self.flat_d = FlatParams([netD_image, netD_object, netD_att])
+        self.sync = GradSync(group)
+        if self.sync.enabled:                       # identical replicas: rank 0's weights everywhere
+            self.sync.broadcast_(self.flat_g.p)
+            self.sync.broadcast_(self.flat_d.p)
+        self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
+        self._d_ready = None
+        self._g_ready = None
+        self.on_d_backward = None        # optional test probes, called after backward and before Adam
+        self.on_g_backward = None
+
+    # ------------------------------------------------------------------ helpers
+    def _slot(self, name):
+        i = IDX[name]
+        return self.raw[i:i + 1]
+
+    def _gen(self, b, eps):
+        return self.netG(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                         b["masks_shift"], b["boxes_shift"], b["attribute_est"], eps=eps)
+
+    def _reduce_and_step(self, flat: FlatParams):
+        """All-reduce the arena's gradients (side stream) and apply Adam there; returns the event the main
+        stream must wait on before it reads the updated weights."""
+        if not self.sync.enabled:
+            flat.adam_step(LR, BETA1, BETA2, ADAM_EPS, 1.0)
+            return None
+        main = torch.cuda.current_stream(self.dev)
+        side = self.sync.side_stream(self.dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.sync.all_reduce_(flat.g)
+            flat.adam_step(LR, BETA1, BETA2, ADAM_EPS, self.sync.grad_scale)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
+    @staticmethod
+    def _wait(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    # ------------------------------------------------------------------ the step
+    def step(self, b: Dict[str, torch.Tensor], eps_d: Optional[Sequence[torch.Tensor]] = None,
+             eps_g: Optional[Sequence[torch.Tensor]] = None):
+        lam = self.lam
+        objs = b["objs"]
+        N = b["imgs"].shape[0]
+        n_swap = math.floor(N / 3)                                        # train64.py:170
+        o2i_dev = b["obj_to_img"].to(self.dev)
+        s = self.netG.obj_size
+
+        # ---- pre-step attribute-estimate forward (train64.py:160-161); independent of G, so the previous
+        #      iteration's G all-reduce/Adam (side stream) overlaps it
+        with torch.no_grad():
+            crops_real = F.crop_boxes(b["imgs"], b["boxes"], o2i_dev, s)
+            self.netDa(crops_real)
+        self._wait(self._g_ready)
+        self._g_ready = None
+
+        # ---- D step (train64.py:191-262)
+        with torch.no_grad():
+            out = self._gen(b, eps_d)
+        crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift = out[:7]
+        self.flat_d.zero_grad()
+        heads, grads = [], []
+
+        def term(t, g):
+            heads.append(t)
+            grads.append(g)
+
+        for name, x, w in (("d_img_rec", img_rec, MIX[0]), ("d_img_rand", img_rand, MIX[1]), ("d_img_shift", img_shift, MIX[2])):
+            lg = self.netDi(x)
+            term(lg, LS.bce_const(lg, 0.0, lam["img_adv"] * w, self._slot(name)))
+        lg = self.netDi(b["imgs"])
+        term(lg, LS.bce_const(lg, 1.0, lam["img_adv"], self._slot("d_img_real")))
+        for name, x, w in (("d_obj_rec", crops_rec, MIX[0]), ("d_obj_rand", crops_rand, MIX[1]), ("d_obj_shift", crops_shift, MIX[2])):
+            src, _ = self.netDo(x, objs)
+            term(src, LS.bce_const(src, 0.0, lam["obj_adv"] * w, self._slot(name)))
+        src, cls = self.netDo(crops_input, objs)
+        term(src, LS.bce_const(src, 1.0, lam["obj_adv"], self._slot("d_obj_real")))
+        term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
+        att = self.netDa(crops_input)
+        term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
+        torch.autograd.backward(heads, grads)
+        if self.on_d_backward is not None:
+            self.on_d_backward(self)
+        self._d_ready = self._reduce_and_step(self.flat_d)
+
+        # ---- G step (train64.py:280-370)
+        self.flat_d.set_requires_grad(False)
+        try:
+            out = self._gen(b, eps_g)           # overlaps the D all-reduce + Adam (side stream)
+            (crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift,
+             mu, logvar, z_rand_rec, z_rand_shift) = out
+            self._wait(self._d_ready)
+            self._d_ready = None
+            self.flat_g.zero_grad()
+            heads, grads = [], []
+            keep = torch.ones(N, dtype=torch.float32, device=self.dev)
+            keep[:n_swap] = 0                                              # :284
+            term(img_rec, LS.l1_rows(img_rec, b["imgs"], keep, lam["img_rec"], float(N - n_swap), self._slot("g_img_rec")))
+            term(z_rand_rec, LS.l1_rows(z_rand_rec, b["z"], None, lam["z_rec"] * 0.5, 1.0, self._slot("g_z_rand")))
+            term(z_rand_shift, LS.l1_rows(z_rand_shift, b["z"], None, lam["z_rec"] * 0.5, 1.0, self._slot("g_z_shift")))
+            dmu, dlv = LS.kl_sum(mu, logvar, lam["kl"], self._slot("g_kl"))
+            term(mu, dmu)
+            term(logvar, dlv)
+            for tag, x, w in (("rec", img_rec, MIX[0]), ("rand", img_rand, MIX[1]), ("shift", img_shift, MIX[2])):
+                lg = self.netDi(x)
+                term(lg, LS.bce_const(lg, 1.0, lam["img_adv"] * w, self._slot("g_img_adv_" + tag)))
+            for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
+                src, cls = self.netDo(x, objs)
+                term(src, LS.bce_const(src, 1.0, lam["obj_adv"] * w, self._slot("g_obj_adv_" + tag)))
+                term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
+                att = self.netDa(x)
+                term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
+            torch.autograd.backward(heads, grads)
+            if self.on_g_backward is not None:
+                self.on_g_backward(self)
+        finally:
+            self.flat_d.set_requires_grad(True)
+        self._g_ready = self._reduce_and_step(self.flat_g)
+        self.last_outputs = out
+        return self.raw
+
+    def finish(self):
+        """Join the side stream (call before reading weights / at the end of a timed region)."""
+        self._wait(self._g_ready)
+        self._wait(self._d_ready)
+        self._g_ready = self._d_ready = None
+
+    def loss_dict(self) -> Dict[str, float]:
+        """The 15 scalars the reference logs (train64.py:266-272, :372-379); one device->host copy."""
+        r = {k: float(v) for k, v in zip(RAW, self.raw.detach().cpu().tolist())}
+        lam = self.lam
+        mix = lambda p: MIX[0] * r[p + "_rec"] + MIX[1] * r[p + "_rand"] + MIX[2] * r[p + "_shift"]
+        d_img_fake, d_obj_fake = mix("d_img"), mix("d_obj")
+        g_img_adv, g_obj_adv, g_obj_cls, g_att = mix("g_img_adv"), mix("g_obj_adv"), mix("g_obj_cls"), mix("g_att")
+        g_z = 0.5 * r["g_z_rand"] + 0.5 * r["g_z_shift"]
+        d_loss = (lam["img_adv"] * (d_img_fake + r["d_img_real"]) + lam["obj_adv"] * (d_obj_fake + r["d_obj_real"])
+                  + lam["obj_cls"] * r["d_obj_cls"] + lam["att_cls"] * r["d_att"])
+        g_loss = (lam["img_rec"] * r["g_img_rec"] + lam["z_rec"] * g_z + lam["img_adv"] * g_img_adv + lam["obj_adv"] * g_obj_adv
+                  + lam["obj_cls"] * g_obj_cls + lam["att_cls"] * g_att + lam["kl"] * r["g_kl"])
+        return {"D/loss": d_loss, "D/image_adv_loss_real": r["d_img_real"], "D/image_adv_loss_fake": d_img_fake,
+                "D/object_adv_loss_real": r["d_obj_real"], "D/object_adv_loss_fake": d_obj_fake,
+                "D/object_cls_loss_real": r["d_obj_cls"], "D/object_att_cls_loss": r["d_att"],
+                "G/loss": g_loss, "G/image_adv_loss": g_img_adv, "G/object_adv_loss": g_obj_adv,
+                "G/object_cls_loss": g_obj_cls, "G/rec_img": r["g_img_rec"], "G/rec_z": g_z, "G/kl": r["g_kl"],
+                "G/object_att_cls_loss": g_att}

@@ -278,12 +278,12 @@ __global__ void reparam_bwd_k(const float* __restrict__ dz, const float* __restr
 
 // torch.optim.Adam (no amsgrad / weight decay), single fused pass over a flat parameter arena
 __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                       float beta1, float beta2, float step_size, float bc2_sqrt, float eps, float grad_scale) {
+                       float omb1, float beta2, float omb2, float step_size, float bc2_sqrt, float eps, float grad_scale) {
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   const float gr = g[i] * grad_scale;
-  const float mi = m[i] + (1.f - beta1) * (gr - m[i]);          // exp_avg.lerp_(grad, 1-beta1)
-  const float vi = v[i] * beta2 + (1.f - beta2) * gr * gr;      // mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float mi = m[i] + omb1 * (gr - m[i]);                  // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v[i] * beta2 + omb2 * gr * gr;              // mul_(beta2).addcmul_(g, g, 1-beta2)
   m[i] = mi; v[i] = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;                 // (sqrt(v)/sqrt(bc2)).add_(eps)
   p[i] = p[i] - step_size * (mi / denom);                       // addcdiv_(m, denom, -step_size)
@@ -475,7 +475,8 @@ int agl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  LAUNCH1D(adam_k, n, p, g, m, v, n, beta1, beta2, step_size, bc2_sqrt, eps, grad_scale);
+  // 1-beta is formed in double like torch's python scalars (1.f - 0.999f is off by 1.3e-5 relative)
+  LAUNCH1D(adam_k, n, p, g, m, v, n, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps, grad_scale);
   AGL_CHECK_LAUNCH("agl_adam_step");
   return AGL_OK;
 }

@@ -15,8 +15,16 @@ import torch
 
 
 def _wave(n: int, k: int) -> np.ndarray:
-    i = np.arange(n, dtype=np.float64)
-    return np.sin(0.37 * i + 0.11 * k + 0.5 * np.sin(0.013 * i + k))
+    """n pseudo-random values in [-1, 1) from a splitmix64 integer hash of (tensor index k, element index):
+    closed-form and platform independent, but statistically like the reference's default uniform init, so
+    the filled networks are as well conditioned in fp32 as freshly initialised ones (a smooth sin() fill
+    made the generator's fp32 result itself uncertain to ~1e-2)."""
+    with np.errstate(over="ignore"):
+        x = np.arange(n, dtype=np.uint64) + np.uint64((k + 1) * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
 
 
 def fill_state(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -48,6 +56,6 @@ def fill_state(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             v = 1.0 + 0.1 * wv
         else:                                                     # conv / linear weight
             fan_in = n // shape[0]
-            v = math.sqrt(3.0 / fan_in) * wv
+            v = math.sqrt(1.0 / fan_in) * wv
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float64).reshape(shape)).to(t.dtype)
     return out

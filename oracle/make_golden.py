@@ -59,7 +59,7 @@ def T(x):
 
 
 def np32(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: CPU tensors share memory with live parameters/buffers
 
 
 def filled(module):
