@@ -60,7 +60,7 @@ SIGNATURES = {
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P]),
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
-    "agl_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "agl_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
 }
 
 
@@ -92,9 +92,23 @@ def load() -> C.CDLL:
     return lib
 
 
+# Optional per-launch timing (bench.py's roofline leg): when EVENT_LOG is a list, every call whose name starts
+# with one of EVENT_PREFIXES is bracketed by HIP events on the current stream (the stream it is launched on).
+EVENT_LOG = None
+EVENT_PREFIXES = ("agl_conv2d_",)
+
+
 def call(name: str, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    log = EVENT_LOG
+    if log is not None and name.startswith(EVENT_PREFIXES):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        log.append((name, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.agl_last_error().decode()}")
 

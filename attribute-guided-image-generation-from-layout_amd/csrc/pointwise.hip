@@ -468,15 +468,15 @@ int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, floa
 
 // One Adam step over a flat arena of n floats; `step` is the 1-based step count.  grad_scale multiplies the
 // gradient first (1/world_size after a sum all-reduce).
-int agl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+int agl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
                   int step, float grad_scale, void* stream) {
   AGL_REQUIRE(p && g && m && v && n > 0 && step >= 1, "agl_adam_step: bad argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   // 1-beta is formed in double like torch's python scalars (1.f - 0.999f is off by 1.3e-5 relative)
-  LAUNCH1D(adam_k, n, p, g, m, v, n, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps, grad_scale);
+  LAUNCH1D(adam_k, n, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps, grad_scale);
   AGL_CHECK_LAUNCH("agl_adam_step");
   return AGL_OK;
 }

@@ -134,7 +134,7 @@ int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* 
                void* stream);
 
 /* ---- optimiser (torch.optim.Adam, train64.py:111-114) over a flat fp32 arena ---------------------- */
-int agl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+int agl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
                   int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
