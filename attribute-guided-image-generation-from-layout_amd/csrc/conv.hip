@@ -32,6 +32,12 @@ template <int KS> struct KDiv {  // k -> (c, kh, kw) for a KSxKS window
   }
 };
 
+constexpr unsigned OOB = 0xFFFFFFF0u;   // byte offset past every buffer: the hardware range check returns 0.0f
+
+// Operand elements are fetched with raw buffer loads (SRD built from the tensor base and byte size): an
+// out-of-window tap / out-of-range row simply gets the offset OOB and the hardware returns zero — no
+// per-element select, no exec-mask branch, and nothing consumes the loaded value before it is staged to LDS.
+
 // ------------------------------------------------------------------ forward
 template <int KS>
 struct FwdProb {
@@ -42,23 +48,28 @@ struct FwdProb {
   int relu, accumulate, in_relu;
   int M, Nc, kbeg, kend;
   int HW, OHW, K;
+  unsigned a_bytes, b_bytes;
 
   __device__ bool setup(int) { return true; }
+  __device__ const float* a_ptr() const { return w; }
+  __device__ const float* b_ptr() const { return x; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return in_relu ? fmaxf(v, 0.f) : v; }
 
-  struct RowA { const float* p; bool ok; };
+  struct RowA { int base; bool ok; };
   struct KA { int k; bool ok; };
-  __device__ RowA row_a(int m) const { return {w + (long)m * K, m < M}; }
+  __device__ RowA row_a(int m) const { return {m * K, m < M}; }
   __device__ KA k_a(int k) const { return {k, k < kend}; }
-  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? r.p[k.k] : 0.f; }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(r.base + k.k) * 4u : OOB; }
 
-  struct RowB { const float* p; int ih0, iw0; bool ok; };
+  struct RowB { int base, ih0, iw0; bool ok; };
   struct KB { int coff, kh, kw; bool ok; };
   __device__ RowB row_b(int n) const {
     RowB r; r.ok = n < Nc;
     int nn = r.ok ? n : 0;
     int img = nn / OHW, pix = nn - img * OHW;
     int oh = pix / OW, ow = pix - oh * OW;
-    r.p = x + (long)img * Cin * HW; r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
+    r.base = img * Cin * HW; r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
     return r;
   }
   __device__ KB k_b(int k) const {
@@ -66,11 +77,10 @@ struct FwdProb {
     KDiv<KS>::split(s.ok ? k : 0, c, s.kh, s.kw); s.coff = c * HW;
     return s;
   }
-  __device__ float load_b(const RowB& r, const KB& k) const {
-    int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
-    bool ok = r.ok && k.ok && (unsigned)ih < (unsigned)(H << up) && (unsigned)iw < (unsigned)(W << up);
-    float v = ok ? r.p[k.coff + (ih >> up) * W + (iw >> up)] : 0.f;
-    return in_relu ? fmaxf(v, 0.f) : v;
+  __device__ unsigned off_b(const RowB& r, const KB& k) const {
+    const int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
+    const bool ok = r.ok & k.ok & ((unsigned)ih < (unsigned)(H << up)) & ((unsigned)iw < (unsigned)(W << up));
+    return ok ? (unsigned)(r.base + k.coff + (ih >> up) * W + (iw >> up)) * 4u : OOB;
   }
   struct Col { long off; bool ok; };
   __device__ Col col(int n) const {
@@ -100,6 +110,7 @@ struct BwdDataProb {
   int accumulate, relu;
   int M, Nc, kbeg, kend;
   int IHW, OHW, ph, pw, kh0, kw0, ohb, owb, IHp, IWp;
+  unsigned a_bytes, b_bytes;
 
   __device__ bool setup(int z) {
     ph = z / S; pw = z - ph * S;
@@ -109,25 +120,30 @@ struct BwdDataProb {
     Nc = N * IHp * IWp; M = Cin; kbeg = 0; kend = Cout * TS * TS;
     return Nc > 0;
   }
-  struct RowA { const float* p; bool ok; };
+  __device__ const float* a_ptr() const { return w; }
+  __device__ const float* b_ptr() const { return dy; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return v; }
+
+  struct RowA { int base; bool ok; };
   struct KA { int off; bool ok; };
-  __device__ RowA row_a(int m) const { return {w + (long)m * KS * KS, m < M}; }
+  __device__ RowA row_a(int m) const { return {m * KS * KS, m < M}; }
   __device__ KA k_a(int k) const {
     KA s; s.ok = k < kend; int co, th, tw;
     KDiv<TS>::split(s.ok ? k : 0, co, th, tw);
     s.off = co * Cin * KS * KS + (kh0 + S * th) * KS + (kw0 + S * tw);
     return s;
   }
-  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? r.p[k.off] : 0.f; }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(r.base + k.off) * 4u : OOB; }
 
-  struct RowB { const float* p; int oh0, ow0; bool ok; };
+  struct RowB { int base, oh0, ow0; bool ok; };
   struct KB { int coff, th, tw; bool ok; };
   __device__ RowB row_b(int n) const {
     RowB r; r.ok = n < Nc; int nn = r.ok ? n : 0;
     int per = IHp * IWp;
     int img = nn / per, q = nn - img * per;
     int a = q / IWp, b = q - a * IWp;
-    r.p = dy + (long)img * Cout * OHW; r.oh0 = a + ohb; r.ow0 = b + owb;
+    r.base = img * Cout * OHW; r.oh0 = a + ohb; r.ow0 = b + owb;
     return r;
   }
   __device__ KB k_b(int k) const {
@@ -135,10 +151,10 @@ struct BwdDataProb {
     KDiv<TS>::split(s.ok ? k : 0, co, s.th, s.tw); s.coff = co * OHW;
     return s;
   }
-  __device__ float load_b(const RowB& r, const KB& k) const {
-    int oh = r.oh0 - k.th, ow = r.ow0 - k.tw;
-    bool ok = r.ok && k.ok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
-    return ok ? r.p[k.coff + oh * OW + ow] : 0.f;
+  __device__ unsigned off_b(const RowB& r, const KB& k) const {
+    const int oh = r.oh0 - k.th, ow = r.ow0 - k.tw;
+    const bool ok = r.ok & k.ok & ((unsigned)oh < (unsigned)OH) & ((unsigned)ow < (unsigned)OW);
+    return ok ? (unsigned)(r.base + k.coff + oh * OW + ow) * 4u : OOB;
   }
   struct Col { long off; bool ok; };
   __device__ Col col(int n) const {
@@ -170,24 +186,30 @@ struct BwdWeightProb {
   int M, Nc, kbeg, kend;
   int HW, OHW, R, per_split;
   long slab;
+  unsigned a_bytes, b_bytes;
 
   __device__ bool setup(int z) {
     kbeg = z * per_split; kend = min(R, kbeg + per_split);
     out += (long)z * slab;
     return kbeg < kend;
   }
+  __device__ const float* a_ptr() const { return dy; }
+  __device__ const float* b_ptr() const { return x; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return in_relu ? fmaxf(v, 0.f) : v; }
+
   struct RowA { int off; bool ok; };
-  struct KA { const float* p; bool ok; };
+  struct KA { int base; bool ok; };
   __device__ RowA row_a(int m) const { return {m * OHW, m < M}; }
   __device__ KA k_a(int r) const {
     KA s; s.ok = r < kend; int rr = s.ok ? r : 0;
     int img = rr / OHW, pix = rr - img * OHW;
-    s.p = dy + (long)img * Cout * OHW + pix; return s;
+    s.base = img * Cout * OHW + pix; return s;
   }
-  __device__ float load_a(const RowA& r, const KA& k) const { return (r.ok && k.ok) ? k.p[r.off] : 0.f; }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(k.base + r.off) * 4u : OOB; }
 
   struct RowB { int coff, kh, kw; bool ok; };
-  struct KB { const float* p; int ih0, iw0; bool ok; };
+  struct KB { int base, ih0, iw0; bool ok; };
   __device__ RowB row_b(int n) const {
     RowB r; r.ok = n < Nc; int c;
     KDiv<KS>::split(r.ok ? n : 0, c, r.kh, r.kw); r.coff = c * HW; return r;
@@ -196,13 +218,12 @@ struct BwdWeightProb {
     KB s; s.ok = r < kend; int rr = s.ok ? r : 0;
     int img = rr / OHW, pix = rr - img * OHW;
     int oh = pix / OW, ow = pix - oh * OW;
-    s.p = x + (long)img * Cin * HW; s.ih0 = oh * stride - pad; s.iw0 = ow * stride - pad; return s;
+    s.base = img * Cin * HW; s.ih0 = oh * stride - pad; s.iw0 = ow * stride - pad; return s;
   }
-  __device__ float load_b(const RowB& r, const KB& k) const {
-    int ih = k.ih0 + r.kh, iw = k.iw0 + r.kw;
-    bool ok = r.ok && k.ok && (unsigned)ih < (unsigned)(H << up) && (unsigned)iw < (unsigned)(W << up);
-    float v = ok ? k.p[r.coff + (ih >> up) * W + (iw >> up)] : 0.f;
-    return in_relu ? fmaxf(v, 0.f) : v;
+  __device__ unsigned off_b(const RowB& r, const KB& k) const {
+    const int ih = k.ih0 + r.kh, iw = k.iw0 + r.kw;
+    const bool ok = r.ok & k.ok & ((unsigned)ih < (unsigned)(H << up)) & ((unsigned)iw < (unsigned)(W << up));
+    return ok ? (unsigned)(k.base + r.coff + (ih >> up) * W + (iw >> up)) * 4u : OOB;
   }
   struct Col { int n; bool ok; };
   __device__ Col col(int n) const { return {n, n < Nc}; }
@@ -252,40 +273,53 @@ __global__ __launch_bounds__(NT) void igemm_f32(P p) {
   }
 
   float va[A_PER], vb[B_PER];
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_ptr(), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.b_ptr(), 0, p.b_bytes, 0x00020000);
+  // Element j of the next K-slice.  The loads are issued one or two at a time BETWEEN the MFMA groups of the
+  // current slice (see the main loop) so their address arithmetic runs in the shadow of the matrix pipe.
+  typename P::KA ka_tile;      // k state of this thread for k-fast operands (one per slice)
+  typename P::KB kb_tile;
+  const int kga = (!P::A_KFAST && BM >= 64) ? __builtin_amdgcn_readfirstlane(tid / BM) : tid / BM;   // wave-uniform
+  const int kgb = (!P::B_KFAST && BN >= 64) ? __builtin_amdgcn_readfirstlane(tid / BN) : tid / BN;   //  -> scalar k decode
+  auto gload_begin = [&](int k0) {
+    if constexpr (P::A_KFAST) ka_tile = p.k_a(k0 + tid % BK);
+    if constexpr (P::B_KFAST) kb_tile = p.k_b(k0 + tid % BK);
+  };
+  auto gload_a = [&](int j, int k0) {
+    unsigned off;
+    if constexpr (P::A_KFAST) off = p.off_a(ra_[j], ka_tile);
+    else off = p.off_a(ra_[0], p.k_a(k0 + kga + (NT / BM) * j));
+    va[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, off, 0, 0));
+  };
+  auto gload_b = [&](int j, int k0) {
+    unsigned off;
+    if constexpr (P::B_KFAST) off = p.off_b(rb_[j], kb_tile);
+    else off = p.off_b(rb_[0], p.k_b(k0 + kgb + (NT / BN) * j));
+    vb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, off, 0, 0));
+  };
   auto gload = [&](int k0) {
-    if constexpr (P::A_KFAST) {
-      auto ks = p.k_a(k0 + tid % BK);
+    gload_begin(k0);
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) va[j] = p.load_a(ra_[j], ks);
-    } else {
+    for (int j = 0; j < A_PER; ++j) gload_a(j, k0);
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) va[j] = p.load_a(ra_[0], p.k_a(k0 + tid / BM + (NT / BM) * j));
-    }
-    if constexpr (P::B_KFAST) {
-      auto ks = p.k_b(k0 + tid % BK);
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) vb[j] = p.load_b(rb_[j], ks);
-    } else {
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) vb[j] = p.load_b(rb_[0], p.k_b(k0 + tid / BN + (NT / BN) * j));
-    }
+    for (int j = 0; j < B_PER; ++j) gload_b(j, k0);
   };
   auto sstore = [&](int buf) {
     float* a = As + buf * A_SZ;
     float* b = Bs + buf * B_SZ;
     if constexpr (P::A_KFAST) {
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) a[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = va[j];
+      for (int j = 0; j < A_PER; ++j) a[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = p.fix_a(va[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) a[(tid / BM + (NT / BM) * j) * BM + tid % BM] = va[j];
+      for (int j = 0; j < A_PER; ++j) a[(tid / BM + (NT / BM) * j) * BM + tid % BM] = p.fix_a(va[j]);
     }
     if constexpr (P::B_KFAST) {
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j) b[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = vb[j];
+      for (int j = 0; j < B_PER; ++j) b[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = p.fix_b(vb[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j) b[(tid / BN + (NT / BN) * j) * BN + tid % BN] = vb[j];
+      for (int j = 0; j < B_PER; ++j) b[(tid / BN + (NT / BN) * j) * BN + tid % BN] = p.fix_b(vb[j]);
     }
   };
 
@@ -305,12 +339,22 @@ __global__ __launch_bounds__(NT) void igemm_f32(P p) {
   __syncthreads();
   int cur = 0;
   for (int k0 = p.kbeg; k0 < p.kend; k0 += BK) {
-    const bool more = k0 + BK < p.kend;
-    if (more) gload(k0 + BK);
+    // The next slice is fetched unconditionally: past kend every offset is OOB and the loads return zeros, which
+    // keeps the loop body free of control flow (the scheduler can then spread the gathers between the MFMAs).
+    gload_begin(k0 + BK);
     const float* a = As + cur * A_SZ;
     const float* b = Bs + cur * B_SZ;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
+      {   // this K-step's share of the next slice's gathers
+        constexpr int STEPS = BK / 2;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j)
+          if (j * STEPS / A_PER == kk / 2) gload_a(j, k0 + BK);
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j)
+          if (j * STEPS / B_PER == kk / 2) gload_b(j, k0 + BK);
+      }
       float fa[WTM], fb[WTN];
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -324,7 +368,7 @@ __global__ __launch_bounds__(NT) void igemm_f32(P p) {
         for (int j = 0; j < WTN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) sstore(cur ^ 1);
+    sstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -381,7 +425,8 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   const int Hl = H << up_log2, Wl = W << up_log2;
   const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_fwd: empty extent");
-  AGL_REQUIRE((long)N * Cin * H * W < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_fwd: tensor too large for 32-bit offsets");
+  AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
+              "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
 #define AGL_FWD(KS_)                                                                                                  \
   case KS_: {                                                                                                         \
@@ -389,6 +434,7 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH;      \
     p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.relu = relu; p.accumulate = accumulate; p.in_relu = in_relu; \
     p.M = Cout; p.Nc = N * OH * OW; p.K = Cin * KS_ * KS_; p.kbeg = 0; p.kend = p.K; p.HW = H * W; p.OHW = OH * OW;  \
+    p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);          \
     return launch_igemm(p, p.M, p.Nc, 1, st, "agl_conv2d_fwd");                                                       \
   }
   switch (ks) { AGL_FWD(1) AGL_FWD(3) AGL_FWD(4) AGL_FWD(5) AGL_FWD(7) }
@@ -405,13 +451,15 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
   AGL_REQUIRE((IH + 2 * pad - ks) / stride + 1 == OH && (IW + 2 * pad - ks) / stride + 1 == OW,
               "agl_conv2d_bwd_data: inconsistent extents IH=%d IW=%d OH=%d OW=%d", IH, IW, OH, OW);
-  AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_bwd_data: tensor too large");
+  AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
+              "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
 #define AGL_BWD(KS_, S_)                                                                                            \
   {                                                                                                                 \
     BwdDataProb<KS_, S_> p;                                                                                         \
     p.dy = dy; p.w = w; p.dx = dx; p.bias = bias; p.pos_mask = pos_mask; p.N = N; p.Cin = Cin; p.IH = IH; p.IW = IW; p.Cout = Cout;       \
     p.OH = OH; p.OW = OW; p.pad = pad; p.accumulate = accumulate; p.relu = relu; p.IHW = IH * IW; p.OHW = OH * OW; \
+    p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cout * OH * OW * 4);      \
     long maxNc = (long)N * ((IH + S_ - 1) / S_) * ((IW + S_ - 1) / S_);                                             \
     return launch_igemm(p, Cin, maxNc, S_ * S_, st, "agl_conv2d_bwd_data");                                         \
   }
@@ -457,7 +505,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
-  AGL_REQUIRE((long)N * Cin * H * W < (1L << 31) && (long)N * Cout * OH * OW < (1L << 31), "agl_conv2d_bwd_weight: tensor too large");
+  AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
   const long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
   long per = 0;
   const int splits = bww_splits(Cout, Nc, R, &per);
@@ -479,6 +527,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     p.dy = dy; p.x = x; p.out = target; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH;        \
     p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.in_relu = in_relu; p.M = Cout; p.Nc = (int)Nc; p.HW = H * W;         \
     p.OHW = OH * OW; p.R = (int)R; p.per_split = (int)per; p.slab = (long)Cout * Nc; p.kbeg = 0; p.kend = 0;    \
+    p.a_bytes = (unsigned)((long)N * Cout * OH * OW * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);    \
     rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight");                                         \
   } break;
   switch (ks) { AGL_BWW(1) AGL_BWW(3) AGL_BWW(4) AGL_BWW(5) AGL_BWW(7) }
