@@ -22,8 +22,9 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "agl_version": (_I, []),
     "agl_last_error": (C.c_char_p, []),
-    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P] + [_I] * 12 + [_P]),
-    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
+    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
+    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
     "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
     "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
@@ -158,7 +159,10 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
         out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
     else:
         assert tuple(out.shape) == (N, Cout, OH, OW)
-    call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), N, Cin, H, W, Cout, ks, stride, pad, up,
+    need = load().agl_conv2d_splitk_ws_bytes(Cout, N * OH * OW, 1, Cin * ks * ks, out.numel())
+    ws = workspace(need, x.device) if need else None
+    call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
          int(in_relu), int(relu), int(accumulate), stream())
     return out
 
@@ -172,8 +176,12 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     if out is None:
         assert not accumulate
         out = torch.empty((N, Cin, IH, IW), dtype=torch.float32, device=dy.device)
-    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), N, Cin, IH, IW, Cout, OH, OW, ks,
-         stride, pad, 0, int(accumulate), stream())
+    tpa = ks // stride
+    need = load().agl_conv2d_splitk_ws_bytes(Cin, N * (-(-IH // stride)) * (-(-IW // stride)), stride * stride,
+                                             Cout * tpa * tpa, out.numel())
+    ws = workspace(need, dy.device) if need else None
+    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), stream())
     return out
 
 

@@ -49,8 +49,12 @@ struct FwdProb {
   int M, Nc, kbeg, kend;
   int HW, OHW, K;
   unsigned a_bytes, b_bytes;
+  int splits, per_split; long slab; float* part;   // split-K: raw partial sums go to part + z*slab
 
-  __device__ bool setup(int) { return true; }
+  __device__ bool setup(int z) {
+    if (splits > 1) { kbeg = z * per_split; kend = min(K, kbeg + per_split); part += (long)z * slab; }
+    return kbeg < kend;
+  }
   __device__ const float* a_ptr() const { return w; }
   __device__ const float* b_ptr() const { return x; }
   __device__ float fix_a(float v) const { return v; }
@@ -91,6 +95,7 @@ struct FwdProb {
   __device__ void store(int m, const Col& c, float v) const {
     if (m < M && c.ok) {
       long o = c.off + (long)m * OHW;
+      if (splits > 1) { part[o] = v; return; }
       if (bias) v += bias[m];
       if (accumulate) v += y[o];
       if (relu) v = fmaxf(v, 0.f);
@@ -111,14 +116,17 @@ struct BwdDataProb {
   int M, Nc, kbeg, kend;
   int IHW, OHW, ph, pw, kh0, kw0, ohb, owb, IHp, IWp;
   unsigned a_bytes, b_bytes;
+  int splits, per_split; long slab; float* part;
 
-  __device__ bool setup(int z) {
+  __device__ bool setup(int zz) {
+    const int z = zz / splits, sp = zz - z * splits;
     ph = z / S; pw = z - ph * S;
     IHp = (IH - ph + S - 1) / S; IWp = (IW - pw + S - 1) / S;
     kh0 = (ph + pad) % S; kw0 = (pw + pad) % S;
     ohb = (ph + pad - kh0) / S; owb = (pw + pad - kw0) / S;
     Nc = N * IHp * IWp; M = Cin; kbeg = 0; kend = Cout * TS * TS;
-    return Nc > 0;
+    if (splits > 1) { kbeg = sp * per_split; kend = min(kend, kbeg + per_split); part += (long)sp * slab; }
+    return Nc > 0 && kbeg < kend;
   }
   __device__ const float* a_ptr() const { return w; }
   __device__ const float* b_ptr() const { return dy; }
@@ -167,6 +175,7 @@ struct BwdDataProb {
   __device__ void store(int m, const Col& c, float v) const {
     if (m < M && c.ok) {
       long o = c.off + (long)m * IHW;
+      if (splits > 1) { part[o] = v; return; }
       if (bias) v += bias[m];
       if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
       if (accumulate) v += dx[o];
@@ -394,6 +403,40 @@ __global__ void slab_reduce(const float* __restrict__ slabs, float* __restrict__
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// out[o] = epilogue(sum_z part[z][o]); channel of o = (o / HW) % C
+__global__ void splitk_epilogue(const float* __restrict__ part, float* __restrict__ out, long n, int splits, int HW, int C,
+                                const float* __restrict__ bias, const float* __restrict__ pos_mask, int accumulate, int relu) {
+  long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += part[(long)z * n + o];
+  if (bias) v += bias[(o / HW) % C];
+  if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+  if (accumulate) v += out[o];
+  if (relu) v = fmaxf(v, 0.f);
+  out[o] = v;
+}
+
+// Reduction splits for the forward / input-gradient passes when the output grid alone cannot fill 256 CUs
+// (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails): K is cut so that ~2 workgroups per CU exist.
+static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
+  const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+  const int bn = M <= 32 ? 256 : 128;
+  const long tiles = (long)agl_cdiv(M, bm) * agl_cdiv(Nc, bn) * Z;
+  int s = 1;
+  if (tiles < 256 && K >= 512) {
+    s = (int)((512 + tiles - 1) / tiles);
+    if (s > K / 128) s = K / 128;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+  }
+  int per = (K + s - 1) / s;
+  per = (per + BK - 1) / BK * BK;
+  s = (K + per - 1) / per;
+  if (per_out) *per_out = per;
+  return s;
+}
+
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name) {
   AGL_REQUIRE(Nc > 0 && Nc < (1L << 31) && M > 0, "%s: bad GEMM extents M=%d Nc=%ld", name, M, Nc);
@@ -417,8 +460,16 @@ bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 
 extern "C" {
 
-int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout,
-                   int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate, void* stream) {
+// Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
+long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {
+  int per;
+  const int s = fwd_splits(M, out_pixels, phases, K, &per);
+  return s > 1 ? (long)s * out_numel * 4 : 0;
+}
+
+int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                   int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
+                   void* stream) {
   AGL_REQUIRE(x && w && y, "agl_conv2d_fwd: null pointer");
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2) && up_log2 >= 0 && up_log2 <= 4,
               "agl_conv2d_fwd: unsupported ks=%d stride=%d up=%d", ks, stride, up_log2);
@@ -428,6 +479,10 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
+  const long out_numel = (long)N * Cout * OH * OW;
+  int per = 0, rc = AGL_ERR_ARG;
+  int splits = fwd_splits(Cout, (long)N * OH * OW, 1, Cin * ks * ks, &per);
+  if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; per = Cin * ks * ks; }   // no scratch: unsplit
 #define AGL_FWD(KS_)                                                                                                  \
   case KS_: {                                                                                                         \
     FwdProb<KS_> p;                                                                                                   \
@@ -435,17 +490,25 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.relu = relu; p.accumulate = accumulate; p.in_relu = in_relu; \
     p.M = Cout; p.Nc = N * OH * OW; p.K = Cin * KS_ * KS_; p.kbeg = 0; p.kend = p.K; p.HW = H * W; p.OHW = OH * OW;  \
     p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);          \
-    return launch_igemm(p, p.M, p.Nc, 1, st, "agl_conv2d_fwd");                                                       \
-  }
+    p.splits = splits; p.per_split = per; p.slab = out_numel; p.part = (float*)ws;                                    \
+    rc = launch_igemm(p, p.M, p.Nc, splits, st, "agl_conv2d_fwd");                                                    \
+  } break;
   switch (ks) { AGL_FWD(1) AGL_FWD(3) AGL_FWD(4) AGL_FWD(5) AGL_FWD(7) }
 #undef AGL_FWD
-  return AGL_ERR_ARG;
+  if (rc != AGL_OK) return rc;
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, y, out_numel, splits,
+                       OH * OW, Cout, bias, (const float*)nullptr, accumulate, relu);
+    AGL_CHECK_LAUNCH("agl_conv2d_fwd(split-K epilogue)");
+  }
+  return AGL_OK;
 }
 
 // dx[N,Cin,IH,IW] = conv2d_backward_input(dy[N,Cout,OH,OW], w[Cout,Cin,ks,ks]).  Also the forward of
 // ConvTranspose2d (weight [C_in_T = Cout][C_out_T = Cin][ks][ks]).
-int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, int N, int Cin, int IH, int IW,
-                        int Cout, int OH, int OW, int ks, int stride, int pad, int relu, int accumulate, void* stream) {
+int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
+                        long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
+                        int relu, int accumulate, void* stream) {
   AGL_REQUIRE(dy && w && dx, "agl_conv2d_bwd_data: null pointer");
   AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && ks == 4)), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
@@ -454,6 +517,11 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
+  const long out_numel = (long)N * Cin * IH * IW;
+  const int phases = stride * stride, Kp = Cout * (ks / stride) * (ks / stride);
+  int per = 0, rc = AGL_ERR_ARG;
+  int splits = fwd_splits(Cin, (long)N * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride), phases, Kp, &per);
+  if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; per = Kp; }
 #define AGL_BWD(KS_, S_)                                                                                            \
   {                                                                                                                 \
     BwdDataProb<KS_, S_> p;                                                                                         \
@@ -461,18 +529,25 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     p.OH = OH; p.OW = OW; p.pad = pad; p.accumulate = accumulate; p.relu = relu; p.IHW = IH * IW; p.OHW = OH * OW; \
     p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cout * OH * OW * 4);      \
     long maxNc = (long)N * ((IH + S_ - 1) / S_) * ((IW + S_ - 1) / S_);                                             \
-    return launch_igemm(p, Cin, maxNc, S_ * S_, st, "agl_conv2d_bwd_data");                                         \
+    p.splits = splits; p.per_split = per; p.slab = out_numel; p.part = (float*)ws;                                  \
+    rc = launch_igemm(p, Cin, maxNc, S_ * S_ * splits, st, "agl_conv2d_bwd_data");                                  \
   }
   if (stride == 2) AGL_BWD(4, 2)
-  switch (ks) {
-    case 1: AGL_BWD(1, 1)
-    case 3: AGL_BWD(3, 1)
-    case 4: AGL_BWD(4, 1)
-    case 5: AGL_BWD(5, 1)
-    case 7: AGL_BWD(7, 1)
+  else switch (ks) {
+    case 1: AGL_BWD(1, 1) break;
+    case 3: AGL_BWD(3, 1) break;
+    case 4: AGL_BWD(4, 1) break;
+    case 5: AGL_BWD(5, 1) break;
+    case 7: AGL_BWD(7, 1) break;
   }
 #undef AGL_BWD
-  return AGL_ERR_ARG;
+  if (rc != AGL_OK) return rc;
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, dx, out_numel, splits,
+                       IH * IW, Cin, bias, pos_mask, accumulate, relu);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_data(split-K epilogue)");
+  }
+  return AGL_OK;
 }
 
 // Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every

@@ -30,15 +30,18 @@ const char* agl_last_error(void);
  *   up_log2  : x is nearest-upsampled by 2^up_log2 on the fly (F.interpolate(...,'nearest'),
  *              normalization.py:100 and generator_obj_att128.py:588) — H,W are the stored sizes.
  *   in_relu  : relu applied to x while gathering (discriminator.py:71 in-place ReLU).
- *   relu     : relu on the output;  accumulate: y += result (before relu).                        */
-int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout,
-                   int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate, void* stream);
+ *   relu     : relu on the output;  accumulate: y += result (before relu).
+ *   ws       : optional split-K scratch (agl_conv2d_splitk_ws_bytes); without it small grids run unsplit.      */
+long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
+int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                   int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
+                   void* stream);
 /* Gradient wrt the input of the conv above; ALSO the forward of nn.ConvTranspose2d(k=4,s=2,p=1)
  * (generator_obj_att.py:532,536,540) with w stored [C_in_T][C_out_T][4][4].  pos_mask (optional, shaped
  * like dx): dx is zeroed where pos_mask <= 0 (backward of a fused input ReLU).                      */
-int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, int N,
-                        int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int relu,
-                        int accumulate, void* stream);
+int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
+                        long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
+                        int relu, int accumulate, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
 int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H,
                           int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
