@@ -32,7 +32,7 @@ SIGNATURES = {
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
-    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
@@ -47,7 +47,8 @@ SIGNATURES = {
     "agl_upsample_nearest_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_sum_hw_fwd": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "agl_sum_hw_bwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P]),
-    "agl_channel_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "agl_channel_sum_ws_bytes": (_L, [_I]),
+    "agl_channel_sum": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "agl_reparam_fwd": (_I, [_P, _P, _P, _P, _L, _P]),
     "agl_reparam_bwd": (_I, [_P, _P, _P, _P, _L, _P]),
     "agl_mask_outer_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -206,7 +207,8 @@ def channel_sum(x, out=None, accumulate=False):
     HW = x.numel() // (N * Cc)
     if out is None:
         out = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    call("agl_channel_sum", ptr(x), ptr(out), N, Cc, HW, int(accumulate), stream())
+    ws = workspace(load().agl_channel_sum_ws_bytes(Cc), x.device)
+    call("agl_channel_sum", ptr(x), ptr(out), N, Cc, HW, int(accumulate), ws.data_ptr(), ws.numel(), stream())
     return out
 
 
@@ -246,7 +248,7 @@ def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=
     ws = workspace(nb, x.device)
     call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
          ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
-         ws.data_ptr(), ws.numel(), stream())
+         p0.shape[0] if mode == 2 else 0, ws.data_ptr(), ws.numel(), stream())
     return dx
 
 

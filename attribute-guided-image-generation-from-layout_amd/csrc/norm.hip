@@ -146,28 +146,52 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
   }
 }
 
-// K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; parameter grads (deterministic, serial over n).
-__global__ void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
-                                  float* __restrict__ dp0, float* __restrict__ dp1) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// K2b (mode 2): gradient of the class table: thread (v, c) scans the objects in increasing n and adds the rows whose
+// label is v — every cell has one owner and a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void norm_bwd_table(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ dtable) {
+  __shared__ int lab[1024];
+  const int v = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f, b = 0.f;
+  for (int n0 = 0; n0 < a.N; n0 += 1024) {
+    const int cnt = min(1024, a.N - n0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) lab[i] = (int)a.labels[n0 + i];
+    __syncthreads();
+    if (c < a.C)
+      for (int i = 0; i < cnt; ++i)
+        if (lab[i] == v) {
+          g += rowsum[2 * ((long)(n0 + i) * a.C + c) + 1];
+          b += rowsum[2 * ((long)(n0 + i) * a.C + c)];
+        }
+  }
+  if (c < a.C) {
+    dtable[(long)v * 2 * a.C + c] += g;
+    dtable[(long)v * 2 * a.C + a.C + c] += b;
+  }
+}
+
+// K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; affine parameter grads (mode 1).  One wave per channel.
+__global__ __launch_bounds__(256) void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
+                                                         float* __restrict__ dp0, float* __restrict__ dp1) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= a.C) return;
   double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
-  for (int n = 0; n < a.N; ++n) {
-    float a1 = rowsum[2 * ((long)n * a.C + c)], a2 = rowsum[2 * ((long)n * a.C + c) + 1];
+  for (int n = lane; n < a.N; n += 64) {
+    const float a1 = rowsum[2 * ((long)n * a.C + c)], a2 = rowsum[2 * ((long)n * a.C + c) + 1];
     float g = 1.f;
-    if (a.mode == 2) {
-      const long t = (long)a.labels[n] * 2 * a.C;
-      g = a.p0[t + c];
-      if (dp0) { dp0[t + c] += a2; dp0[t + a.C + c] += a1; }
-    }
+    if (a.mode == 2) g = a.p0[(long)a.labels[n] * 2 * a.C + c];
     S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
   }
-  if (a.mode == 1) {
-    if (dp0) { dp0[c] = (float)A2; dp1[c] = (float)A1; }
-    S1 *= a.p0[c]; S2 *= a.p0[c];
+  S1 = wave_sum(S1); S2 = wave_sum(S2); A1 = wave_sum(A1); A2 = wave_sum(A2);
+  if (lane == 0) {
+    if (a.mode == 1) {
+      if (dp0) { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+      S1 *= a.p0[c]; S2 *= a.p0[c];
+    }
+    chansum[2 * c] = (float)S1;
+    chansum[2 * c + 1] = (float)S2;
   }
-  chansum[2 * c] = (float)S1;
-  chansum[2 * c + 1] = (float)S2;
 }
 
 // K3: dx = rstd * (ge*g - S1/M - xhat*S2/M)
@@ -280,7 +304,7 @@ long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2
 //          mode 3 -> dp0 = dgb[N][2C][HW] (overwritten).  Either may be NULL to skip parameter gradients (not mode 3).
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, void* ws, long ws_bytes, void* stream) {
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, void* ws, long ws_bytes, void* stream) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
   if (rc) return rc;
@@ -295,9 +319,14 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
   hipStream_t st = (hipStream_t)stream;
   AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
   AGL_CHECK_LAUNCH("agl_norm_bwd(rows)");
-  hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 64)), dim3(64), 0, st, a, (const float*)rowsum, chansum,
+  hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 4)), dim3(256), 0, st, a, (const float*)rowsum, chansum,
                      mode == 3 ? nullptr : dp0, dp1);
   AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
+  if (mode == 2 && dp0) {
+    AGL_REQUIRE(n_classes > 0, "agl_norm_bwd: mode 2 needs the number of table rows");
+    hipLaunchKernelGGL(norm_bwd_table, dim3(agl_cdiv(C, 256), n_classes), dim3(256), 0, st, a, (const float*)rowsum, dp0);
+    AGL_CHECK_LAUNCH("agl_norm_bwd(table)");
+  }
   const float inv_m = 1.0f / (float)((long)N * HW);
   AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)chansum, inv_m, batch_stats, dx);
   AGL_CHECK_LAUNCH("agl_norm_bwd(apply)");

@@ -252,18 +252,27 @@ __global__ void sum_hw_bwd_k(const float* __restrict__ dy, const float* __restri
   dx[i] = v;
 }
 
-// out[c] = sum_{n,hw} x[n,c,hw]   (bias gradients); one block per channel, fixed order -> deterministic
-__global__ __launch_bounds__(256) void channel_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, int accumulate) {
+// out[c] = sum_{n,hw} x[n,c,hw]   (bias gradients): (C x S) partial blocks, then a fixed-order finish -> deterministic
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, double* __restrict__ part, int N, int C, int HW, int S) {
   __shared__ double sc[4];
-  const int c = blockIdx.x;
-  double s = 0.0;
+  const int c = blockIdx.x, sl = blockIdx.y;
   const long total = (long)N * HW;
-  for (long e = threadIdx.x; e < total; e += 256) {
+  const long chunk = (total + S - 1) / S;
+  const long e0 = sl * chunk, e1 = min(total, e0 + chunk);
+  double s = 0.0;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
     const long n = e / HW, hw = e - n * HW;
     s += x[(n * C + c) * HW + hw];
   }
   s = block_sum_256(s, sc);
-  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (threadIdx.x == 0) part[(long)c * S + sl] = s;
+}
+__global__ void channel_sum_final(const double* __restrict__ part, float* __restrict__ out, int C, int S, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < S; ++i) s += part[(long)c * S + i];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // z = eps*exp(0.5*logvar) + mu  (models/generator_obj_att.py:418-420)
@@ -445,10 +454,22 @@ int agl_sum_hw_bwd(const float* dy, const float* x, float* dx, long NC, int HW, 
   return AGL_OK;
 }
 
-int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+long agl_channel_sum_ws_bytes(int C) { return (long)C * 64 * sizeof(double); }
+
+int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* ws, long ws_bytes, void* stream) {
   AGL_REQUIRE(x && out && N > 0 && C > 0 && HW > 0, "agl_channel_sum: bad argument");
-  hipLaunchKernelGGL(channel_sum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW, accumulate);
-  AGL_CHECK_LAUNCH("agl_channel_sum");
+  const long total = (long)N * HW;
+  int S = (int)((total + 4095) / 4096);
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  if (!ws || ws_bytes < (long)C * S * (long)sizeof(double)) {
+    agl_set_error("agl_channel_sum: workspace too small");
+    return AGL_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(channel_sum_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, (double*)ws, N, C, HW, S);
+  AGL_CHECK_LAUNCH("agl_channel_sum(partial)");
+  hipLaunchKernelGGL(channel_sum_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, (const double*)ws, out, C, S, accumulate);
+  AGL_CHECK_LAUNCH("agl_channel_sum(final)");
   return AGL_OK;
 }
 

@@ -65,7 +65,7 @@ int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int
 long agl_norm_bwd_ws_bytes(int N, int C);
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, void* ws, long ws_bytes, void* stream);
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, void* ws, long ws_bytes, void* stream);
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;
@@ -97,7 +97,8 @@ int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, 
 /* torch.sum(h, dim=(2,3)) (discriminator.py:226; generator_obj_att.py:444) and AdaptiveAvgPool2d(1) (:389) */
 int agl_sum_hw_fwd(const float* x, float* y, long NC, int HW, int in_relu, float scale, void* stream);
 int agl_sum_hw_bwd(const float* dy, const float* x, float* dx, long NC, int HW, int in_relu, float scale, void* stream);
-int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream);
+long agl_channel_sum_ws_bytes(int C);
+int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* ws, long ws_bytes, void* stream);
 /* z = eps*exp(.5*logvar)+mu (generator_obj_att.py:418-420) */
 int agl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream);
 int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream);
