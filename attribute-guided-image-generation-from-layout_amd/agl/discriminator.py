@@ -45,11 +45,14 @@ class OptimizedBlock(nn.Module):
 
     def forward(self, x, W=None):
         h = self.resi[0](x, relu=True, weight=_w(W, self.resi[0]))
-        h = self.resi[2](h, weight=_w(W, self.resi[2]))
+        c2 = self.resi[2]
+        w2 = _w(W, c2)
         s = x
-        if self.downsample:
-            h = F.avg_pool2(h)
+        if self.downsample:            # conv3x3 + avg-pool == one 4x4 stride-2 conv (2.25x fewer MACs)
+            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias)
             s = F.avg_pool2(x)
+        else:
+            h = c2(h, weight=w2)
         return self.sc(s, addend=h, weight=_w(W, self.sc))
 
 
@@ -69,10 +72,12 @@ class ResidualBlock(nn.Module):
         if not self.learnable_sc:
             raise NotImplementedError("identity-shortcut blocks are not on the reference path")
         h = self.resi[1](x, in_relu=True, relu=True, weight=_w(W, self.resi[1]))
-        h = self.resi[3](h, weight=_w(W, self.resi[3]))
+        c2 = self.resi[3]
+        w2 = _w(W, c2)
         if self.downsample:
-            h = F.avg_pool2(h)
+            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias)
             return self.sc(F.avg_pool2(x, in_relu=True), addend=h, weight=_w(W, self.sc))
+        h = c2(h, weight=w2)
         return self.sc(x, in_relu=True, addend=h, weight=_w(W, self.sc))
 
 

@@ -269,6 +269,30 @@ def mask_outer(u, mask, pad=1):
     return _MaskOuter.apply(u, mask, pad)
 
 
+class _PoolFuseWeight(torch.autograd.Function):
+    """(Cout,Cin,3,3) -> (Cout,Cin,4,4): the 4x4/stride-2 filter equal to conv3x3(pad 1) followed by avg_pool2d(2)."""
+
+    @staticmethod
+    def forward(ctx, w3):
+        w3 = _c(w3)
+        assert w3.shape[2:] == (3, 3)
+        w4 = torch.empty(w3.shape[:2] + (4, 4), dtype=torch.float32, device=w3.device)
+        L.call("agl_pool_fuse_weight_fwd", L.ptr(w3), L.ptr(w4), w3.shape[0] * w3.shape[1], L.stream())
+        return w4
+
+    @staticmethod
+    def backward(ctx, dw4):
+        dw4 = _c(dw4)
+        dw3 = torch.empty(dw4.shape[:2] + (3, 3), dtype=torch.float32, device=dw4.device)
+        L.call("agl_pool_fuse_weight_bwd", L.ptr(dw4), L.ptr(dw3), dw4.shape[0] * dw4.shape[1], L.stream())
+        return dw3
+
+
+def conv3x3_avgpool2(x, w3, bias=None, in_relu=False):
+    """avg_pool2d(conv2d(x, w3, bias, padding=1), 2) as one 4x4 stride-2 convolution (exact in real arithmetic)."""
+    return conv2d(x, _PoolFuseWeight.apply(w3), bias, 2, 1, 0, in_relu, False, None)
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

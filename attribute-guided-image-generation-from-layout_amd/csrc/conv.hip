@@ -243,7 +243,7 @@ struct BwdWeightProb {
 
 // ------------------------------------------------------------------ the kernel
 template <class P, int BM, int BN>
-__global__ __launch_bounds__(NT) void igemm_f32(P p) {
+__global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
   constexpr int WAVES_M = (BM >= 128) ? 2 : 1;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WTM = BM / (32 * WAVES_M);

@@ -108,6 +108,11 @@ int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, floa
 int agl_mask_outer_fwd(const float* u, const float* mask, float* y, int O, int C, int R, int pad, void* stream);
 int agl_mask_outer_bwd(const float* dy, const float* mask, float* du, int O, int C, int R, int pad, void* stream);
 
+/* conv3x3(p1) + avg_pool2d(2) == conv4x4(s2,p1): weight transform (n_filters = Cout*Cin) and its adjoint
+ * (models/discriminator.py:46-51, :81-86 residual branches that end in _downsample). */
+int agl_pool_fuse_weight_fwd(const float* w3, float* w4, long n_filters, void* stream);
+int agl_pool_fuse_weight_bwd(const float* dw4, float* dw3, long n_filters, void* stream);
+
 /* ---- spectral norm (torch.nn.utils.spectral_norm via add_sn, discriminator.py:15-22), batched per net */
 struct AglSnLayer {
   const float* w; float* u; float* v; float* w_sn; float* sigma; float* tmp; float* u_used; float* v_used;
