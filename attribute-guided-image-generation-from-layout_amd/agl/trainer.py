@@ -58,9 +58,12 @@ class Trainer:
         self.flat_g = FlatParams([netG])
         self.flat_d = FlatParams([netD_image, netD_object, netD_att])
         self.sync = GradSync(group)
-        if self.sync.enabled:                       # identical replicas: rank 0's weights everywhere
-            self.sync.broadcast_(self.flat_g.p)
+        if self.sync.enabled:                       # identical replicas: rank 0's weights and buffers everywhere
+            self.sync.broadcast_(self.flat_g.p)     # (spectral-norm u/v are randomly initialised buffers)
             self.sync.broadcast_(self.flat_d.p)
+            for net in (netG, netD_image, netD_object, netD_att):
+                for buf in net.buffers():
+                    self.sync.broadcast_(buf)
         self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
         self._d_ready = None
         self._g_ready = None

@@ -80,19 +80,23 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 64 at 64px, 32 at 128px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # one GPU per rank on a real node
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
     from agl import lib as L, synth
     from agl.trainer import Trainer, batch_to_device
@@ -102,7 +106,7 @@ def main():
     nets, obj_size = build_nets(a.res, dev)
     pw = torch.from_numpy(synth.make_pos_weight())
     tr = Trainer(*nets, pw)
-    bn = synth.make_batch(per_gpu, a.res, seed=1234 + rank)
+    bn = synth.make_batch(per_gpu, a.res, seed=a.seed + rank)
     b = batch_to_device(bn, dev)
     O = int(bn["objs"].shape[0])
     gen = torch.Generator().manual_seed(100 + rank)
@@ -135,14 +139,16 @@ def main():
     assert all(np.isfinite(v) for v in losses.values()), losses
 
     roof = None
-    if not a.no_roofline and rank == 0:
-        # one extra, instrumented step: HIP events around every convolution launch (igemm_f32 family, >99.9 % of the
-        # algorithmic FLOPs) on the stream they are launched on
-        L.EVENT_LOG = []
+    if not a.no_roofline:
+        # one extra, instrumented step (outside the timed region; EVERY rank runs it, the gradient all-reduce is
+        # collective): HIP events around every convolution launch (igemm_f32 family, >99.9 % of the algorithmic
+        # FLOPs) on the stream they are launched on; rank 0 reports.
+        L.EVENT_LOG = [] if rank == 0 else None
         one_step()
         tr.finish()
-        torch.cuda.synchronize()
+        fence()
         log, L.EVENT_LOG = L.EVENT_LOG, None
+    if not a.no_roofline and rank == 0:
         conv_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in log)
         c0, c1 = FLOPS_PER_IMAGE[a.res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic, per GPU per step
