@@ -57,6 +57,22 @@ class SequencePlan:
         self.hprev_rows = up(hprev)
 
 
+def _split_w(W, cx):
+    """W (4h, cx+h, 5, 5) -> contiguous W[:, :cx], W[:, cx:] (input / recurrent halves)."""
+    n, c = W.shape[0], W.shape[1]
+    a = torch.empty((n, cx, 5, 5), dtype=torch.float32, device=W.device)
+    b = torch.empty((n, c - cx, 5, 5), dtype=torch.float32, device=W.device)
+    L.call("agl_concat2_bwd", L.ptr(W.contiguous()), L.ptr(a), L.ptr(b), n, cx, c - cx, 25, 0, L.stream())
+    return a, b
+
+
+def _join_w(dWx, dWh):
+    n, ca, cb = dWx.shape[0], dWx.shape[1], dWh.shape[1]
+    out = torch.empty((n, ca + cb, 5, 5), dtype=torch.float32, device=dWx.device)
+    L.call("agl_concat2_fwd", L.ptr(dWx), L.ptr(dWh), L.ptr(out), n, ca, cb, 25, 0, L.stream())
+    return out
+
+
 class _LayoutConvLSTM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan: SequencePlan, hidden: Sequence[int], *params):
@@ -70,8 +86,7 @@ class _LayoutConvLSTM(torch.autograd.Function):
         for li, hid in enumerate(hidden):
             W, b = params[2 * li], params[2 * li + 1]
             cx = X.shape[1]
-            Wx = W[:, :cx].contiguous()
-            Wh = W[:, cx:].contiguous()
+            Wx, Wh = _split_w(W, cx)
             ccx = L.conv2d_fwd(X, Wx, b, 1, 2)                                    # (O, 4h, 8, 8)
             H = torch.empty((O, hid, SH, SW), dtype=torch.float32, device=dev)    # time-major
             Cs = torch.empty_like(H)
@@ -136,7 +151,7 @@ class _LayoutConvLSTM(torch.autograd.Function):
             else:
                 dCCx = dCC
             dWx = L.conv2d_bwd_weight(dCCx, X, 5, 1, 2)
-            grads[2 * li] = torch.cat([dWx, dWh], dim=1)
+            grads[2 * li] = _join_w(dWx, dWh)
             grads[2 * li + 1] = L.channel_sum(dCCx)
             if li > 0 or ctx.needs_input_grad[0]:
                 dX = L.conv2d_bwd_data(dCCx, Wx, (SH, SW), 1, 2)

@@ -293,6 +293,69 @@ def conv3x3_avgpool2(x, w3, bias=None, in_relu=False):
     return conv2d(x, _PoolFuseWeight.apply(w3), bias, 2, 1, 0, in_relu, False, None)
 
 
+class _Concat2(torch.autograd.Function):
+    """cat((a, b), dim=1) for (N,Ca,*spatial) and (N,Cb,*spatial) — or b of shape (N,Cb) broadcast over the spatial dims."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        N, Ca, Cb = a.shape[0], a.shape[1], b.shape[1]
+        HW = a.numel() // (N * Ca)
+        bcast = int(b.dim() == 2 and a.dim() > 2)
+        assert bcast or b.numel() == N * Cb * HW
+        out = torch.empty((N, Ca + Cb) + tuple(a.shape[2:]), dtype=torch.float32, device=a.device)
+        L.call("agl_concat2_fwd", L.ptr(a), L.ptr(b), L.ptr(out), N, Ca, Cb, HW, bcast, L.stream())
+        ctx.cfg = (tuple(a.shape), tuple(b.shape), HW, bcast)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        sa, sb, HW, bcast = ctx.cfg
+        d = _c(d)
+        da = torch.empty(sa, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(sb, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            L.call("agl_concat2_bwd", L.ptr(d), L.ptr(da), L.ptr(db), sa[0], sa[1], sb[1], HW, bcast, L.stream())
+        return da, db
+
+
+def concat_channels(a, b):
+    return _Concat2.apply(a, b)
+
+
+def concat_rows(a, b):
+    """cat((a, b), dim=0) of two contiguous tensors with equal trailing shape (a flat copy)."""
+    y = _Concat2.apply(a.reshape(1, -1), b.reshape(1, -1))
+    return y.reshape((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]))
+
+
+class _Split2(torch.autograd.Function):
+    """x (N, Ca+Cb, *rest) -> contiguous copies x[:, :Ca], x[:, Ca:] (the adjoint of concat_channels)."""
+
+    @staticmethod
+    def forward(ctx, x, Ca):
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * Cc)
+        a = torch.empty((N, Ca) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        b = torch.empty((N, Cc - Ca) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        L.call("agl_concat2_bwd", L.ptr(x), L.ptr(a), L.ptr(b), N, Ca, Cc - Ca, HW, 0, L.stream())
+        ctx.cfg = (Ca, Cc - Ca, HW)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        Ca, Cb, HW = ctx.cfg
+        da, db = _c(da), _c(db)
+        out = torch.empty((da.shape[0], Ca + Cb) + tuple(da.shape[2:]), dtype=torch.float32, device=da.device)
+        L.call("agl_concat2_fwd", L.ptr(da), L.ptr(db), L.ptr(out), da.shape[0], Ca, Cb, HW, 0, L.stream())
+        return out, None
+
+
+def split_channels(x, Ca):
+    return _Split2.apply(x, Ca)
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -321,9 +384,9 @@ class _GatherRows(torch.autograd.Function):
     def backward(ctx, dout):
         (rows,) = ctx.saved_tensors
         dout = _c(dout)
-        # dtable[rows[r]] += dout[r]: reuse the conditional-norm channel kernel shape via index_add on device memory
+        D = dout.numel() // dout.shape[0]
         dt = torch.zeros((ctx.n,) + tuple(dout.shape[1:]), dtype=dout.dtype, device=dout.device)
-        dt.index_add_(0, rows, dout)
+        L.call("agl_embedding_bwd", L.ptr(dout), L.ptr(rows, torch.int64), L.ptr(dt), dout.shape[0], D, ctx.n, L.stream())
         return dt, None
 
 

@@ -170,7 +170,7 @@ class LayoutEncoder(nn.Module):
         self.pool_to_8 = pool_to_8
 
     def forward(self, objs_att, masks, obj_to_img, z, objs, plan: Optional[SequencePlan] = None):
-        v = torch.cat((objs_att, z), dim=1)
+        v = F.concat_channels(objs_att, z)
         assert self.c0.kernel_size == (1, 1) and self.c0.padding == (1, 1)
         u = F.linear(v, self.c0.weight.view(self.c0.out_channels, -1))   # c0 on the rank-1 tensor v (x) mask
         h = self.bn1(F.mask_outer(u, masks, 1), objs, relu=True)
@@ -202,8 +202,8 @@ class SPADE(nn.Module):
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
         actv = self.mlp_shared[0](segmap, relu=True, up=up)
-        w = torch.cat((self.mlp_gamma.weight, self.mlp_beta.weight), dim=0)
-        b = torch.cat((self.mlp_gamma.bias, self.mlp_beta.bias), dim=0)
+        w = F.concat_rows(self.mlp_gamma.weight, self.mlp_beta.weight)
+        b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
         gb = F.conv2d(actv, w, b, 1, 1)
         n = self.param_free_norm
         return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training)
@@ -235,8 +235,7 @@ class Decoder(nn.Module):
 
     def forward(self, hidden, global_h, z=None):
         seg = hidden
-        g = global_h.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 8, 8)
-        h = self.c0_new(torch.cat((hidden, g), dim=1))
+        h = self.c0_new(F.concat_channels(hidden, global_h))      # global vector broadcast over the 8x8 map
         h = self.spade_0(h, seg, relu=True)
         h = self.spade_1(self.dc1(h), seg, relu=True)
         h = self.spade_2(self.dc2(h), seg, relu=True)
@@ -263,7 +262,7 @@ class AttributeEncoder(nn.Module):
         self.c2 = A.Linear(64, 64)
 
     def forward(self, objs, attribute):
-        a = torch.cat((self.embedding(objs), attribute), dim=1)
+        a = F.concat_channels(self.embedding(objs), attribute)
         a = self.bn0(self.c0(a), relu=True)
         a = self.bn1(self.c1(a), relu=True)
         return self.c2(a)

@@ -51,6 +51,9 @@ SIGNATURES = {
     "agl_channel_sum": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "agl_reparam_fwd": (_I, [_P, _P, _P, _P, _L, _P]),
     "agl_reparam_bwd": (_I, [_P, _P, _P, _P, _L, _P]),
+    "agl_concat2_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_concat2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_embedding_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "agl_mask_outer_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "agl_mask_outer_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "agl_pool_fuse_weight_fwd": (_I, [_P, _P, _L, _P]),

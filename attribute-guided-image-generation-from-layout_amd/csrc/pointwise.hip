@@ -365,6 +365,61 @@ __global__ void pool_fuse_w_bwd_k(const float* __restrict__ dw4, float* __restri
   dw3[i] = 0.25f * s;
 }
 
+// out[n] = [a[n] ; b[n]] along the channel axis for rows of HW floats; b may be (N,Cb) broadcast over HW (bcast=1).
+// Covers torch.cat((hidden, global.expand), 1) (generator_obj_att.py:549-552), cat((emb, attr), 1) (:589-590),
+// cat((objs_att, z), 1) (:489) and contiguous weight concatenation.
+__global__ void concat2_fwd_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long N, int Ca,
+                              int Cb, int HW, int bcast) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  const long per = (long)(Ca + Cb) * HW;
+  if (i >= N * per) return;
+  const long n = i / per, r = i - n * per;
+  const int c = (int)(r / HW), hw = (int)(r - (long)c * HW);
+  out[i] = c < Ca ? a[(n * Ca + c) * HW + hw] : (bcast ? b[n * Cb + (c - Ca)] : b[(n * Cb + (c - Ca)) * HW + hw]);
+}
+// adjoint: da = d[:, :Ca], db = d[:, Ca:] (summed over HW when bcast)
+__global__ void concat2_bwd_k(const float* __restrict__ d, float* __restrict__ da, float* __restrict__ db, long N, int Ca, int Cb,
+                              int HW, int bcast) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  const long na = N * Ca * HW, nb = bcast ? N * Cb : N * Cb * HW;
+  if (i < na) {
+    if (!da) return;
+    const long n = i / ((long)Ca * HW), r = i - n * (long)Ca * HW;
+    da[i] = d[n * (long)(Ca + Cb) * HW + r];
+  } else if (i < na + nb) {
+    if (!db) return;
+    const long j = i - na;
+    if (bcast) {
+      const long n = j / Cb; const int c = (int)(j - n * Cb);
+      const float* p = d + (n * (Ca + Cb) + Ca + c) * HW;
+      float s = 0.f;
+      for (int k = 0; k < HW; ++k) s += p[k];
+      db[j] = s;
+    } else {
+      const long n = j / ((long)Cb * HW), r = j - n * (long)Cb * HW;
+      db[j] = d[(n * (Ca + Cb) + Ca) * HW + r];
+    }
+  }
+}
+
+// dtable[v][c] += sum_{n: rows[n]==v} dout[n][c]  — embedding backward, one owner per cell, fixed order
+__global__ __launch_bounds__(256) void embedding_bwd_k(const float* __restrict__ dout, const long long* __restrict__ rows,
+                                                       float* __restrict__ dtable, int N, int D) {
+  __shared__ int lab[1024];
+  const int v = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f;
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int cnt = min(1024, N - n0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) lab[i] = (int)rows[n0 + i];
+    __syncthreads();
+    if (c < D)
+      for (int i = 0; i < cnt; ++i)
+        if (lab[i] == v) g += dout[(long)(n0 + i) * D + c];
+  }
+  if (c < D) dtable[(long)v * D + c] += g;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -561,6 +616,27 @@ int agl_pool_fuse_weight_bwd(const float* dw4, float* dw3, long n_filters, void*
   AGL_REQUIRE(dw4 && dw3 && n_filters > 0, "agl_pool_fuse_weight_bwd: bad argument");
   LAUNCH1D(pool_fuse_w_bwd_k, n_filters * 9, dw4, dw3, n_filters);
   AGL_CHECK_LAUNCH("agl_pool_fuse_weight_bwd");
+  return AGL_OK;
+}
+
+int agl_concat2_fwd(const float* a, const float* b, float* out, long N, int Ca, int Cb, int HW, int bcast, void* stream) {
+  AGL_REQUIRE(a && b && out && N > 0 && Ca > 0 && Cb > 0 && HW > 0, "agl_concat2_fwd: bad argument");
+  LAUNCH1D(concat2_fwd_k, N * (long)(Ca + Cb) * HW, a, b, out, N, Ca, Cb, HW, bcast);
+  AGL_CHECK_LAUNCH("agl_concat2_fwd");
+  return AGL_OK;
+}
+
+int agl_concat2_bwd(const float* d, float* da, float* db, long N, int Ca, int Cb, int HW, int bcast, void* stream) {
+  AGL_REQUIRE(d && (da || db) && N > 0 && Ca > 0 && Cb > 0 && HW > 0, "agl_concat2_bwd: bad argument");
+  LAUNCH1D(concat2_bwd_k, N * (long)Ca * HW + (bcast ? N * (long)Cb : N * (long)Cb * HW), d, da, db, N, Ca, Cb, HW, bcast);
+  AGL_CHECK_LAUNCH("agl_concat2_bwd");
+  return AGL_OK;
+}
+
+int agl_embedding_bwd(const float* dout, const long long* rows, float* dtable, int N, int D, int V, void* stream) {
+  AGL_REQUIRE(dout && rows && dtable && N > 0 && D > 0 && V > 0, "agl_embedding_bwd: bad argument");
+  hipLaunchKernelGGL(embedding_bwd_k, dim3(agl_cdiv(D, 256), V), dim3(256), 0, (hipStream_t)stream, dout, rows, dtable, N, D);
+  AGL_CHECK_LAUNCH("agl_embedding_bwd");
   return AGL_OK;
 }
 

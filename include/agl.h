@@ -103,6 +103,12 @@ int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumu
 int agl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream);
 int agl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream);
 
+/* torch.cat along channels of two NCHW tensors (b optionally (N,Cb) broadcast over HW) and its adjoint;
+ * nn.Embedding backward as a fixed-order row accumulation (generator_obj_att.py:489,549-552,589-590). */
+int agl_concat2_fwd(const float* a, const float* b, float* out, long N, int Ca, int Cb, int HW, int bcast, void* stream);
+int agl_concat2_bwd(const float* d, float* da, float* db, long N, int Ca, int Cb, int HW, int bcast, void* stream);
+int agl_embedding_bwd(const float* dout, const long long* rows, float* dtable, int N, int D, int V, void* stream);
+
 /* y[o,c] = u[o,c] (x) zero-padded mask[o]: the rank-1 layout tensor through LayoutEncoder.c0 (k1,p1)
  * (generator_obj_att.py:489-494) without materialising the (O,128,R,R) product. */
 int agl_mask_outer_fwd(const float* u, const float* mask, float* y, int O, int C, int R, int pad, void* stream);
