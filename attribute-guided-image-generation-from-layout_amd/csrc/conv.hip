@@ -15,6 +15,7 @@
 // LDS images are [k][row] (row-fast gathers) or [row][k] padded to 17 (k-fast gathers) so both
 // the staging writes and the 32-lane fragment reads stay (nearly) bank-conflict free.
 #include "agl_internal.h"
+#include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -417,19 +418,28 @@ __global__ void splitk_epilogue(const float* __restrict__ part, float* __restric
   out[o] = v;
 }
 
-// Reduction splits for the forward / input-gradient passes when the output grid alone cannot fill 256 CUs
-// (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails): K is cut so that ~2 workgroups per CU exist.
+// Reduction splits for the forward / input-gradient passes.  Two reasons to cut K: (1) the output grid alone cannot
+// fill the chip (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails); (2) wave quantisation — with 3
+// resident workgroups per CU there are 768 slots, and e.g. 788 tiles cost two full rounds; s-way splitting turns that
+// into ceil(788 s / 768) rounds of 1/s the length.  A small cost model picks s: rounds x per-round time + the slab
+// traffic of the deterministic split (s writes + s reads of the output).
 static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
   const int bn = M <= 32 ? 256 : 128;
   const long tiles = (long)agl_cdiv(M, bm) * agl_cdiv(Nc, bn) * Z;
-  int s = 1;
-  if (tiles < 256 && K >= 512) {
-    s = (int)((512 + tiles - 1) / tiles);
-    if (s > K / 128) s = K / 128;
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
+  const double slots = 768.0;
+  const double t_k = (double)bm * bn * 2.0 / 150e9;            // seconds per unit of K per workgroup (3 per CU)
+  const double out_bytes = (double)M * (double)Nc * Z * 4.0;    // upper bound of the output size
+  int best = 1;
+  double best_t = 1e30;
+  for (int s = 1; s <= 16; ++s) {
+    if (s > 1 && K / s < 128) break;
+    const double rounds = ceil((double)tiles * s / slots);
+    double t = rounds * ((double)K / s) * t_k + 4e-6 * (s > 1);
+    if (s > 1) t += out_bytes * (2.0 * s + 1.0) / 4.0e12;
+    if (t < best_t * 0.97) { best_t = t; best = s; }             // need a 3 % win to take a larger split
   }
+  int s = best;
   int per = (K + s - 1) / s;
   per = (per + BK - 1) / BK * BK;
   s = (K + per - 1) / per;
@@ -550,17 +560,25 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   return AGL_OK;
 }
 
-// Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every
-// split z < splits owns a non-empty range [z*per, min(R,(z+1)*per)).
+// Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every split z < splits owns
+// a non-empty range [z*per, min(R,(z+1)*per)).  Same quantisation-aware cost model as fwd_splits (768 slots).
 static int bww_splits(int Cout, long Nc, long R, long* per_out) {
   const int bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
   const int bn = Cout <= 32 ? 256 : 128;
-  long tiles = (long)agl_cdiv(Cout, bm) * agl_cdiv(Nc, bn);
-  long want = (1024 + tiles - 1) / tiles;
-  long maxs = R / 256 > 0 ? R / 256 : 1;
-  long s = want < maxs ? want : maxs;
-  if (s > 256) s = 256;
-  if (s < 1) s = 1;
+  const long tiles = (long)agl_cdiv(Cout, bm) * agl_cdiv(Nc, bn);
+  const double slots = 768.0;
+  const double t_k = (double)bm * bn * 2.0 / 150e9;
+  const double out_bytes = (double)Cout * (double)Nc * 4.0;
+  long best = 1;
+  double best_t = 1e30;
+  const long smax = R / 256 > 0 ? (R / 256 > 256 ? 256 : R / 256) : 1;
+  for (long s = 1; s <= smax; s = s < 16 ? s + 1 : s + s / 8) {
+    const double rounds = ceil((double)tiles * s / slots);
+    double t = rounds * ((double)R / s) * t_k + 4e-6 * (s > 1);
+    if (s > 1) t += out_bytes * (2.0 * s + 1.0) / 4.0e12;
+    if (t < best_t * 0.97) { best_t = t; best = s; }
+  }
+  long s = best;
   long per = (R + s - 1) / s;
   per = (per + BK - 1) / BK * BK;
   s = (R + per - 1) / per;
