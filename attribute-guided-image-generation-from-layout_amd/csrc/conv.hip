@@ -464,6 +464,79 @@ int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name) 
   return AGL_OK;
 }
 
+// ------------------------------------------------------------------ few-output-channel direct convolution
+// Convolutions with <= 4 output channels (decoder c4/c7: 64->3 k7; and the input gradients of the 3-channel first
+// layers: CropEncoder.c1, OptimizedBlock.resi[0], decoder.c5) would waste 29 of 32 MFMA rows and re-gather every
+// tap from HBM.  Here a workgroup owns a 16x16 output tile of one image, stages each input channel's
+// (16+ks-1)^2 patch in LDS once and accumulates the <= 4 outputs per pixel on the VALU; the filter taps are
+// wave-uniform (scalar loads).  The weight tensor is addressed by strides so the same kernel evaluates the
+// input-gradient form (flipped taps, channel roles swapped).  Stride 1 only.
+template <int KS>
+__global__ __launch_bounds__(256) void small_cout_conv(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ pos_mask,
+                                                       float* __restrict__ y, int Cin, int H, int W, int Cout, int OH, int OW,
+                                                       int pad, int s_co, int s_ci, int flip, int relu, int accumulate) {
+  constexpr int T = 16, P = T + KS - 1, CB = 4;
+  __shared__ float patch[CB][P * P];
+  const int tiles_x = (OW + T - 1) / T;
+  const int n = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * T, tx0 = (blockIdx.x % tiles_x) * T;
+  const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xn = x + (long)n * Cin * H * W;
+  for (int c0 = 0; c0 < Cin; c0 += CB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < CB * P * P; e += 256) {
+      const int c = e / (P * P), r = e - c * (P * P);
+      const int iy = ty0 - pad + r / P, ix = tx0 - pad + r % P;
+      float v = 0.f;
+      if (c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[(long)(c0 + c) * H * W + (long)iy * W + ix];
+      patch[c][r] = v;
+    }
+    __syncthreads();
+    const int cn = min(CB, Cin - c0);
+    for (int c = 0; c < cn; ++c) {
+      const float* wc = w + (long)(c0 + c) * s_ci;
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const float v = patch[c][(ty + kh) * P + tx + kw];
+          const int t = flip ? (KS - 1 - kh) * KS + (KS - 1 - kw) : kh * KS + kw;
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (o < Cout) acc[o] = fmaf(v, wc[(long)o * s_co + t], acc[o]);
+        }
+    }
+  }
+  const int oy = ty0 + ty, ox = tx0 + tx;
+  if (oy < OH && ox < OW) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < Cout) {
+        const long idx = ((long)n * Cout + o) * OH * OW + (long)oy * OW + ox;
+        float v = acc[o];
+        if (bias) v += bias[o];
+        if (pos_mask && !(pos_mask[idx] > 0.f)) v = 0.f;
+        if (accumulate) v += y[idx];
+        if (relu) v = fmaxf(v, 0.f);
+        y[idx] = v;
+      }
+  }
+}
+
+int launch_small_cout(const float* x, const float* w, const float* bias, const float* pos_mask, float* y, int N, int Cin, int H,
+                      int W, int Cout, int ks, int pad, int s_co, int s_ci, int flip, int relu, int accumulate, hipStream_t st,
+                      const char* name) {
+  const int OH = H + 2 * pad - ks + 1, OW = W + 2 * pad - ks + 1;
+  dim3 g(agl_cdiv(OH, 16) * agl_cdiv(OW, 16), N);
+#define AGL_SC(KS_) case KS_: hipLaunchKernelGGL((small_cout_conv<KS_>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, \
+                                                 Cout, OH, OW, pad, s_co, s_ci, flip, relu, accumulate); break;
+  switch (ks) { AGL_SC(1) AGL_SC(3) AGL_SC(4) AGL_SC(5) AGL_SC(7) default: return AGL_ERR_ARG; }
+#undef AGL_SC
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+
 bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 
 }  // namespace
@@ -489,6 +562,9 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
+  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu)
+    return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
+                             "agl_conv2d_fwd(small Cout)");
   const long out_numel = (long)N * Cout * OH * OW;
   int per = 0, rc = AGL_ERR_ARG;
   int splits = fwd_splits(Cout, (long)N * OH * OW, 1, Cin * ks * ks, &per);
@@ -527,6 +603,9 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
+  if (Cin <= 4 && stride == 1)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+    return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
+                             accumulate, st, "agl_conv2d_bwd_data(small Cin)");
   const long out_numel = (long)N * Cin * IH * IW;
   const int phases = stride * stride, Kp = Cout * (ks / stride) * (ks / stride);
   int per = 0, rc = AGL_ERR_ARG;
