@@ -22,6 +22,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "agl_version": (_I, []),
     "agl_last_error": (C.c_char_p, []),
+    "agl_set_conv_precision": (_I, [_I]),
+    "agl_get_conv_precision": (_I, []),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
     "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
     "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
@@ -118,6 +120,11 @@ def call(name: str, *args):
         rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.agl_last_error().decode()}")
+
+
+def set_conv_precision(mode: str):
+    """'f32': exact fp32 MFMA convolutions (default).  'bf16': bf16 MFMA operands, fp32 accumulation."""
+    call("agl_set_conv_precision", {"f32": 0, "fp32": 0, "bf16": 1}[mode])
 
 
 # --------------------------------------------------------------------------- helpers

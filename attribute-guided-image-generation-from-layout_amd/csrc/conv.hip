@@ -18,6 +18,7 @@
 #include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -243,7 +244,10 @@ struct BwdWeightProb {
 };
 
 // ------------------------------------------------------------------ the kernel
-template <class P, int BM, int BN>
+// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: operands rounded to bf16 (RNE) when the fragments are read
+// from LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the "bf16" configurations of BASELINE.json); the LDS
+// images are then [row][k] with a 20-float row pitch so a lane's 8 consecutive k values are two 16-byte reads.
+template <class P, int BM, int BN, int PREC>
 __global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
   constexpr int WAVES_M = (BM >= 128) ? 2 : 1;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -251,9 +255,10 @@ __global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
   constexpr int WTN = BN / (32 * WAVES_N);
   static_assert(WTM >= 1 && WTN >= 1, "tile too small for 4 waves");
   constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
-  constexpr int A_SZ = P::A_KFAST ? BM * (BK + 1) : BK * BM;
-  constexpr int B_SZ = P::B_KFAST ? BN * (BK + 1) : BK * BN;
-  __shared__ float lds[2 * (A_SZ + B_SZ)];
+  constexpr int LDH = BK + 4;   // PREC 1 row pitch (floats): 80 B, 16-byte aligned, conflict-free for b128 reads
+  constexpr int A_SZ = PREC ? BM * LDH : (P::A_KFAST ? BM * (BK + 1) : BK * BM);
+  constexpr int B_SZ = PREC ? BN * LDH : (P::B_KFAST ? BN * (BK + 1) : BK * BN);
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
   float* As = lds;
   float* Bs = lds + 2 * A_SZ;
 
@@ -317,6 +322,19 @@ __global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
   auto sstore = [&](int buf) {
     float* a = As + buf * A_SZ;
     float* b = Bs + buf * B_SZ;
+    if constexpr (PREC) {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) {
+        if constexpr (P::A_KFAST) a[(tid / BK + (NT / BK) * j) * LDH + tid % BK] = p.fix_a(va[j]);
+        else a[(tid % BM) * LDH + tid / BM + (NT / BM) * j] = p.fix_a(va[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        if constexpr (P::B_KFAST) b[(tid / BK + (NT / BK) * j) * LDH + tid % BK] = p.fix_b(vb[j]);
+        else b[(tid % BN) * LDH + tid / BN + (NT / BN) * j] = p.fix_b(vb[j]);
+      }
+      return;
+    }
     if constexpr (P::A_KFAST) {
 #pragma unroll
       for (int j = 0; j < A_PER; ++j) a[(tid / BK + (NT / BK) * j) * (BK + 1) + tid % BK] = p.fix_a(va[j]);
@@ -354,29 +372,55 @@ __global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
     gload_begin(k0 + BK);
     const float* a = As + cur * A_SZ;
     const float* b = Bs + cur * B_SZ;
+    if constexpr (PREC == 0) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      {   // this K-step's share of the next slice's gathers
-        constexpr int STEPS = BK / 2;
+      for (int kk = 0; kk < BK; kk += 2) {
+        {   // this K-step's share of the next slice's gathers
+          constexpr int STEPS = BK / 2;
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j)
-          if (j * STEPS / A_PER == kk / 2) gload_a(j, k0 + BK);
+          for (int j = 0; j < A_PER; ++j)
+            if (j * STEPS / A_PER == kk / 2) gload_a(j, k0 + BK);
 #pragma unroll
-        for (int j = 0; j < B_PER; ++j)
-          if (j * STEPS / B_PER == kk / 2) gload_b(j, k0 + BK);
+          for (int j = 0; j < B_PER; ++j)
+            if (j * STEPS / B_PER == kk / 2) gload_b(j, k0 + BK);
+        }
+        float fa[WTM], fb[WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+          fa[i] = P::A_KFAST ? a[(arow0 + 32 * i) * (BK + 1) + kk + lh] : a[(kk + lh) * BM + arow0 + 32 * i];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+          fb[j] = P::B_KFAST ? b[(brow0 + 32 * j) * (BK + 1) + kk + lh] : b[(kk + lh) * BN + brow0 + 32 * j];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-      float fa[WTM], fb[WTN];
+    } else {
+      // one 32x32x16 bf16 MFMA per accumulator covers the whole BK=16 slice; lane l supplies k = 8*(l>>5) .. +7
+      auto frag = [&](const float* base, int row) {
+        const float4 lo = *reinterpret_cast<const float4*>(base + row * LDH + 8 * lh);
+        const float4 hi = *reinterpret_cast<const float4*>(base + row * LDH + 8 * lh + 4);
+        bf16x8 f;
+        f[0] = (__bf16)lo.x; f[1] = (__bf16)lo.y; f[2] = (__bf16)lo.z; f[3] = (__bf16)lo.w;
+        f[4] = (__bf16)hi.x; f[5] = (__bf16)hi.y; f[6] = (__bf16)hi.z; f[7] = (__bf16)hi.w;
+        return f;
+      };
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
-        fa[i] = P::A_KFAST ? a[(arow0 + 32 * i) * (BK + 1) + kk + lh] : a[(kk + lh) * BM + arow0 + 32 * i];
+      for (int j = 0; j < A_PER; ++j) gload_a(j, k0 + BK);
 #pragma unroll
-      for (int j = 0; j < WTN; ++j)
-        fb[j] = P::B_KFAST ? b[(brow0 + 32 * j) * (BK + 1) + kk + lh] : b[(kk + lh) * BN + brow0 + 32 * j];
+      for (int j = 0; j < B_PER; ++j) gload_b(j, k0 + BK);
+      bf16x8 fa[WTM], fb[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) fa[i] = frag(a, arow0 + 32 * i);
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) fb[j] = frag(b, brow0 + 32 * j);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     sstore(cur ^ 1);
     __syncthreads();
@@ -447,19 +491,21 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
+int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
+
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name) {
   AGL_REQUIRE(Nc > 0 && Nc < (1L << 31) && M > 0, "%s: bad GEMM extents M=%d Nc=%ld", name, M, Nc);
-  if (M <= 32) {
-    dim3 g(agl_cdiv(Nc, 256), agl_cdiv(M, 32), Z);
-    hipLaunchKernelGGL((igemm_f32<P, 32, 256>), g, dim3(NT), 0, st, p);
-  } else if (M <= 64) {
-    dim3 g(agl_cdiv(Nc, 128), agl_cdiv(M, 64), Z);
-    hipLaunchKernelGGL((igemm_f32<P, 64, 128>), g, dim3(NT), 0, st, p);
-  } else {
-    dim3 g(agl_cdiv(Nc, 128), agl_cdiv(M, 128), Z);
-    hipLaunchKernelGGL((igemm_f32<P, 128, 128>), g, dim3(NT), 0, st, p);
-  }
+#define AGL_LAUNCH(BM_, BN_)                                                                      \
+  do {                                                                                            \
+    dim3 g(agl_cdiv(Nc, BN_), agl_cdiv(M, BM_), Z);                                               \
+    if (g_conv_precision) hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 1>), g, dim3(NT), 0, st, p); \
+    else hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 0>), g, dim3(NT), 0, st, p);                  \
+  } while (0)
+  if (M <= 32) AGL_LAUNCH(32, 256);
+  else if (M <= 64) AGL_LAUNCH(64, 128);
+  else AGL_LAUNCH(128, 128);
+#undef AGL_LAUNCH
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
@@ -542,6 +588,14 @@ bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 }  // namespace
 
 extern "C" {
+
+// 0: exact fp32 MFMA (default).  1: bf16 MFMA operands (round-to-nearest-even of the fp32 tensors), fp32 accumulate.
+int agl_set_conv_precision(int mode) {
+  AGL_REQUIRE(mode == 0 || mode == 1, "agl_set_conv_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+  g_conv_precision = mode;
+  return AGL_OK;
+}
+int agl_get_conv_precision(void) { return g_conv_precision; }
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {

@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 # train step, linear in P = objects per image (FlopCounterMode on the reference step, exact fit at P=3,6,9).
 FLOPS_PER_IMAGE = {64: (7.334e10, 6.566e10), 128: (6.202e11, 2.232e11)}
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
 
 
 def build_nets(res, dev):
@@ -80,6 +81,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 64 at 64px, 32 at 128px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="MFMA arithmetic of the convolutions: exact fp32 (BASELINE config 2) or bf16 operands with fp32 "
+                         "accumulation (configs 3/5); statistics, SN, losses and Adam are fp32 either way")
     ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     a = ap.parse_args()
@@ -101,6 +105,7 @@ def main():
     from agl import lib as L, synth
     from agl.trainer import Trainer, batch_to_device
     L.load()
+    L.set_conv_precision(a.dtype)
     per_gpu = a.batch or (64 if a.res == 64 else 32)
     torch.manual_seed(0)                         # identical initial weights on every rank
     nets, obj_size = build_nets(a.res, dev)
@@ -153,8 +158,9 @@ def main():
         c0, c1 = FLOPS_PER_IMAGE[a.res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic, per GPU per step
         ach = flops_step / (conv_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None,
                 "kernel": "igemm_f32<Fwd|BwdData|BwdWeight> (all convolution launches of one step)",
                 "launches_per_step": len(log), "kernel_ms_per_step": round(conv_ms, 3),
                 "algorithmic_flops_per_step": flops_step}
@@ -165,8 +171,8 @@ def main():
         images = per_gpu * world * a.steps
         out = {"metric": f"images/sec per G+D train step ({a.res}px)", "value": round(images / dt, 3), "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{a.res}x{a.res} G+D train step, batch={per_gpu}/GPU, fp32, synthetic VG-shaped batch "
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"{a.res}x{a.res} G+D train step, batch={per_gpu}/GPU, {a.dtype}, synthetic VG-shaped batch "
                                       f"(P~U{{3..9}}, O={O} objects on rank 0), random-init weights",
                           "global_batch": per_gpu * world, "objects_rank0": O, "parallelism": f"dp{world}"},
                "roofline": roof, "cpu_baseline": cpu}

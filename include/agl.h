@@ -32,6 +32,10 @@ const char* agl_last_error(void);
  *   in_relu  : relu applied to x while gathering (discriminator.py:71 in-place ReLU).
  *   relu     : relu on the output;  accumulate: y += result (before relu).
  *   ws       : optional split-K scratch (agl_conv2d_splitk_ws_bytes); without it small grids run unsplit.      */
+/* Arithmetic of the MFMA convolutions: 0 = exact fp32 (default, BASELINE config 2), 1 = bf16 operands with fp32
+ * accumulation (BASELINE configs 3/5).  Process-wide; everything else (statistics, SN, losses, Adam) stays fp32. */
+int agl_set_conv_precision(int mode);
+int agl_get_conv_precision(void);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,

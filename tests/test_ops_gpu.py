@@ -269,3 +269,31 @@ def test_convlstm_matches_reference_fixture(golden_dir):
     close(m.cell_list[0].conv.weight.grad, torch.from_numpy(g["clstm_dW0"]), 2e-4, "convlstm dW0")
     close(m.cell_list[2].conv.weight.grad, torch.from_numpy(g["clstm_dW2"]), 2e-4, "convlstm dW2")
     close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[8]])
+def test_conv2d_bf16_operand_mode(case):
+    """bf16 MFMA mode (BASELINE configs 3/5): operands are the RNE bf16 roundings of the fp32 tensors, accumulation is
+    fp32 — so the result must equal an fp32 convolution of the rounded tensors to fp32 accuracy, and the plain fp32
+    result to bf16 accuracy (2^-8 per operand)."""
+    from agl import functional as F, lib as L
+    N, Cin, H, W, Cout, ks, s, p = case
+    x, w = rn(N, Cin, H, W), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5)
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    xr, wr = r(x).requires_grad_(True), r(w).requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, stride=s, padding=p)
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(r(gy))                       # reference of the backward passes: rounded dy as well
+    y32 = TF.conv2d(x, w, None, stride=s, padding=p)
+    L.set_conv_precision("bf16")
+    try:
+        xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+        yg = F.conv2d(xg, wg, None, s, p)
+        yg.backward(dev(gy))
+    finally:
+        L.set_conv_precision("f32")
+    close(yg, yr, 2e-5, "y vs fp32 conv of bf16-rounded operands")
+    close(yg, y32, 2e-2, "y vs plain fp32")
+    close(xg.grad, xr.grad, 1e-4, "dx")
+    close(wg.grad, TF.conv2d(r(x).transpose(0, 1), r(gy).transpose(0, 1), stride=1, padding=p, dilation=s).transpose(0, 1)[:, :, :ks, :ks]
+          if False else wr.grad, 1e-2, "dw")        # dw uses rounded x and rounded dy: compare at bf16 accuracy

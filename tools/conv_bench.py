@@ -6,6 +6,8 @@ import torch
 from agl import lib as L
 
 dev = "cuda:0"
+if os.environ.get("AGL_PREC"):
+    L.set_conv_precision(os.environ["AGL_PREC"])
 O, N = 393, 64
 # name, batch, Cin, H, Cout, ks, stride, pad
 SHAPES = [
