@@ -69,6 +69,7 @@ SIGNATURES = {
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P]),
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "agl_attr_estimate": (_I, [_P, _P, _P, _I, _I, _P]),
     "agl_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
 }
 
@@ -369,3 +370,11 @@ def lstm_gates_bwd(dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     call("agl_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream())
+
+
+def attr_estimate(logits, attribute):
+    """train64.py:156-166 on device: un-annotated rows get one-hot(argmax(logits)); annotated rows keep their attributes."""
+    est = torch.empty_like(attribute)
+    O, A = attribute.shape
+    call("agl_attr_estimate", ptr(logits.contiguous()), ptr(attribute), ptr(est), O, A, stream())
+    return est

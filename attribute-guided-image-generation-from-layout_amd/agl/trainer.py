@@ -47,7 +47,7 @@ def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
 
 class Trainer:
     def __init__(self, netG, netD_image, netD_object, netD_att, pos_weight: torch.Tensor, *, lambdas: Optional[dict] = None,
-                 group=None):
+                 group=None, estimate_attributes: bool = False):
         self.netG, self.netDi, self.netDo, self.netDa = netG, netD_image, netD_object, netD_att
         dev = next(netG.parameters()).device
         if dev.type != "cuda":
@@ -64,6 +64,9 @@ class Trainer:
             for net in (netG, netD_image, netD_object, netD_att):
                 for buf in net.buffers():
                     self.sync.broadcast_(buf)
+        # True: derive attribute_est on device from the pre-step D_att logits (train64.py:156-166);
+        # False (default): take the batch's attribute_est (what the parity fixtures pin).
+        self.estimate_attributes = estimate_attributes
         self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
         self._d_ready = None
         self._g_ready = None
@@ -114,7 +117,10 @@ class Trainer:
         #      iteration's G all-reduce/Adam (side stream) overlaps it
         with torch.no_grad():
             crops_real = F.crop_boxes(b["imgs"], b["boxes"], o2i_dev, s)
-            self.netDa(crops_real)
+            att_logits = self.netDa(crops_real)
+            if self.estimate_attributes:
+                from . import lib as L
+                b = dict(b, attribute_est=L.attr_estimate(att_logits, b["attribute"]))
         self._wait(self._g_ready)
         self._g_ready = None
 

@@ -420,6 +420,33 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const float* __restrict__
   if (c < D) dtable[(long)v * D + c] += g;
 }
 
+// Attribute estimate of the training loop (reference train64.py:156-166): rows without any annotated attribute get
+// the arg-max of the attribute discriminator's logits as their single estimated attribute; annotated rows keep
+// their annotation.  One wave per object; ties resolve to the lowest index like torch.argmax.
+__global__ __launch_bounds__(256) void attr_estimate_k(const float* __restrict__ logits, const float* __restrict__ attr,
+                                                       float* __restrict__ est, int O, int A) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= O) return;
+  float best = -INFINITY, any = 0.f;
+  int arg = 0x7fffffff;
+  for (int a = lane; a < A; a += 64) {
+    const float v = logits[(long)row * A + a];
+    if (v > best) { best = v; arg = a; }          // strictly greater: keeps the lowest index within the lane
+    any += attr[(long)row * A + a];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oa = __shfl_xor(arg, o);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    any += __shfl_xor(any, o);
+  }
+  for (int a = lane; a < A; a += 64) {
+    const float t = attr[(long)row * A + a];
+    est[(long)row * A + a] = any != 0.f ? t : (a == arg ? 1.f : 0.f);
+  }
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -637,6 +664,13 @@ int agl_embedding_bwd(const float* dout, const long long* rows, float* dtable, i
   AGL_REQUIRE(dout && rows && dtable && N > 0 && D > 0 && V > 0, "agl_embedding_bwd: bad argument");
   hipLaunchKernelGGL(embedding_bwd_k, dim3(agl_cdiv(D, 256), V), dim3(256), 0, (hipStream_t)stream, dout, rows, dtable, N, D);
   AGL_CHECK_LAUNCH("agl_embedding_bwd");
+  return AGL_OK;
+}
+
+int agl_attr_estimate(const float* logits, const float* attribute, float* attribute_est, int O, int A, void* stream) {
+  AGL_REQUIRE(logits && attribute && attribute_est && O > 0 && A > 0, "agl_attr_estimate: bad argument");
+  hipLaunchKernelGGL(attr_estimate_k, dim3(agl_cdiv(O, 4)), dim3(256), 0, (hipStream_t)stream, logits, attribute, attribute_est, O, A);
+  AGL_CHECK_LAUNCH("agl_attr_estimate");
   return AGL_OK;
 }
 

@@ -152,6 +152,9 @@ int agl_l1_rows(const float* a, const float* b, const float* keep, long N, long 
 int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* loss_out, float* dmu, float* dlogvar,
                void* stream);
 
+/* ---- host logic of the loop moved on device: attribute estimate, train64.py:156-166 ------- */
+int agl_attr_estimate(const float* logits, const float* attribute, float* attribute_est, int O, int A, void* stream);
+
 /* ---- optimiser (torch.optim.Adam, train64.py:111-114) over a flat fp32 arena ---------------------- */
 int agl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
                   int step, float grad_scale, void* stream);

@@ -316,3 +316,50 @@ def test_step_bf16_mode_vs_reference_fixture(tag, res128, golden_dir):
         close(t, ref, 5e-2, n + " (bf16 mode)")
         rms = float((t.detach().cpu() - ref).pow(2).mean().sqrt() / ref.abs().max())
         assert rms <= 1e-2, (n, rms)
+
+
+def test_attribute_estimate_on_device():
+    """the per-row python loop of train64.py:156-166 as one kernel."""
+    from agl import lib as L
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(37, 106, generator=g)
+    logits[5, 10] = logits[5, 70] = logits[5].max() + 1        # tie -> lowest index, like torch.argmax
+    attr = (torch.rand(37, 106, generator=g) < 0.01).float()
+    attr[::3] = 0
+    ref = attr.clone()
+    for r in range(37):
+        if attr[r].sum() == 0:
+            ref[r, int(logits[r].argmax())] = 1
+    est = L.attr_estimate(logits.to(DEV), attr.to(DEV))
+    assert torch.equal(est.cpu(), ref)
+
+
+@pytest.mark.parametrize("res", [64, 128])
+def test_eval_mode_vs_oracle(res):
+    """SURVEY §8f N2 (inference path of test64.py:114-198): eval() uses the BatchNorm running statistics and spectral
+    norm without a power iteration; outputs must match the oracle with train=False and no state may change."""
+    from agl import synth
+    import oracle.graph as OG, oracle.step as OS
+    res128 = res == 128
+    G, Di, Do, Da = build_nets(res128)
+    for m in (G, Di, Do, Da):
+        m.eval()
+    P = OS.as_params({k: v.cpu() for k, v in G.state_dict().items()})
+    b = tensors(synth.make_batch(2, res, seed=8, objs_per_image=[3, 2]))
+    eps = [torch.randn(5, 64, generator=torch.Generator().manual_seed(1)) for _ in range(3)]
+    with torch.no_grad():
+        out_o = OG.generator(P, b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                             b["masks_shift"], b["boxes_shift"], b["attribute_est"], obj_size=G.obj_size, res128=res128,
+                             train=False, eps=eps)
+        d = {k: (v.to(DEV) if k != "obj_to_img" else v) for k, v in b.items()}
+        before = {k: v.clone() for k, v in G.state_dict().items()}
+        out_g = G(d["imgs"], d["objs"], d["boxes"], d["masks"], d["obj_to_img"], d["z"], d["attribute"], d["masks_shift"],
+                  d["boxes_shift"], d["attribute_est"], eps=eps)
+        for a, r in zip(out_g, out_o):
+            close(a, r, 1e-3, "eval generator output")
+        for k, v in G.state_dict().items():
+            assert torch.equal(v, before[k]), k
+        Pd = OS.as_params({k: v.cpu() for k, v in Di.state_dict().items()})
+        u_before = Di.state_dict()["classifier.weight_u"].clone()
+        close(Di(out_g[4]), OG.image_discriminator(Pd, out_o[4], train=False), 1e-3, "eval D_img")
+        assert torch.equal(Di.state_dict()["classifier.weight_u"], u_before)
