@@ -24,6 +24,7 @@ SIGNATURES = {
     "agl_last_error": (C.c_char_p, []),
     "agl_set_conv_precision": (_I, [_I]),
     "agl_get_conv_precision": (_I, []),
+    "agl_set_conv_patch": (_I, [_I]),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
     "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
     "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),

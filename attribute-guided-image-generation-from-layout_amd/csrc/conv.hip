@@ -491,6 +491,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
+int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
 int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
 
 template <class P>
@@ -583,6 +584,253 @@ int launch_small_cout(const float* x, const float* w, const float* bias, const f
   return AGL_OK;
 }
 
+// ------------------------------------------------------------------ LDS-patch ("direct") convolution, stride 1
+// For 3x3 / 5x5 stride-1 convolutions on power-of-two maps the im2col gather fetches every input element ks^2
+// times, each with its own address arithmetic.  Here a workgroup owns BM output channels x 128 output pixels laid
+// out as TI images x TH x TW, and per chunk of CB input channels stages (a) the raw input patch
+// TI x CB x (TH+ks-1) x (TW+ks-1) (zero padded, optional nearest up-sampling / input ReLU) and (b) the weight
+// slice [CB*ks^2][BM] in LDS.  The MFMA B fragment for k = (c,kh,kw) is then read straight from the patch at
+// pixel_offset(lane) + c*PS + kh*PW + kw — the tap offsets are compile-time constants.  The same kernel evaluates
+// the stride-1 input gradient (flipped taps, channel roles swapped through the weight strides).
+struct PatchArgs {
+  const float* x; const float* w; const float* bias; const float* pos_mask; float* y; float* part;
+  int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up); OH, OW: output map
+  int pad, up, in_relu, relu, accumulate;
+  int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
+  int splits, c_per_split;
+  long slab;
+  unsigned x_bytes, w_bytes;
+};
+
+// WVEC: the weight slice of a row is contiguous in memory (forward pass): stage it with coalesced 16-byte loads.
+template <int KS, int TW, int TH, int TI, int CB, int BM, bool WVEC>
+__global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
+  constexpr int BN = 128, PH = TH + KS - 1, PW = TW + KS - 1, PS = PH * PW, KC = CB * KS * KS;
+  constexpr int NP = TI * CB * PS, PL = (NP + NT - 1) / NT, WL = (KC * BM + NT - 1) / NT;
+  constexpr int LDW = BM + 1;                                  // odd pitch: both staging patterns stay (nearly) conflict free
+  constexpr int QR = KC / 4, WV = (QR * BM + NT - 1) / NT;     // WVEC: float4 per row, float4 loads per thread
+  constexpr int WAVES_M = BM >= 128 ? 2 : 1, WAVES_N = 4 / WAVES_M, WTM = BM / (32 * WAVES_M), WTN = BN / (32 * WAVES_N);
+  static_assert(KC % 2 == 0 && TI * TH * TW == BN, "patch_conv geometry");
+  __shared__ float patch[NP];
+  __shared__ float wt[KC * LDW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int Hl = p.H << p.up, Wl = p.W << p.up;
+  int img0, ty0, tx0;
+  if constexpr (TI == 1) {
+    const int tpr = p.OW / TW, tpi = (p.OH / TH) * tpr;
+    img0 = blockIdx.x / tpi;
+    const int t = blockIdx.x - img0 * tpi;
+    ty0 = (t / tpr) * TH; tx0 = (t % tpr) * TW;
+  } else {
+    img0 = blockIdx.x * TI; ty0 = 0; tx0 = 0;
+  }
+  const int bm0 = blockIdx.y * BM;
+  int c_beg = 0, c_end = p.Cin;
+  float* outp = p.y;
+  if (p.splits > 1) {
+    c_beg = blockIdx.z * p.c_per_split; c_end = min(p.Cin, c_beg + p.c_per_split);
+    outp = p.part + (long)blockIdx.z * p.slab;
+  }
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // per-thread constants of the two staging passes
+  unsigned poff_src[PL];   // byte offset of patch element e (without the channel-chunk term), or OOB
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int e = tid + NT * i;
+    const int ti = e / (CB * PS), r = e - ti * (CB * PS), c = r / PS, q = r - c * PS, yy = q / PW, xx = q - yy * PW;
+    const int img = img0 + ti, ly = ty0 - p.pad + yy, lx = tx0 - p.pad + xx;
+    const bool ok = e < NP && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+    poff_src[i] = ok ? (unsigned)(((img * p.Cin + c) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB;
+  }
+  const int wm_row = tid % BM;                       // weight staging: lanes along m, k_local = tid/BM + (NT/BM)*j
+  const int wkq = BM >= 64 ? __builtin_amdgcn_readfirstlane(tid / BM) : tid / BM;
+  const unsigned w_row_off = (bm0 + wm_row < p.Cout) ? (unsigned)((bm0 + wm_row) * p.w_sm) * 4u : OOB;
+
+  float pl[PL], wl[WVEC ? 4 * WV : WL];
+  bool wok[WVEC ? WV : 1];
+  auto gload = [&](int c0) {
+    const unsigned cstep = (unsigned)(c0 * p.H * p.W) * 4u;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int e = tid + NT * i;
+      const int c = (e % (CB * PS)) / PS;
+      const unsigned off = (poff_src[i] != OOB && c0 + c < c_end) ? poff_src[i] + cstep : OOB;
+      pl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, 0, 0));
+    }
+    if constexpr (WVEC) {
+      static_assert(!WVEC || KC % 4 == 0, "vector weight staging needs KC % 4 == 0");
+#pragma unroll
+      for (int j = 0; j < WV; ++j) {
+        const int f = tid + NT * j, m = f / QR, q = f - m * QR;          // lanes run along k inside a weight row
+        const bool ok = f < QR * BM && bm0 + m < p.Cout && c0 < c_end;   // chunks are CB-aligned: whole row valid or not
+        // (this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to a single dword load, so the 16-byte
+        //  fetch is a plain global load from a clamped, always-valid address; invalid rows are zeroed when staged)
+        const long idx = ok ? (long)(bm0 + m) * p.w_sm + (long)c0 * p.w_sc + 4 * q : 0;
+        const float4 v = *reinterpret_cast<const float4*>(p.w + idx);
+        wok[j] = ok;
+        wl[4 * j + 0] = v.x; wl[4 * j + 1] = v.y; wl[4 * j + 2] = v.z; wl[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+      const int k = wkq + (NT / BM) * j;             // scalar
+      const int c = k / (KS * KS), t = k - c * (KS * KS);
+      const int tap = p.flip ? KS * KS - 1 - t : t;
+      const unsigned off = (w_row_off != OOB && k < KC && c0 + c < c_end) ? w_row_off + (unsigned)((c0 + c) * p.w_sc + tap) * 4u : OOB;
+      wl[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, off, 0, 0));
+    }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int e = tid + NT * i;
+      if (e < NP) patch[e] = p.in_relu ? fmaxf(pl[i], 0.f) : pl[i];
+    }
+    if constexpr (WVEC) {
+#pragma unroll
+      for (int j = 0; j < WV; ++j) {
+        const int f = tid + NT * j, m = f / QR, q = f - m * QR;
+        if (f < QR * BM) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wt[(4 * q + e) * LDW + m] = wok[j] ? wl[4 * j + e] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WL; ++j)
+        if (tid / BM + (NT / BM) * j < KC) wt[(tid / BM + (NT / BM) * j) * LDW + wm_row] = wl[j];
+    }
+  };
+
+  // per-lane pixel offsets inside the patch image for the WTN 32-pixel sub-tiles of this wave
+  int ppix[WTN];
+#pragma unroll
+  for (int jt = 0; jt < WTN; ++jt) {
+    const int j = wn * 32 * WTN + 32 * jt + l31;
+    const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
+    ppix[jt] = ti * (CB * PS) + py * PW + px;
+  }
+  const int arow0 = wm * 32 * WTM + l31;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(c_beg);
+  sstore();
+  __syncthreads();
+  for (int c0 = c_beg; c0 < c_end; c0 += CB) {
+    gload(c0 + CB);                                   // past c_end everything is OOB -> zeros
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+      // tap offsets of k = kk and kk+1 are compile-time constants
+      constexpr auto PB = [](int k) { const int c = k / (KS * KS), t = k - c * (KS * KS); return c * PS + (t / KS) * PW + t % KS; };
+      const int pb = lh ? PB(kk + 1) : PB(kk);
+      float fa[WTM], fb[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) fa[i] = wt[(kk + lh) * LDW + arow0 + 32 * i];
+#pragma unroll
+      for (int jt = 0; jt < WTN; ++jt) fb[jt] = patch[ppix[jt] + pb];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int jt = 0; jt < WTN; ++jt)
+          acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[jt], acc[i][jt], 0, 0, 0);
+    }
+    __syncthreads();
+    sstore();
+    __syncthreads();
+  }
+
+  const long OHW = (long)p.OH * p.OW;
+#pragma unroll
+  for (int jt = 0; jt < WTN; ++jt) {
+    const int j = wn * 32 * WTN + 32 * jt + l31;
+    const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
+    const int img = img0 + ti;
+    const long pbase = (long)img * p.Cout * OHW + (long)(ty0 + py) * p.OW + tx0 + px;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      const int mb = bm0 + wm * 32 * WTM + 32 * i + 4 * lh;
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int m = mb + (r2 & 3) + 8 * (r2 >> 2);
+        if (m < p.Cout && img < p.N) {
+          const long o = pbase + (long)m * OHW;
+          float v = acc[i][jt][r2];
+          if (p.splits > 1) { outp[o] = v; continue; }
+          if (p.bias) v += p.bias[m];
+          if (p.pos_mask && !(p.pos_mask[o] > 0.f)) v = 0.f;
+          if (p.accumulate) v += outp[o];
+          if (p.relu) v = fmaxf(v, 0.f);
+          outp[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back to the im2col kernel)
+int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  if (g_conv_precision != 0) return -1;                       // fp32 path only (bf16 mode uses the im2col kernel)
+  if (ks != 3) return -1;                                     // 5x5 (ConvLSTM at 8x8): measured no faster than im2col
+  if (a.flip && a.OW < 32) return -1;                         // input-gradient form: wins on >= 32-wide maps only
+  const int cb = ks == 3 ? 8 : 2;
+  if (a.Cin % cb != 0 || a.Cout < 48) return -1;
+  int geo;
+  if (a.OW >= 16 && a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
+  else if (a.OW == 8 && a.OH == 8) geo = 1;
+  else if (a.OW == 4 && a.OH == 4) geo = 2;
+  else return -1;
+  const int bm = a.Cout <= 64 ? 64 : 128;
+  const long ptiles = geo == 0 ? (long)a.N * (a.OH / 8) * (a.OW / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  const long tiles = ptiles * agl_cdiv(a.Cout, bm);
+  // channel-chunk splits (same quantisation-aware idea as fwd_splits)
+  const long out_numel = (long)a.N * a.Cout * a.OH * a.OW;
+  int best = 1; double best_t = 1e30;
+  const int chunks = a.Cin / cb;
+  for (int s = 1; s <= 16 && s <= chunks; ++s) {
+    if (s > 1 && (chunks / s) * cb * ks * ks < 128) break;
+    const double rounds = ceil((double)tiles * s / 768.0);
+    double t = rounds * ((double)a.Cin * ks * ks / s) * (bm * 128 * 2.0 / 150e9) + 4e-6 * (s > 1);
+    if (s > 1) t += (double)out_numel * 4.0 * (2.0 * s + 1.0) / 4.0e12;
+    if (t < best_t * 0.97) { best_t = t; best = s; }
+  }
+  int splits = best;
+  int cps = agl_cdiv(agl_cdiv(chunks, splits), 1) * cb;
+  splits = agl_cdiv(a.Cin, cps);
+  if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; cps = a.Cin; }
+  a.splits = splits; a.c_per_split = cps; a.slab = out_numel; a.part = (float*)ws;
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), splits);
+#define AGL_PC(KS_, TW_, TH_, TI_, CB_, WV_)                                                                   \
+  do {                                                                                                          \
+    if (bm == 64) hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, CB_, 64, WV_>), g, dim3(NT), 0, st, a);     \
+    else hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, CB_, 128, WV_>), g, dim3(NT), 0, st, a);            \
+  } while (0)
+  if (ks == 3 && !a.flip) {       // forward: weight rows contiguous -> vector staging
+    if (geo == 0) AGL_PC(3, 16, 8, 1, 8, true); else if (geo == 1) AGL_PC(3, 8, 8, 2, 8, true); else AGL_PC(3, 4, 4, 8, 8, true);
+  } else {
+    AGL_PC(3, 16, 8, 1, 8, false);
+  }
+#undef AGL_PC
+  AGL_CHECK_LAUNCH(name);
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, a.y, out_numel, splits,
+                       a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu);
+    AGL_CHECK_LAUNCH(name);
+  }
+  return AGL_OK;
+}
+
 bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 
 }  // namespace
@@ -596,6 +844,7 @@ int agl_set_conv_precision(int mode) {
   return AGL_OK;
 }
 int agl_get_conv_precision(void) { return g_conv_precision; }
+int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; return AGL_OK; }
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {
@@ -619,6 +868,15 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
+  if (stride == 1 && g_use_patch) {
+    PatchArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.OH = OH; a.OW = OW; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu; a.accumulate = accumulate;
+    a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0;
+    a.x_bytes = (unsigned)((long)N * Cin * H * W * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
+    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_fwd(patch)");
+    if (prc >= 0) return prc;
+  }
   const long out_numel = (long)N * Cout * OH * OW;
   int per = 0, rc = AGL_ERR_ARG;
   int splits = fwd_splits(Cout, (long)N * OH * OW, 1, Cin * ks * ks, &per);
@@ -660,6 +918,15 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   if (Cin <= 4 && stride == 1)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
+  if (stride == 1 && g_use_patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
+    PatchArgs a;
+    a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
+    a.OH = IH; a.OW = IW; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
+    a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1;
+    a.x_bytes = (unsigned)((long)N * Cout * OH * OW * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
+    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_bwd_data(patch)");
+    if (prc >= 0) return prc;
+  }
   const long out_numel = (long)N * Cin * IH * IW;
   const int phases = stride * stride, Kp = Cout * (ks / stride) * (ks / stride);
   int per = 0, rc = AGL_ERR_ARG;

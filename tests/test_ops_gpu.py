@@ -297,3 +297,44 @@ def test_conv2d_bf16_operand_mode(case):
     close(xg.grad, xr.grad, 1e-4, "dx")
     close(wg.grad, TF.conv2d(r(x).transpose(0, 1), r(gy).transpose(0, 1), stride=1, padding=p, dilation=s).transpose(0, 1)[:, :, :ks, :ks]
           if False else wr.grad, 1e-2, "dw")        # dw uses rounded x and rounded dy: compare at bf16 accuracy
+
+
+PATCH_CASES = [
+    # N, Cin, H, W, Cout, ks   (stride 1, "same" padding) — shapes routed to the LDS-patch kernel
+    (2, 64, 16, 16, 128, 3), (3, 16, 32, 16, 64, 3), (5, 8, 4, 4, 64, 3), (9, 24, 4, 4, 136, 3), (3, 64, 8, 8, 512, 5),
+    (3, 40, 8, 8, 200, 3), (2, 6, 16, 32, 96, 5), (17, 10, 4, 4, 48, 5), (1, 128, 64, 64, 64, 3),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_patch_conv_fwd_bwd(case):
+    from agl import functional as F
+    N, Cin, H, W, Cout, ks = case
+    p = ks // 2
+    x, w, b = rn(N, Cin, H, W), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = TF.relu(TF.conv2d(TF.relu(xr), wr, br, padding=p))
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    yg = F.conv2d(xg, wg, bg, 1, p, in_relu=True, relu=True)
+    yg.backward(dev(gy))
+    close(yg, yr, 2e-5, "y")
+    close(xg.grad, xr.grad, 1e-4, "dx")
+    close(wg.grad, wr.grad, 1e-4, "dw")
+    close(bg.grad, br.grad, 1e-4, "db")
+
+
+def test_patch_conv_upsampled_input_and_addend():
+    from agl import functional as F
+    x, w, b = rn(3, 64, 8, 8), rn(128, 64, 3, 3, seed=1) * 0.05, rn(128, seed=2)
+    add = rn(3, 128, 32, 32, seed=5)
+    xr, wr, br, ar = (t.clone().requires_grad_(True) for t in (x, w, b, add))
+    yr = TF.conv2d(TF.interpolate(xr, scale_factor=4, mode="nearest"), wr, br, padding=1) + ar * 1.0
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    xg, wg, bg, ag = (dev(t).requires_grad_(True) for t in (x, w, b, add))
+    yg = F.conv2d(xg, wg, bg, 1, 1, up=2, addend=ag * 1.0)
+    yg.backward(dev(gy))
+    for n, a, r in (("y", yg, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad), ("dadd", ag.grad, ar.grad)):
+        close(a, r, 1e-4, "patch up+addend " + n)
