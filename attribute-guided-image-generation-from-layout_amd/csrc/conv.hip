@@ -248,7 +248,7 @@ struct BwdWeightProb {
 // from LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the "bf16" configurations of BASELINE.json); the LDS
 // images are then [row][k] with a 20-float row pitch so a lane's 8 consecutive k values are two 16-byte reads.
 template <class P, int BM, int BN, int PREC>
-__global__ __launch_bounds__(NT, 3) void igemm_f32(P p) {
+__global__ __launch_bounds__(NT, 4) void igemm_f32(P p) {
   constexpr int WAVES_M = (BM >= 128) ? 2 : 1;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WTM = BM / (32 * WAVES_M);
@@ -471,8 +471,8 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
   const int bn = M <= 32 ? 256 : 128;
   const long tiles = (long)agl_cdiv(M, bm) * agl_cdiv(Nc, bn) * Z;
-  const double slots = 768.0;
-  const double t_k = (double)bm * bn * 2.0 / 150e9;            // seconds per unit of K per workgroup (3 per CU)
+  const double slots = 1024.0;                                 // 4 resident workgroups per CU (<=128 VGPRs, 35 KB LDS)
+  const double t_k = (double)bm * bn * 2.0 / 115e9;            // seconds per unit of K per workgroup (4 per CU)
   const double out_bytes = (double)M * (double)Nc * Z * 4.0;    // upper bound of the output size
   int best = 1;
   double best_t = 1e30;
@@ -966,8 +966,8 @@ static int bww_splits(int Cout, long Nc, long R, long* per_out) {
   const int bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
   const int bn = Cout <= 32 ? 256 : 128;
   const long tiles = (long)agl_cdiv(Cout, bm) * agl_cdiv(Nc, bn);
-  const double slots = 768.0;
-  const double t_k = (double)bm * bn * 2.0 / 150e9;
+  const double slots = 1024.0;
+  const double t_k = (double)bm * bn * 2.0 / 115e9;
   const double out_bytes = (double)Cout * (double)Nc * 4.0;
   long best = 1;
   double best_t = 1e30;
