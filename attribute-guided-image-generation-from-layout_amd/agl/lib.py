@@ -109,6 +109,20 @@ EVENT_LOG = None
 EVENT_PREFIXES = ("agl_conv2d_",)
 
 
+def conv_flops(name, args) -> float:
+    """Executed FLOPs (2*MAC) of one convolution launch, from its C-ABI arguments."""
+    if name == "agl_conv2d_fwd":
+        N, Cin, H, W, Cout, ks, stride, pad, up = args[6:15]
+        OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
+    elif name == "agl_conv2d_bwd_data":
+        N, Cin, _, _, Cout, OH, OW, ks = args[7:15]
+    elif name == "agl_conv2d_bwd_weight":
+        N, Cin, _, _, Cout, OH, OW, ks = args[5:13]
+    else:
+        return 0.0
+    return 2.0 * N * OH * OW * Cout * Cin * ks * ks
+
+
 def call(name: str, *args):
     lib = load()
     log = EVENT_LOG
@@ -117,7 +131,7 @@ def call(name: str, *args):
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        log.append((name, e0, e1))
+        log.append((name, e0, e1, conv_flops(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-14:]))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

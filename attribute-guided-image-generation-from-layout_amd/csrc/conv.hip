@@ -865,7 +865,7 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu)
+  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64)   // (linear layers, HW = 1, stay on the GEMM)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
   if (stride == 1 && g_use_patch) {
@@ -915,7 +915,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cin <= 4 && stride == 1)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+  if (Cin <= 4 && stride == 1 && IH * IW >= 64)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
   if (stride == 1 && g_use_patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)

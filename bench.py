@@ -156,7 +156,17 @@ def main():
         fence()
         log, L.EVENT_LOG = L.EVENT_LOG, None
     if not a.no_roofline and rank == 0:
-        conv_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in log)
+        conv_ms = sum(e[1].elapsed_time(e[2]) for e in log)
+        executed = sum(e[3] for e in log)
+        if os.environ.get("AGL_DUMP_CONV"):
+            import collections
+            agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for name, e0, e1, f, dims in log:
+                k = (name.replace('agl_conv2d_', ''), dims)
+                agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
+            rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2] / 157.3e9))
+            for (nm, dims), (cnt, ms, fl) in rows[:40]:
+                print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/157.3e9:6.2f} ms  dims {dims}', file=sys.stderr)
         c0, c1 = FLOPS_PER_IMAGE[a.res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic, per GPU per step
         ach = flops_step / (conv_ms * 1e-3) / 1e12
@@ -165,6 +175,7 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": None,
                 "kernel": "convolution family: igemm_f32<Fwd|BwdData|BwdWeight> + patch_conv + small_cout_conv (all agl_conv2d_* launches of one step)",
                 "launches_per_step": len(log), "kernel_ms_per_step": round(conv_ms, 3),
+                "executed_flops_per_step": executed, "executed_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 3),
                 "algorithmic_flops_per_step": flops_step}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
