@@ -70,6 +70,7 @@ SIGNATURES = {
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P]),
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "agl_rasterize_boxes": (_I, [_P, _P, _I, _I, _P]),
     "agl_attr_estimate": (_I, [_P, _P, _P, _I, _I, _P]),
     "agl_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
 }
@@ -393,3 +394,11 @@ def attr_estimate(logits, attribute):
     O, A = attribute.shape
     call("agl_attr_estimate", ptr(logits.contiguous()), ptr(attribute), ptr(est), O, A, stream())
     return est
+
+
+def rasterize_boxes(boxes, R):
+    """(O,4) [x0,y0,x1,y1] in [0,1] -> (O,1,R,R) {0,1} masks (data/vg_custom_mask.py:136 semantics)."""
+    O = boxes.shape[0]
+    masks = torch.empty((O, 1, R, R), dtype=torch.float32, device=boxes.device)
+    call("agl_rasterize_boxes", ptr(boxes.contiguous()), ptr(masks), O, R, stream())
+    return masks

@@ -447,6 +447,25 @@ __global__ __launch_bounds__(256) void attr_estimate_k(const float* __restrict__
   }
 }
 
+// Box rasteriser of the dataset code (reference data/vg_custom_mask.py:136,158): mask[o,0,round(y0 R):round(y1 R),
+// round(x0 R):round(x1 R)] = 1 with python round() (double arithmetic, half-to-even) — SURVEY.md §8f N3: only
+// boxes need to cross PCIe, the (O,1,R,R) masks are built in HBM.
+__global__ void rasterize_boxes_k(const float* __restrict__ boxes, float* __restrict__ masks, int O, int R) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= (long)O * R * R) return;
+  const int x = (int)(i % R);
+  long t = i / R;
+  const int y = (int)(t % R);
+  const int o = (int)(t / R);
+  const float* b = boxes + 4 * o;
+  const long x0 = (long)rint((double)b[0] * R), y0 = (long)rint((double)b[1] * R);
+  const long x1 = (long)rint((double)b[2] * R), y1 = (long)rint((double)b[3] * R);
+  // python slice semantics: negative bounds count from the end, everything is clipped to [0, R]
+  auto clip = [R](long v) { if (v < 0) v += R; return v < 0 ? 0L : (v > R ? (long)R : v); };
+  const long cx0 = clip(x0), cx1 = clip(x1), cy0 = clip(y0), cy1 = clip(y1);
+  masks[i] = (x >= cx0 && x < cx1 && y >= cy0 && y < cy1) ? 1.f : 0.f;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -671,6 +690,13 @@ int agl_attr_estimate(const float* logits, const float* attribute, float* attrib
   AGL_REQUIRE(logits && attribute && attribute_est && O > 0 && A > 0, "agl_attr_estimate: bad argument");
   hipLaunchKernelGGL(attr_estimate_k, dim3(agl_cdiv(O, 4)), dim3(256), 0, (hipStream_t)stream, logits, attribute, attribute_est, O, A);
   AGL_CHECK_LAUNCH("agl_attr_estimate");
+  return AGL_OK;
+}
+
+int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* stream) {
+  AGL_REQUIRE(boxes && masks && O > 0 && R > 0, "agl_rasterize_boxes: bad argument");
+  LAUNCH1D(rasterize_boxes_k, (long)O * R * R, boxes, masks, O, R);
+  AGL_CHECK_LAUNCH("agl_rasterize_boxes");
   return AGL_OK;
 }
 

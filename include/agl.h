@@ -155,6 +155,8 @@ int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* 
                void* stream);
 
 /* ---- host logic of the loop moved on device: attribute estimate, train64.py:156-166 ------- */
+/* N3: object masks from boxes on device (data/vg_custom_mask.py:136,158: python round(), slice semantics) */
+int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* stream);
 int agl_attr_estimate(const float* logits, const float* attribute, float* attribute_est, int O, int A, void* stream);
 
 /* ---- optimiser (torch.optim.Adam, train64.py:111-114) over a flat fp32 arena ---------------------- */

@@ -363,3 +363,14 @@ def test_eval_mode_vs_oracle(res):
         u_before = Di.state_dict()["classifier.weight_u"].clone()
         close(Di(out_g[4]), OG.image_discriminator(Pd, out_o[4], train=False), 1e-3, "eval D_img")
         assert torch.equal(Di.state_dict()["classifier.weight_u"], u_before)
+
+
+def test_rasterize_boxes_on_device():
+    """masks built in HBM from the boxes equal the host rasteriser of the batch builder (python round,
+    slice clipping), for the regular and the shifted boxes (which may leave the image)."""
+    from agl import lib as L, synth
+    for R in (64, 128):
+        b = synth.make_batch(6, R, seed=17)
+        for boxes, masks in ((b["boxes"], b["masks"]), (b["boxes_shift"], b["masks_shift"])):
+            got = L.rasterize_boxes(torch.from_numpy(boxes).to(DEV), R)
+            assert torch.equal(got.cpu(), torch.from_numpy(masks))

@@ -338,3 +338,26 @@ def test_patch_conv_upsampled_input_and_addend():
     yg.backward(dev(gy))
     for n, a, r in (("y", yg, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad), ("dadd", ag.grad, ar.grad)):
         close(a, r, 1e-4, "patch up+addend " + n)
+
+
+@pytest.mark.parametrize("shape", [(393, 64, 66, 128, 4, 2, 1), (393, 512, 8, 512, 5, 1, 2), (64, 128, 64, 128, 3, 1, 1), (393, 256, 8, 512, 3, 1, 1)])
+def test_conv_adjoint_identities_at_full_size(shape):
+    """Oracle-free properties at BASELINE config-2 sizes (batch 64 / 393 objects): the three convolution passes are
+    mutually adjoint — <conv(x,w), g> = <x, bwd_data(g,w)> = <w, bwd_weight(g,x)> — and the forward pass is linear."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, s, p = shape
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, Cin, H, H, device=DEV, generator=gen)
+    w = torch.randn(Cout, Cin, ks, ks, device=DEV, generator=gen) * (1.0 / (Cin * ks * ks) ** 0.5)
+    y = L.conv2d_fwd(x, w, None, s, p)
+    g = torch.randn(y.shape, device=DEV, generator=gen)
+    dx = L.conv2d_bwd_data(g, w, (H, H), s, p)
+    dw = L.conv2d_bwd_weight(g, x, ks, s, p)
+    a = float((y.double() * g.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((w.double() * dw.double()).sum())
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    x2 = torch.randn(N, Cin, H, H, device=DEV, generator=gen)
+    lin = L.conv2d_fwd(0.5 * x - 2.0 * x2, w, None, s, p)
+    close(lin, 0.5 * y - 2.0 * L.conv2d_fwd(x2, w, None, s, p), 2e-5, "linearity")
