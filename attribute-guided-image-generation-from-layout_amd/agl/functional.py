@@ -356,6 +356,67 @@ def split_channels(x, Ca):
     return _Split2.apply(x, Ca)
 
 
+class _LayoutStage1(torch.autograd.Function):
+    """c2(relu(CondBN(c0-output))) of the layout encoder for the rank-1 input u (x) mask, in closed form
+    (csrc/layout.hip): the (O,64,R+2,R+2) activations are never built and c2 costs 32 FMAs per output."""
+
+    @staticmethod
+    def forward(ctx, u, masks, labels, table, w2, rmean, rvar, nbt, training):
+        u, masks, table, w2 = _c(u), _c(masks), _c(table), _c(w2)
+        O, Cc = u.shape
+        R, Co = masks.shape[-1], w2.shape[0]
+        assert w2.shape[1:] == (Cc, 4, 4) and masks.shape[-2] == R
+        dev = u.device
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        area, A, B, D = f(O), f(O, Cc), f(O, Cc), f(O, Cc)
+        if training:
+            mean, rstd = f(Cc), f(Cc)
+        else:
+            mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
+        L.call("agl_layout1_levels", L.ptr(u), L.ptr(masks), L.ptr(labels, torch.int64), L.ptr(table), L.ptr(area), L.ptr(mean),
+               L.ptr(rstd), L.ptr(A), L.ptr(B), L.ptr(D), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt, torch.int64), O, Cc, R, BN_EPS,
+               BN_MOMENTUM, int(training), L.stream())
+        Wr = f(Co * 16, Cc, 1, 1)
+        L.call("agl_layout1_permute", L.ptr(w2), L.ptr(Wr), Co, Cc, 1, L.stream())
+        WB = L.conv2d_fwd(B.view(O, Cc, 1, 1), Wr)
+        WD = L.conv2d_fwd(D.view(O, Cc, 1, 1), Wr)
+        OH = R // 2 + 1
+        y = f(O, Co, OH, OH)
+        L.call("agl_layout1_pixels", L.ptr(WB), L.ptr(WD), L.ptr(masks), L.ptr(y), O, Co, R, L.stream())
+        ctx.cfg = (training, R, Co)
+        ctx.save_for_backward(u, masks, labels, table, area, mean, rstd, A, B, D, Wr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, R, Co = ctx.cfg
+        u, masks, labels, table, area, mean, rstd, A, B, D, Wr = ctx.saved_tensors
+        dy = _c(dy)
+        O, Cc = u.shape
+        dev = u.device
+        GB = torch.empty((O, Co * 16, 1, 1), dtype=torch.float32, device=dev)
+        GD = torch.empty_like(GB)
+        L.call("agl_layout1_tapsum", L.ptr(dy), L.ptr(masks), L.ptr(GB), L.ptr(GD), O, Co, R, L.stream())
+        dW2 = None
+        if ctx.needs_input_grad[4]:
+            dWr = L.axpby(L.conv2d_bwd_weight(GB, B.view(O, Cc, 1, 1), 1), L.conv2d_bwd_weight(GD, D.view(O, Cc, 1, 1), 1))
+            dW2 = torch.empty((Co, Cc, 4, 4), dtype=torch.float32, device=dev)
+            L.call("agl_layout1_permute", L.ptr(dWr), L.ptr(dW2), Co, Cc, 0, L.stream())
+        dA = L.conv2d_bwd_data(GD, Wr, (1, 1)).view(O, Cc)
+        dB = L.conv2d_bwd_data(L.axpby(GB, GD, 1.0, -1.0), Wr, (1, 1)).view(O, Cc)
+        du = torch.empty_like(u)
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[3] else None
+        ws = L.workspace((O * Cc * 4 + 2 * Cc) * 4, dev)
+        L.call("agl_layout1_levels_bwd", L.ptr(dA), L.ptr(dB), L.ptr(A), L.ptr(B), L.ptr(u), L.ptr(area), L.ptr(mean), L.ptr(rstd),
+               L.ptr(table), L.ptr(labels, torch.int64), L.ptr(du), L.ptr(dtable), O, Cc, R, table.shape[0], int(training),
+               ws.data_ptr(), ws.numel(), L.stream())
+        return du, None, None, dtable, dW2, None, None, None, None
+
+
+def layout_stage1(u, masks, labels, table, w2, rmean, rvar, nbt, training=True):
+    return _LayoutStage1.apply(u, masks, labels, table, w2, rmean, rvar, nbt, training)
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -168,13 +168,19 @@ class LayoutEncoder(nn.Module):
         if pool_to_8:
             self.pool = nn.AdaptiveAvgPool2d(8)
         self.pool_to_8 = pool_to_8
+        self.closed_form_stage1 = True     # False: materialise c0's output and run bn1 / c2 as generic kernels
 
     def forward(self, objs_att, masks, obj_to_img, z, objs, plan: Optional[SequencePlan] = None):
         v = F.concat_channels(objs_att, z)
         assert self.c0.kernel_size == (1, 1) and self.c0.padding == (1, 1)
         u = F.linear(v, self.c0.weight.view(self.c0.out_channels, -1))   # c0 on the rank-1 tensor v (x) mask
-        h = self.bn1(F.mask_outer(u, masks, 1), objs, relu=True)
-        h = self.bn2(self.c2(h), objs, relu=True)
+        if self.closed_form_stage1 and masks.shape[-1] % 2 == 0 and self.c2.kernel_size == (4, 4):
+            bn = self.bn1.bn                                              # bn1 + ReLU + c2 on two-level images
+            h = F.layout_stage1(u, masks, objs, self.bn1.embed.weight, self.c2.weight, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, self.training)
+        else:
+            h = self.c2(self.bn1(F.mask_outer(u, masks, 1), objs, relu=True))
+        h = self.bn2(h, objs, relu=True)
         h = self.bn3(self.c3(h), objs, relu=True)
         h = self.bn4(self.c4(h), objs)
         if self.pool_to_8:

@@ -61,6 +61,11 @@ SIGNATURES = {
     "agl_mask_outer_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "agl_pool_fuse_weight_fwd": (_I, [_P, _P, _L, _P]),
     "agl_pool_fuse_weight_bwd": (_I, [_P, _P, _L, _P]),
+    "agl_layout1_levels": (_I, [_P] * 13 + [_I, _I, _I, _F, _F, _I, _P]),
+    "agl_layout1_permute": (_I, [_P, _P, _I, _I, _I, _P]),
+    "agl_layout1_pixels": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_layout1_tapsum": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_layout1_levels_bwd": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _P, _L, _P]),
     "agl_sn_layer_desc_bytes": (_L, []),
     "agl_sn_tmp_floats": (_L, [_I, _I]),
     "agl_sn_forward": (_I, [_P, _I, _I, _F, _P]),

@@ -125,6 +125,18 @@ int agl_mask_outer_bwd(const float* dy, const float* mask, float* du, int O, int
 int agl_pool_fuse_weight_fwd(const float* w3, float* w4, long n_filters, void* stream);
 int agl_pool_fuse_weight_bwd(const float* dw4, float* dw3, long n_filters, void* stream);
 
+/* ---- layout-encoder first stage in closed form (generator_obj_att.py:489-497: rank-1 tensor -> c0 -> CondBN -> ReLU
+ * -> c2): two-level images; see csrc/layout.hip.  OH = R/2 + 1. */
+int agl_layout1_levels(const float* u, const float* mask, const long long* labels, const float* table, float* area, float* mean,
+                       float* rstd, float* A, float* B, float* D, float* running_mean, float* running_var,
+                       long long* num_batches_tracked, int O, int C, int R, float eps, float momentum, int training, void* stream);
+int agl_layout1_permute(const float* src, float* dst, int Co, int C, int to_rows, void* stream);
+int agl_layout1_pixels(const float* WB, const float* WD, const float* mask, float* y, int O, int Co, int R, void* stream);
+int agl_layout1_tapsum(const float* dy, const float* mask, float* GB, float* GD, int O, int Co, int R, void* stream);
+int agl_layout1_levels_bwd(const float* dA, const float* dB, const float* A, const float* B, const float* u, const float* area,
+                           const float* mean, const float* rstd, const float* table, const long long* labels, float* du,
+                           float* dtable, int O, int C, int R, int V, int training, void* ws, long ws_bytes, void* stream);
+
 /* ---- spectral norm (torch.nn.utils.spectral_norm via add_sn, discriminator.py:15-22), batched per net */
 struct AglSnLayer {
   const float* w; float* u; float* v; float* w_sn; float* sigma; float* tmp; float* u_used; float* v_used;

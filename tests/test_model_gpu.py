@@ -374,3 +374,43 @@ def test_rasterize_boxes_on_device():
         for boxes, masks in ((b["boxes"], b["masks"]), (b["boxes_shift"], b["masks_shift"])):
             got = L.rasterize_boxes(torch.from_numpy(boxes).to(DEV), R)
             assert torch.equal(got.cpu(), torch.from_numpy(masks))
+
+
+@pytest.mark.parametrize("res", [64, 128])
+def test_layout_stage1_closed_form_equals_generic_kernels(res):
+    """The closed-form first stage of the layout encoder (two-level images, csrc/layout.hip) against the same stage run
+    through the generic kernels (materialised c0 output -> CondBN -> ReLU -> c2): outputs, every gradient and the
+    BatchNorm running statistics."""
+    from agl import synth
+    from agl.generator import LayoutEncoder
+    from oracle.fill import fill_state
+    torch.manual_seed(0)
+    enc = LayoutEncoder(z_dim=64, obj_att_dim=64, class_num=179, clstm_layers=3, pool_to_8=(res == 128))
+    enc.load_state_dict(fill_state(enc.state_dict()))
+    enc = enc.to(DEV)
+    b = tensors(synth.make_batch(3, res, seed=4, objs_per_image=[3, 5, 2]))
+    O = b["objs"].shape[0]
+    g = torch.Generator().manual_seed(2)
+    att, z = torch.randn(O, 64, generator=g), torch.randn(O, 64, generator=g)
+    results = []
+    for closed in (True, False):
+        enc.closed_form_stage1 = closed
+        enc.zero_grad()
+        enc.bn1.bn.running_mean.zero_(); enc.bn1.bn.running_var.fill_(1.0)
+        a, zz = att.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+        v = torch.cat((a, zz), 1)
+        u = __import__("agl.functional", fromlist=["x"]).linear(v, enc.c0.weight.view(64, -1))
+        F = __import__("agl.functional", fromlist=["x"])
+        if closed:
+            bn = enc.bn1.bn
+            h = F.layout_stage1(u, b["masks"].to(DEV), b["objs"].to(DEV), enc.bn1.embed.weight, enc.c2.weight, bn.running_mean,
+                                bn.running_var, bn.num_batches_tracked, True)
+        else:
+            h = enc.c2(enc.bn1(F.mask_outer(u, b["masks"].to(DEV), 1), b["objs"].to(DEV), relu=True))
+        cot = torch.randn(h.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        h.backward(cot)
+        results.append((h.detach().clone(), a.grad.clone(), zz.grad.clone(), enc.c2.weight.grad.clone(), enc.c0.weight.grad.clone(),
+                        enc.bn1.embed.weight.grad.clone(), enc.bn1.bn.running_mean.clone(), enc.bn1.bn.running_var.clone()))
+    names = ["y", "d obj_att", "d z", "d c2.weight", "d c0.weight", "d bn1.embed", "running_mean", "running_var"]
+    for n, x, r in zip(names, results[0], results[1]):
+        close(x, r, 2e-4 if n.startswith("d") else 2e-5, n)
