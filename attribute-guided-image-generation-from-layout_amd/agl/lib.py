@@ -77,6 +77,7 @@ SIGNATURES = {
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "agl_rasterize_boxes": (_I, [_P, _P, _I, _I, _P]),
     "agl_attr_estimate": (_I, [_P, _P, _P, _I, _I, _P]),
+    "agl_deprocess_u8": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "agl_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
 }
 
@@ -407,3 +408,13 @@ def rasterize_boxes(boxes, R):
     masks = torch.empty((O, 1, R, R), dtype=torch.float32, device=boxes.device)
     call("agl_rasterize_boxes", ptr(boxes.contiguous()), ptr(masks), O, R, stream())
     return masks
+
+
+def deprocess_u8(imgs, inv_std, mean, rescale=True):
+    """(N,3,H,W) fp32 -> (N,3,H,W) uint8 on device (data/utils.py:47-66)."""
+    N, Cc, H, W = imgs.shape
+    out = torch.empty((N, Cc, H, W), dtype=torch.uint8, device=imgs.device)
+    a = (C.c_float * 3)(*inv_std)
+    b = (C.c_float * 3)(*mean)
+    call("agl_deprocess_u8", ptr(imgs.contiguous()), ptr(out, torch.uint8), N, Cc, H * W, int(bool(rescale)), a, b, stream())
+    return out

@@ -98,6 +98,16 @@ def make_pos_weight(n_attr: int = NUM_ATTRIBUTES, seed: int = 7) -> np.ndarray:
     return ((100000.0 - c) / c).astype(np.float32)
 
 
+def make_cooccurrence(n_classes: int = NUM_OBJECT_CLASSES, n_attr: int = NUM_ATTRIBUTES, seed: int = 11) -> np.ndarray:
+    """Stand-in for matrix_obj_vs_att.pt (train64.py:83): (V, A) non-negative co-occurrence counts, sparse like the
+    real table (most object classes see a handful of attributes)."""
+    rng = np.random.default_rng(seed)
+    m = rng.integers(1, 500, size=(n_classes, n_attr)).astype(np.float32)
+    m *= rng.random((n_classes, n_attr)) < 0.3
+    m[:, 0] += 1.0                                   # no all-zero row (random.choices would raise)
+    return m
+
+
 def shard(batch: Dict[str, np.ndarray], rank: int, world: int) -> Dict[str, np.ndarray]:
     """Contiguous image shard for data-parallel rank `rank`; obj_to_img renumbered from 0."""
     n = batch["imgs"].shape[0]

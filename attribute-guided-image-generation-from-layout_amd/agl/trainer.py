@@ -195,6 +195,21 @@ class Trainer:
         self._wait(self._d_ready)
         self._g_ready = self._d_ready = None
 
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """Adam moments and step counts of both arenas (what torch.optim.Adam.state_dict() would carry)."""
+        self.finish()
+        return {"g_m": self.flat_g.m.clone(), "g_v": self.flat_g.v.clone(), "g_step": self.flat_g.step_count,
+                "d_m": self.flat_d.m.clone(), "d_v": self.flat_d.v.clone(), "d_step": self.flat_d.step_count}
+
+    def load_optimizer_state(self, st):
+        self.finish()
+        for flat, k in ((self.flat_g, "g"), (self.flat_d, "d")):
+            if st[k + "_m"].numel() != flat.n:
+                raise ValueError(f"optimizer state size {st[k + '_m'].numel()} != arena size {flat.n}")
+            flat.m.copy_(st[k + "_m"])
+            flat.v.copy_(st[k + "_v"])
+            flat.step_count = int(st[k + "_step"])
+
     def loss_dict(self) -> Dict[str, float]:
         """The 15 scalars the reference logs (train64.py:266-272, :372-379); one device->host copy."""
         r = {k: float(v) for k, v in zip(RAW, self.raw.detach().cpu().tolist())}

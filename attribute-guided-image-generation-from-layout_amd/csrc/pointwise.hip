@@ -466,6 +466,42 @@ __global__ void rasterize_boxes_k(const float* __restrict__ boxes, float* __rest
   masks[i] = (x >= cx0 && x < cx1 && y >= cy0 && y < cy1) ? 1.f : 0.f;
 }
 
+// ImageNet de-normalisation to bytes (data/utils.py:47-66 imagenet_deprocess_batch): per channel
+// y = x / fp32(1/std_c) + fp32(mean_c) (two torchvision Normalize passes: sub 0, div 1/std; sub -mean, div 1),
+// then per IMAGE (all channels) r = (y - lo) / (hi - lo) when rescaling, then byte(clamp(255 r, 0, 255)).
+// One workgroup per image; the operation order is the reference's so the bytes are identical.
+__global__ __launch_bounds__(256) void deprocess_u8_k(const float* __restrict__ x, unsigned char* __restrict__ out, int C, int HW,
+                                                      int rescale, float is0, float is1, float is2, float m0, float m1, float m2) {
+  __shared__ float s_lo[256], s_hi[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const long base = (long)n * C * HW;
+  const int per = C * HW;
+  auto denorm = [&](int e) {
+    const int c = e / HW;
+    const float is = c == 0 ? is0 : (c == 1 ? is1 : is2), mm = c == 0 ? m0 : (c == 1 ? m1 : m2);
+    float y = (x[base + e] - 0.f) / is;
+    return (y - (-mm)) / 1.f;
+  };
+  float lo = INFINITY, hi = -INFINITY;
+  if (rescale) {
+    for (int e = tid; e < per; e += 256) { const float y = denorm(e); lo = fminf(lo, y); hi = fmaxf(hi, y); }
+    s_lo[tid] = lo; s_hi[tid] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) { s_lo[tid] = fminf(s_lo[tid], s_lo[tid + s]); s_hi[tid] = fmaxf(s_hi[tid], s_hi[tid + s]); }
+      __syncthreads();
+    }
+    lo = s_lo[0]; hi = s_hi[0];
+  }
+  const float range = hi - lo;
+  for (int e = tid; e < per; e += 256) {
+    float y = denorm(e);
+    if (rescale) y = (y - lo) / range;
+    y = fminf(fmaxf(y * 255.f, 0.f), 255.f);
+    out[base + e] = (unsigned char)(int)y;       // NaN (constant image, 0/0) -> 0 like the host cast
+  }
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -697,6 +733,15 @@ int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* st
   AGL_REQUIRE(boxes && masks && O > 0 && R > 0, "agl_rasterize_boxes: bad argument");
   LAUNCH1D(rasterize_boxes_k, (long)O * R * R, boxes, masks, O, R);
   AGL_CHECK_LAUNCH("agl_rasterize_boxes");
+  return AGL_OK;
+}
+
+int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, int rescale, const float* inv_std, const float* mean,
+                     void* stream) {
+  AGL_REQUIRE(x && out && inv_std && mean && N > 0 && C == 3 && HW > 0, "agl_deprocess_u8: bad argument (C must be 3)");
+  hipLaunchKernelGGL(deprocess_u8_k, dim3(N), dim3(256), 0, (hipStream_t)stream, x, out, C, HW, rescale, inv_std[0], inv_std[1],
+                     inv_std[2], mean[0], mean[1], mean[2]);
+  AGL_CHECK_LAUNCH("agl_deprocess_u8");
   return AGL_OK;
 }
 

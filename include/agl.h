@@ -170,6 +170,10 @@ int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* 
 /* N3: object masks from boxes on device (data/vg_custom_mask.py:136,158: python round(), slice semantics) */
 int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* stream);
 int agl_attr_estimate(const float* logits, const float* attribute, float* attribute_est, int O, int A, void* stream);
+/* N2: data/utils.py:47-66 imagenet_deprocess_batch — de-normalise, per-image min/max rescale, bytes. inv_std/mean are
+ * HOST pointers to 3 floats (fp32(1/std_c), fp32(mean_c)). */
+int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, int rescale, const float* inv_std, const float* mean,
+                     void* stream);
 
 /* ---- optimiser (torch.optim.Adam, train64.py:111-114) over a flat fp32 arena ---------------------- */
 int agl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,

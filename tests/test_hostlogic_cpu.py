@@ -1,0 +1,80 @@
+"""CPU coverage of the rows next to the hot path: checkpoint file conventions
+(utils/model_saver_iter.py:6-87), the rows the attribute swap touches (train64.py:170-178) and the oracle's
+host-logic restatement against hand-computed cases."""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def test_checkpoint_naming_pruning_and_latest(tmp_path):
+    from agl import checkpoint as CK
+    d = str(tmp_path / "ck")
+    m = nn.Sequential(nn.Linear(3, 2), nn.BatchNorm1d(2))
+    assert CK.load_model(m, d, appendix="netG", iter='l') == 0          # directory missing -> scratch
+    for it in (1000, 2000, 3000, 4000):
+        with torch.no_grad():
+            m[0].weight.fill_(float(it))
+        CK.save_model(m, d, appendix="netG", iter=it, save_num=2, save_step=1000)
+        CK.save_model(m, d, appendix="netD_image", iter=it, save_num=2, save_step=1000)
+    names = sorted(os.listdir(d))
+    assert names == ["iter-3000_netD_image.pkl", "iter-3000_netG.pkl", "iter-4000_netD_image.pkl", "iter-4000_netG.pkl"]
+    m2 = nn.Sequential(nn.Linear(3, 2), nn.BatchNorm1d(2))
+    assert CK.load_model(m2, d, appendix="netG", iter='l') == 4000
+    assert float(m2[0].weight[0, 0]) == 4000.0
+    assert CK.load_model(m2, d, appendix="netG", iter=3000) == 3000
+    assert float(m2[0].weight[0, 0]) == 3000.0
+    assert CK.load_model(m2, d, appendix="netG", iter=1000) == 0        # pruned -> scratch
+    assert CK.load_model(m2, d, appendix="netG", iter='s') == 0
+    # the file is a plain state_dict (what the reference's torch.save(model.state_dict()) writes)
+    sd = torch.load(os.path.join(d, "iter-4000_netG.pkl"))
+    assert list(sd.keys()) == list(m.state_dict().keys())
+
+
+def test_dropin_import_paths():
+    import utils.model_saver_iter as MS
+    from agl import checkpoint as CK
+    assert MS.load_model is CK.load_model and MS.save_model is CK.save_model
+
+
+def test_swap_rows_match_oracle_loop():
+    from agl import hostlogic as H, synth
+    import oracle.hostlogic as OH
+    bn = synth.make_batch(9, 64, seed=3)
+    o2i = torch.from_numpy(bn["obj_to_img"])
+    A = bn["attribute_gt"].shape[1]
+    att = torch.from_numpy(bn["attribute_gt"]).clone()
+    est = att.clone()
+    matrix = torch.from_numpy(synth.make_cooccurrence())
+    before = att.clone()
+    random.seed(4)
+    OH.swap_attributes(att, est, torch.from_numpy(bn["objs"]), o2i, matrix, 9)
+    changed = sorted(int(i) for i in torch.nonzero((att != before).any(dim=1)).view(-1))
+    rows = H.swap_rows(o2i, 9)
+    assert set(changed) <= set(rows)
+    P = np.bincount(bn["obj_to_img"])
+    assert len(rows) == sum(int(P[i]) // 2 for i in range(3))
+    for r in rows:                                           # new rows: 1 or 2 attributes, none of the old ones
+        assert 1 <= int(att[r].sum()) <= 2
+        assert float((att[r] * before[r]).sum()) == 0.0
+        assert torch.equal(att[r], est[r])
+    assert att.shape[1] == A
+
+
+def test_oracle_estimate_and_deprocess_small_cases():
+    import oracle.hostlogic as OH
+    attr = torch.zeros(3, 5)
+    attr[1, 2] = 1
+    logits = torch.tensor([[0.1, 0.9, 0.0, 0.0, 0.0], [5.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 2.0]])
+    est = OH.estimate_attributes(logits, attr)
+    assert est.tolist() == [[0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 1]]
+    x = torch.zeros(1, 3, 2, 2)
+    x[0, 0, 0, 0] = 1.0
+    b = OH.imagenet_deprocess_batch(x, rescale=True)
+    assert b.dtype == torch.uint8 and int(b.max()) == 255 and int(b.min()) == 0
+    # no rescale: (x*std + mean)*255 truncated
+    b2 = OH.imagenet_deprocess_batch(torch.zeros(1, 3, 1, 1), rescale=False)
+    assert b2.view(-1).tolist() == [int(np.float32(0.485) * np.float32(255)), int(np.float32(0.456) * np.float32(255)),
+                                    int(np.float32(0.406) * np.float32(255))]
