@@ -96,11 +96,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
+    path = os.environ.get("AGL_LIBRARY", LIB_PATH)      # A/B builds of the same ABI (tools/); default = in-tree build
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build the HIP extension first "
                           f"(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc). "
                           f"This package has no CPU or eager fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -23,6 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BK = 16;
+#ifndef AGL_GATHER_STEPS
+#define AGL_GATHER_STEPS (BK / 2)   // MFMA k-steps of a slice over which the next slice's gathers are spread
+#endif
 constexpr int NT = 256;
 
 template <int KS> struct KDiv {  // k -> (c, kh, kw) for a KSxKS window
@@ -243,12 +246,39 @@ struct BwdWeightProb {
   }
 };
 
+// ------------------------------------------------------------------ workgroup -> tile, XCD-aware
+// The grid is 1-D; workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an XCD and its L2).  Tiles
+// that read the same operand slices are therefore placed 8 ids apart:
+//   * z >= 8 slices (split-K parts / weight-gradient slabs: each slice reads its own K-range of both operands):
+//     slice z lives on XCD z % 8, so one L2 fetches that K-range once instead of all eight;
+//   * otherwise: the gy row tiles of a column tile (same im2col columns, different filters) sit on one XCD, adjacent
+//     in dispatch order, so the gathered operand is fetched from HBM once per column tile, not once per row tile.
+#ifndef AGL_XCD_REMAP
+#define AGL_XCD_REMAP 1
+#endif
+__device__ __forceinline__ void tile_of_block(int gx, int gy, int gz, int& bx, int& by, int& bz) {
+  const int L = blockIdx.x, T = gx * gy;
+  if (!AGL_XCD_REMAP) { bz = L / T; const int l = L - bz * T; by = l / gx; bx = l - by * gx; return; }
+  int t;
+  if (gz >= 8) {
+    const int z8 = gz & ~7;
+    if (L < T * z8) { const int local = L >> 3; const int q = local / T; bz = q * 8 + (L & 7); t = local - q * T; }
+    else { bz = L / T; t = L - bz * T; }
+    by = t % gy; bx = t / gy;
+    return;
+  }
+  bz = L / T;
+  const int l = L - bz * T, gx8 = gx & ~7;
+  if (l < gx8 * gy) { const int local = l >> 3; const int c = local / gy; by = local - c * gy; bx = c * 8 + (l & 7); }
+  else { const int r = l - gx8 * gy; const int c = r / gy; by = r - c * gy; bx = gx8 + c; }
+}
+
 // ------------------------------------------------------------------ the kernel
 // PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: operands rounded to bf16 (RNE) when the fragments are read
 // from LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the "bf16" configurations of BASELINE.json); the LDS
 // images are then [row][k] with a 20-float row pitch so a lane's 8 consecutive k values are two 16-byte reads.
 template <class P, int BM, int BN, int PREC>
-__global__ __launch_bounds__(NT, 4) void igemm_f32(P p) {
+__global__ __launch_bounds__(NT, (BM * BN > 128 * 128) ? 2 : 4) void igemm_f32(P p, int gx, int gy, int gz) {
   constexpr int WAVES_M = (BM >= 128) ? 2 : 1;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WTM = BM / (32 * WAVES_M);
@@ -262,8 +292,10 @@ __global__ __launch_bounds__(NT, 4) void igemm_f32(P p) {
   float* As = lds;
   float* Bs = lds + 2 * A_SZ;
 
-  if (!p.setup(blockIdx.z)) return;
-  const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+  int bx, by, bz;
+  tile_of_block(gx, gy, gz, bx, by, bz);
+  if (!p.setup(bz)) return;
+  const int bm0 = by * BM, bn0 = bx * BN;
   if (bm0 >= p.M || bn0 >= p.Nc) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -373,29 +405,36 @@ __global__ __launch_bounds__(NT, 4) void igemm_f32(P p) {
     const float* a = As + cur * A_SZ;
     const float* b = Bs + cur * B_SZ;
     if constexpr (PREC == 0) {
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        {   // this K-step's share of the next slice's gathers
-          constexpr int STEPS = BK / 2;
-#pragma unroll
-          for (int j = 0; j < A_PER; ++j)
-            if (j * STEPS / A_PER == kk / 2) gload_a(j, k0 + BK);
-#pragma unroll
-          for (int j = 0; j < B_PER; ++j)
-            if (j * STEPS / B_PER == kk / 2) gload_b(j, k0 + BK);
-        }
-        float fa[WTM], fb[WTN];
+      // Software pipeline, pinned with scheduling barriers (left alone, the compiler sinks every gather to the end of
+      // the slice and waits on it at once, exposing the full memory latency each slice): K-step s issues its share of
+      // the next slice's gathers and the LDS fragment reads of step s+1, then runs the 4 MFMAs of step s on fragments
+      // read one step earlier.
+      constexpr int STEPS = BK / 2;
+      float fa[2][WTM], fb[2][WTN];
+      auto read_frags = [&](int kk, float (&xa)[WTM], float (&xb)[WTN]) {
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
-          fa[i] = P::A_KFAST ? a[(arow0 + 32 * i) * (BK + 1) + kk + lh] : a[(kk + lh) * BM + arow0 + 32 * i];
+          xa[i] = P::A_KFAST ? a[(arow0 + 32 * i) * (BK + 1) + kk + lh] : a[(kk + lh) * BM + arow0 + 32 * i];
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-          fb[j] = P::B_KFAST ? b[(brow0 + 32 * j) * (BK + 1) + kk + lh] : b[(kk + lh) * BN + brow0 + 32 * j];
+          xb[j] = P::B_KFAST ? b[(brow0 + 32 * j) * (BK + 1) + kk + lh] : b[(kk + lh) * BN + brow0 + 32 * j];
+      };
+      read_frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        if (st + 1 < STEPS) read_frags(2 * (st + 1), fa[(st + 1) & 1], fb[(st + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j)
+          if (j * AGL_GATHER_STEPS / A_PER == st) gload_a(j, k0 + BK);
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j)
+          if (j * AGL_GATHER_STEPS / B_PER == st) gload_b(j, k0 + BK);
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
 #pragma unroll
           for (int j = 0; j < WTN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][i], fb[st & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       // one 32x32x16 bf16 MFMA per accumulator covers the whole BK=16 slice; lane l supplies k = 8*(l>>5) .. +7
@@ -495,16 +534,20 @@ int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution 
 int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
 
 template <class P>
-int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name) {
+int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int big_tile = 0) {
   AGL_REQUIRE(Nc > 0 && Nc < (1L << 31) && M > 0, "%s: bad GEMM extents M=%d Nc=%ld", name, M, Nc);
 #define AGL_LAUNCH(BM_, BN_)                                                                      \
   do {                                                                                            \
-    dim3 g(agl_cdiv(Nc, BN_), agl_cdiv(M, BM_), Z);                                               \
-    if (g_conv_precision) hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 1>), g, dim3(NT), 0, st, p); \
-    else hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 0>), g, dim3(NT), 0, st, p);                  \
+    const long gx_ = agl_cdiv(Nc, BN_), gy_ = agl_cdiv(M, BM_);                                   \
+    AGL_REQUIRE(gx_ * gy_ * Z < (1L << 31), "%s: grid too large", name);                          \
+    dim3 g((unsigned)(gx_ * gy_ * Z));                                                            \
+    if (g_conv_precision) hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 1>), g, dim3(NT), 0, st, p, (int)gx_, (int)gy_, Z); \
+    else hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 0>), g, dim3(NT), 0, st, p, (int)gx_, (int)gy_, Z);                  \
   } while (0)
   if (M <= 32) AGL_LAUNCH(32, 256);
   else if (M <= 64) AGL_LAUNCH(64, 128);
+  else if (big_tile == 1) AGL_LAUNCH(256, 128);
+  else if (big_tile == 2) AGL_LAUNCH(128, 256);
   else AGL_LAUNCH(128, 128);
 #undef AGL_LAUNCH
   AGL_CHECK_LAUNCH(name);
@@ -962,12 +1005,22 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
 
 // Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every split z < splits owns
 // a non-empty range [z*per, min(R,(z+1)*per)).  Same quantisation-aware cost model as fwd_splits (768 slots).
+// Weight-gradient GEMMs use a 256x128 (Cout multiple of 256) or 128x256 (Cout <= 128) tile where it fits (2 workgroups
+// per CU, 8 accumulators per wave): both operands are long streams there and the larger tile moves 25 % fewer bytes per
+// FLOP through LDS (+8-16 % measured); forward and input-gradient passes measured no gain (or a loss) and stay on 128x128.
+static int bww_big_tile(int Cout, long Nc) {
+  if (Cout >= 256 && Cout % 256 == 0) return 1;
+  if (Cout > 64 && Cout <= 128 && (Nc + 255) / 256 * 256 * 100 <= Nc * 112) return 2;   // 128x256 unless padding costs > 12 %
+  return 0;
+}
+
 static int bww_splits(int Cout, long Nc, long R, long* per_out) {
-  const int bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
-  const int bn = Cout <= 32 ? 256 : 128;
+  const int big = bww_big_tile(Cout, Nc);
+  const int bm = big == 1 ? 256 : (Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128));
+  const int bn = (Cout <= 32 || big == 2) ? 256 : 128;
   const long tiles = (long)agl_cdiv(Cout, bm) * agl_cdiv(Nc, bn);
-  const double slots = 1024.0;
-  const double t_k = (double)bm * bn * 2.0 / 115e9;
+  const double slots = big ? 512.0 : 1024.0;
+  const double t_k = (double)bm * bn * 2.0 / (big ? 230e9 : 115e9);
   const double out_bytes = (double)Cout * (double)Nc * 4.0;
   long best = 1;
   double best_t = 1e30;
@@ -1021,7 +1074,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.in_relu = in_relu; p.M = Cout; p.Nc = (int)Nc; p.HW = H * W;         \
     p.OHW = OH * OW; p.R = (int)R; p.per_split = (int)per; p.slab = (long)Cout * Nc; p.kbeg = 0; p.kend = 0;    \
     p.a_bytes = (unsigned)((long)N * Cout * OH * OW * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);    \
-    rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight");                                         \
+    rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight", bww_big_tile(Cout, Nc));                \
   } break;
   switch (ks) { AGL_BWW(1) AGL_BWW(3) AGL_BWW(4) AGL_BWW(5) AGL_BWW(7) }
 #undef AGL_BWW

@@ -1,0 +1,15 @@
+"""Run one convolution shape a few times (for rocprofv3 --pmc / --kernel-trace): one_conv.py B Cin H Cout ks stride pad [pass]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "attribute-guided-image-generation-from-layout_amd"))
+import torch
+from agl import lib as L
+B, Cin, H, Cout, ks, s, p = (int(v) for v in sys.argv[1:8])
+which = sys.argv[8] if len(sys.argv) > 8 else "fwd"
+x = torch.randn(B, Cin, H, H, device="cuda:0"); w = torch.randn(Cout, Cin, ks, ks, device="cuda:0") * 0.05
+y = L.conv2d_fwd(x, w, None, s, p); dy = torch.randn_like(y)
+for _ in range(5):
+    if which == "fwd": L.conv2d_fwd(x, w, None, s, p)
+    elif which == "bwd_data": L.conv2d_bwd_data(dy, w, (H, H), s, p)
+    else: L.conv2d_bwd_weight(dy, x, ks, s, p)
+torch.cuda.synchronize()
