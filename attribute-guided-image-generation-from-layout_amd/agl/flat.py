@@ -35,6 +35,7 @@ class FlatParams:
                 self.p[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.p[o:o + k].view(p.shape)
                 p.grad = self.g[o:o + k].view(p.shape)
+                p._agl_slot = True          # backward kernels accumulate straight into this slot (functional._slot)
                 o += k
 
     def zero_grad(self):

@@ -19,10 +19,18 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _slot(p):
+    """Gradient slot of a parameter owned by a flat arena (agl.flat.FlatParams marks them): backward kernels then
+    accumulate straight into the arena and return None, instead of handing autograd a temporary that it adds to
+    .grad with one extra elementwise launch per parameter per use (~700 launches per training iteration)."""
+    return p.grad if (p is not None and getattr(p, "_agl_slot", False) and p.grad is not None) else None
+
+
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu):
+        ctx.slots = (_slot(w), _slot(bias))
         x, w = _c(x), _c(w)
         if addend is not None:
             assert not relu, "addend with fused ReLU is not supported"
@@ -50,10 +58,17 @@ class _Conv2d(torch.autograd.Function):
                 assert not in_relu
             else:
                 dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if in_relu else None)
+        wslot, bslot = ctx.slots
         if ctx.needs_input_grad[1]:
-            dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu)
+            if wslot is not None:
+                L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True)
+            else:
+                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu)
         if has_bias and ctx.needs_input_grad[2]:
-            db = L.channel_sum(g)
+            if bslot is not None:
+                L.channel_sum(g, out=bslot, accumulate=True)
+            else:
+                db = L.channel_sum(g)
         dadd = dy if (has_add and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dadd, None, None, None, None, None
 
@@ -76,6 +91,7 @@ class _ConvT4s2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
+        ctx.slot = _slot(w)
         x, w = _c(x), _c(w)
         ctx.save_for_backward(x, w)
         return L.conv2d_bwd_data(x, w, (2 * x.shape[2], 2 * x.shape[3]), 2, 1)
@@ -85,7 +101,12 @@ class _ConvT4s2(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _c(dy)
         dx = L.conv2d_fwd(dy, w, None, 2, 1) if ctx.needs_input_grad[0] else None
-        dw = L.conv2d_bwd_weight(x, dy, 4, 2, 1) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.slot is not None:
+                L.conv2d_bwd_weight(x, dy, 4, 2, 1, out=ctx.slot, accumulate=True)
+            else:
+                dw = L.conv2d_bwd_weight(x, dy, 4, 2, 1)
         return dx, dw
 
 
@@ -496,6 +517,8 @@ class _SpectralNormWeights(torch.autograd.Function):
         L.call("agl_sn_forward", C.cast(descs, C.c_void_p), n, int(training), SN_EPS, L.stream())
         ctx.descs, ctx.keep = descs, (arena, sigma, u_used, v_used, tmp)
         ctx.shapes = [tuple(w.shape) for w in ws]
+        slots = [_slot(w) for w in ws]
+        ctx.slots = slots if all(sl is not None for sl in slots) else None
         return tuple(outs)
 
     @staticmethod
@@ -503,7 +526,8 @@ class _SpectralNormWeights(torch.autograd.Function):
         descs = ctx.descs
         arena = ctx.keep[0]
         n = len(gs)
-        dws = torch.empty_like(arena)
+        slots = ctx.slots
+        dws = torch.empty_like(arena) if slots is None else None
         held, o = [], 0
         for i, g in enumerate(gs):
             if g is None:
@@ -511,9 +535,11 @@ class _SpectralNormWeights(torch.autograd.Function):
             g = _c(g)
             held.append(g)
             descs[i].g = g.data_ptr()
-            descs[i].dw = dws.data_ptr() + 4 * o
+            descs[i].dw = slots[i].data_ptr() if slots is not None else dws.data_ptr() + 4 * o
             o += g.numel()
-        L.call("agl_sn_backward", C.cast(descs, C.c_void_p), n, L.stream())
+        L.call("agl_sn_backward", C.cast(descs, C.c_void_p), n, int(slots is not None), L.stream())
+        if slots is not None:                      # accumulated straight into the weight_orig gradient slots
+            return (None, None, None) + (None,) * n
         outs, o = [], 0
         for i in range(n):
             sz = held[i].numel()

@@ -69,7 +69,7 @@ SIGNATURES = {
     "agl_sn_layer_desc_bytes": (_L, []),
     "agl_sn_tmp_floats": (_L, [_I, _I]),
     "agl_sn_forward": (_I, [_P, _I, _I, _F, _P]),
-    "agl_sn_backward": (_I, [_P, _I, _P]),
+    "agl_sn_backward": (_I, [_P, _I, _I, _P]),
     "agl_bce_logits_const": (_I, [_P, _L, _F, _F, _P, _P, _P]),
     "agl_bce_logits_posw": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),

@@ -124,34 +124,44 @@ __global__ __launch_bounds__(256) void l1_pixels_k(const float* __restrict__ WB,
   }
 }
 
-// GB[o,co,t] = sum_p dy[o,co,p] I_t(p), GD[o,co,t] = sum_p dy[o,co,p] m_t(p).  Block: one object x 4 output channels
-// (one per wave); the 32 tap sums of a wave are reduced with shuffles (fixed order).
+// GB[o,co,t] = sum_p dy[o,co,p] I_t(p), GD[o,co,t] = sum_p dy[o,co,p] m_t(p).  Block: one object x 32 output channels.
+// The tap bits of every output pixel are computed once per block into LDS (the mask is read once per 32 channels, not
+// once per channel); wave g then owns channels g, g+4, ... and reduces its 32 tap sums with shuffles (fixed order).
+constexpr int TAPSUM_CH = 32;
 __global__ __launch_bounds__(256) void l1_tapsum_k(const float* __restrict__ dy, const float* __restrict__ mask, float* __restrict__ GB,
                                                    float* __restrict__ GD, int O, int Co, int R, int OH) {
-  const int o = blockIdx.y, co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (co >= Co) return;
+  extern __shared__ unsigned l1_bits[];       // [OH*OH]: in_img | in_mask << 16
+  const int o = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int OHW = OH * OH;
-  float sb[16], sd[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) { sb[t] = 0.f; sd[t] = 0.f; }
-  const float* d = dy + ((long)o * Co + co) * OHW;
-  for (int p = lane; p < OHW; p += 64) {
+  for (int p = threadIdx.x; p < OHW; p += 256) {
     unsigned bi, bm;
     tap_bits(mask + (long)o * R * R, R, p / OH, p % OH, bi, bm);
-    const float v = d[p];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      sb[t] += (bi >> t & 1) ? v : 0.f;
-      sd[t] += (bm >> t & 1) ? v : 0.f;
-    }
+    l1_bits[p] = bi | (bm << 16);
   }
+  __syncthreads();
+  const int c_end = min(Co, (int)(blockIdx.x + 1) * TAPSUM_CH);
+  for (int co = blockIdx.x * TAPSUM_CH + g; co < c_end; co += 4) {
+    float sb[16], sd[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) { sb[t] = wave_sum(sb[t]); sd[t] = wave_sum(sd[t]); }
-  if (lane == 0) {
+    for (int t = 0; t < 16; ++t) { sb[t] = 0.f; sd[t] = 0.f; }
+    const float* d = dy + ((long)o * Co + co) * OHW;
+    for (int p = lane; p < OHW; p += 64) {
+      const unsigned bits = l1_bits[p];
+      const float v = d[p];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      GB[((long)o * Co + co) * 16 + t] = sb[t];
-      GD[((long)o * Co + co) * 16 + t] = sd[t];
+      for (int t = 0; t < 16; ++t) {
+        sb[t] += (bits >> t & 1) ? v : 0.f;
+        sd[t] += (bits >> (16 + t) & 1) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { sb[t] = wave_sum(sb[t]); sd[t] = wave_sum(sd[t]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        GB[((long)o * Co + co) * 16 + t] = sb[t];
+        GD[((long)o * Co + co) * 16 + t] = sd[t];
+      }
     }
   }
 }
@@ -261,7 +271,10 @@ int agl_layout1_pixels(const float* WB, const float* WD, const float* mask, floa
 
 int agl_layout1_tapsum(const float* dy, const float* mask, float* GB, float* GD, int O, int Co, int R, void* stream) {
   AGL_REQUIRE(dy && mask && GB && GD && O > 0 && Co > 0 && R > 0 && R % 2 == 0, "agl_layout1_tapsum: bad argument");
-  hipLaunchKernelGGL(l1_tapsum_k, dim3(agl_cdiv(Co, 4), O), dim3(256), 0, (hipStream_t)stream, dy, mask, GB, GD, O, Co, R, R / 2 + 1);
+  const int OH = R / 2 + 1;
+  AGL_REQUIRE((long)OH * OH * 4 <= 64 * 1024, "agl_layout1_tapsum: map too large for the LDS bit table");
+  hipLaunchKernelGGL(l1_tapsum_k, dim3(agl_cdiv(Co, TAPSUM_CH), O), dim3(256), (size_t)OH * OH * sizeof(unsigned), (hipStream_t)stream, dy, mask,
+                     GB, GD, O, Co, R, OH);
   AGL_CHECK_LAUNCH("agl_layout1_tapsum");
   return AGL_OK;
 }

@@ -16,7 +16,7 @@ struct AglSnLayer {       // one entry per layer (host array, passed to the kern
   float* u_used;          // output [rows]: the u that defines sigma (kept for backward)
   float* v_used;          // output [cols]
   const float* g;         // backward: grad wrt w_sn
-  float* dw;              // backward: grad wrt weight_orig (overwritten)
+  float* dw;              // backward: grad wrt weight_orig (overwritten, or += when accumulate is set)
   int rows, cols;
 };
 constexpr int AGL_SN_MAX_LAYERS = 24;
@@ -112,13 +112,14 @@ __global__ __launch_bounds__(256) void sn_bwd_dot(const AglSnBatch L) {
   s = block_sum_256(s, sc);
   if (threadIdx.x == 0) l.tmp[max(l.rows, l.cols)] = (float)s;
 }
-__global__ void sn_bwd_apply(const AglSnBatch L) {
+__global__ void sn_bwd_apply(const AglSnBatch L, int accumulate) {
   const AglSnLayer& l = L.l[blockIdx.y];
   const long n = (long)l.rows * l.cols;
   const float sg = *l.sigma, dot = l.tmp[max(l.rows, l.cols)];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int r = (int)(i / l.cols), k = (int)(i - (long)r * l.cols);
-    l.dw[i] = (l.g[i] - dot * l.u_used[r] * l.v_used[k]) / sg;
+    const float d = (l.g[i] - dot * l.u_used[r] * l.v_used[k]) / sg;
+    l.dw[i] = accumulate ? l.dw[i] + d : d;
   }
 }
 
@@ -171,7 +172,7 @@ int agl_sn_forward(const void* layers, int n_layers, int power_iter, float eps, 
 }
 
 // dw = (g - <g, w_sn> u v^T) / sigma for every layer (u_used, v_used, sigma, w_sn as left by the matching forward).
-int agl_sn_backward(const void* layers, int n_layers, void* stream) {
+int agl_sn_backward(const void* layers, int n_layers, int accumulate, void* stream) {
   AglSnBatch L; int max_rows, max_cols;
   int rc = sn_pack(layers, n_layers, L, max_rows, max_cols, "agl_sn_backward");
   if (rc) return rc;
@@ -184,7 +185,7 @@ int agl_sn_backward(const void* layers, int n_layers, void* stream) {
   long maxn = (long)max_rows * max_cols;
   int gx = agl_cdiv(maxn, 256 * 4);
   if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(sn_bwd_apply, dim3(gx, n_layers), dim3(256), 0, st, L);
+  hipLaunchKernelGGL(sn_bwd_apply, dim3(gx, n_layers), dim3(256), 0, st, L, accumulate);
   AGL_CHECK_LAUNCH("agl_sn_backward(apply)");
   return AGL_OK;
 }

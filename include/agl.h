@@ -145,7 +145,7 @@ struct AglSnLayer {
 long agl_sn_layer_desc_bytes(void);
 long agl_sn_tmp_floats(int rows, int cols);
 int agl_sn_forward(const void* host_layers, int n_layers, int power_iter, float eps, void* stream);
-int agl_sn_backward(const void* host_layers, int n_layers, void* stream);
+int agl_sn_backward(const void* host_layers, int n_layers, int accumulate, void* stream);
 
 /* ---- losses of train64.py:195-245, 284-354 -----------------------------------------------------------
  * Single-workgroup, fixed-order reductions.  Each call writes the UNWEIGHTED loss to *loss_out and, when the
