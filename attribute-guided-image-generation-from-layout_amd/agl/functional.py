@@ -438,6 +438,55 @@ def layout_stage1(u, masks, labels, table, w2, rmean, rvar, nbt, training=True):
     return _LayoutStage1.apply(u, masks, labels, table, w2, rmean, rvar, nbt, training)
 
 
+class _CatBatch(torch.autograd.Function):
+    """Concatenate equally shaped tensors along dim 0 (plumbing copies; backward hands out views)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        n = xs[0].shape[0]
+        out = torch.empty((n * len(xs),) + tuple(xs[0].shape[1:]), dtype=xs[0].dtype, device=xs[0].device)
+        for i, x in enumerate(xs):
+            assert x.shape == xs[0].shape
+            out[i * n:(i + 1) * n].copy_(x)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        n = ctx.n
+        return tuple(d[i * n:(i + 1) * n] for i in range(d.shape[0] // n))
+
+
+class _SplitBatch(torch.autograd.Function):
+    """Inverse of _CatBatch: k equal chunks along dim 0 as views; backward gathers the chunk gradients."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        n = x.shape[0] // k
+        ctx.shape = tuple(x.shape)
+        outs = tuple(x[i * n:(i + 1) * n] for i in range(k))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *ds):
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=next(d for d in ds if d is not None).device)
+        n = ctx.shape[0] // len(ds)
+        for i, d in enumerate(ds):
+            if d is None:
+                out[i * n:(i + 1) * n].zero_()
+            else:
+                out[i * n:(i + 1) * n].copy_(d)
+        return out, None
+
+
+def cat_batch(xs):
+    return _CatBatch.apply(*xs)
+
+
+def split_batch(x, k):
+    return _SplitBatch.apply(x, k)
+
+
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

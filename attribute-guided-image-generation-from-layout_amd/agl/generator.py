@@ -171,6 +171,26 @@ class LayoutEncoder(nn.Module):
         self.closed_form_stage1 = True     # False: materialise c0's output and run bn1 / c2 as generic kernels
 
     def forward(self, objs_att, masks, obj_to_img, z, objs, plan: Optional[SequencePlan] = None):
+        h = self.front(objs_att, masks, z, objs)
+        h = self.clstm(h, obj_to_img, plan=plan)
+        return self.residual(h)
+
+    def forward_many(self, calls, obj_to_img, objs):
+        """Several forward calls [(objs_att, masks, z), ...] on the same object list, results identical to calling
+        forward() once per entry in order: the stages that carry batch statistics (CondBN before the ConvLSTM, BN in
+        the residual blocks) run per call in call order, so every normalisation layer sees the same sequence of
+        batches; the ConvLSTM between them has no batch coupling and runs ONCE on the concatenated object lists
+        (k times the images per recurrence step: k times fewer launches, fuller grids, one backward)."""
+        k = len(calls)
+        fronts = [self.front(a, m, z, objs) for (a, m, z) in calls]
+        ids = obj_to_img.detach().cpu()
+        n_img = int(ids.max()) + 1
+        # image ids must stay one run per image: offset every copy past the previous one's last id
+        plan = SequencePlan(torch.cat([ids + i * n_img for i in range(k)]), fronts[0].device)
+        h = self.clstm(F.cat_batch(fronts), None, plan=plan)
+        return [self.residual(hh) for hh in F.split_batch(h, k)]
+
+    def front(self, objs_att, masks, z, objs):
         v = F.concat_channels(objs_att, z)
         assert self.c0.kernel_size == (1, 1) and self.c0.padding == (1, 1)
         u = F.linear(v, self.c0.weight.view(self.c0.out_channels, -1))   # c0 on the rank-1 tensor v (x) mask
@@ -186,8 +206,7 @@ class LayoutEncoder(nn.Module):
         if self.pool_to_8:
             assert h.shape[2] == 16, "AdaptiveAvgPool2d(8) is an exact 2x2 mean on the 16x16 map of the 128 px model"
             h = F.avg_pool2(h)
-        h = self.clstm(h, obj_to_img, plan=plan)
-        return self.residual(h)
+        return h
 
 
 class SPADE(nn.Module):
@@ -286,6 +305,7 @@ class Generator(nn.Module):
                  res128=False):
         super().__init__()
         self.obj_size = obj_size
+        self.batch_clstm = True        # one ConvLSTM pass for the three layout-encoder calls (LayoutEncoder.forward_many)
         self.crop_encoder = CropEncoder(z_dim=z_dim, class_num=num_embeddings)
         self.layout_encoder = LayoutEncoder(z_dim=z_dim, obj_att_dim=obj_att_dim, class_num=num_embeddings,
                                             clstm_layers=clstm_layers, pool_to_8=res128)
@@ -306,9 +326,13 @@ class Generator(nn.Module):
         z_rec, mu, logvar = self.crop_encoder(crops_input, objs, e[0])
         objs_att = self.attribute_encoder(objs, attribute)
         objs_att_est = self.attribute_encoder(objs, attribute_est)
-        h_rec = self.layout_encoder(objs_att_est, masks, obj_to_img, z_rec, objs, plan)
-        h_rand = self.layout_encoder(objs_att, masks, obj_to_img, z_rand, objs, plan)
-        h_shift = self.layout_encoder(objs_att, masks_shift, obj_to_img, z_rand, objs, plan)
+        if self.batch_clstm:
+            h_rec, h_rand, h_shift = self.layout_encoder.forward_many(
+                [(objs_att_est, masks, z_rec), (objs_att, masks, z_rand), (objs_att, masks_shift, z_rand)], obj_to_img, objs)
+        else:
+            h_rec = self.layout_encoder(objs_att_est, masks, obj_to_img, z_rec, objs, plan)
+            h_rand = self.layout_encoder(objs_att, masks, obj_to_img, z_rand, objs, plan)
+            h_shift = self.layout_encoder(objs_att, masks_shift, obj_to_img, z_rand, objs, plan)
         g_rec = self.global_encoder(h_rec)
         g_rand = self.global_encoder(h_rand)
         g_shift = self.global_encoder(h_shift)

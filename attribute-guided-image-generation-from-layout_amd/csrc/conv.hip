@@ -46,6 +46,7 @@ constexpr unsigned OOB = 0xFFFFFFF0u;   // byte offset past every buffer: the ha
 // ------------------------------------------------------------------ forward
 template <int KS>
 struct FwdProb {
+  static constexpr bool BIG_TILES = false;   // 256x128 / 128x256 tiles are instantiated for the weight gradient only
   static constexpr bool A_KFAST = true;   // weights: k contiguous
   static constexpr bool B_KFAST = false;  // im2col: pixels contiguous
   const float* x; const float* w; const float* bias; float* y;
@@ -112,6 +113,7 @@ struct FwdProb {
 // ------------------------------------------------------------------ backward data (and ConvTranspose forward)
 template <int KS, int S>
 struct BwdDataProb {
+  static constexpr bool BIG_TILES = false;
   static constexpr bool A_KFAST = false;
   static constexpr bool B_KFAST = false;
   static constexpr int TS = KS / S;  // taps per axis per phase
@@ -193,6 +195,7 @@ struct BwdDataProb {
 // ------------------------------------------------------------------ backward weight
 template <int KS>
 struct BwdWeightProb {
+  static constexpr bool BIG_TILES = true;
   static constexpr bool A_KFAST = true;  // reduction index r = (n,oh,ow) is the contiguous one
   static constexpr bool B_KFAST = true;
   const float* dy; const float* x; float* out;  // out: dw (splits==1) or slab base
@@ -546,8 +549,8 @@ int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, 
   } while (0)
   if (M <= 32) AGL_LAUNCH(32, 256);
   else if (M <= 64) AGL_LAUNCH(64, 128);
-  else if (big_tile == 1) AGL_LAUNCH(256, 128);
-  else if (big_tile == 2) AGL_LAUNCH(128, 256);
+  else if (big_tile == 1) { if constexpr (P::BIG_TILES) AGL_LAUNCH(256, 128); }
+  else if (big_tile == 2) { if constexpr (P::BIG_TILES) AGL_LAUNCH(128, 256); }
   else AGL_LAUNCH(128, 128);
 #undef AGL_LAUNCH
   AGL_CHECK_LAUNCH(name);

@@ -414,3 +414,39 @@ def test_layout_stage1_closed_form_equals_generic_kernels(res):
     names = ["y", "d obj_att", "d z", "d c2.weight", "d c0.weight", "d bn1.embed", "running_mean", "running_var"]
     for n, x, r in zip(names, results[0], results[1]):
         close(x, r, 2e-4 if n.startswith("d") else 2e-5, n)
+
+
+def test_batched_convlstm_equals_per_call():
+    """Generator.batch_clstm runs the ConvLSTM of the three layout-encoder calls as one batched recurrence; outputs,
+    gradients and BatchNorm running statistics must equal the call-by-call schedule (fp32 rounding only: the GEMM
+    splits differ with the batch)."""
+    from agl import synth
+    from agl.trainer import batch_to_device
+    bn = synth.make_batch(5, 64, seed=17, objs_per_image=[3, 1, 4, 2, 5])
+    b = batch_to_device(bn, DEV)
+    O = bn["objs"].shape[0]
+    gen = torch.Generator().manual_seed(3)
+    eps = [torch.randn(O, 64, generator=gen) for _ in range(3)]
+    res = []
+    for flag in (True, False):
+        G = build_nets(False)[0]
+        G.batch_clstm = flag
+        out = G(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"], b["masks_shift"],
+                b["boxes_shift"], b["attribute_est"], eps=eps)
+        loss = sum((o * o).mean() for o in out[4:7]) + out[9].sum() * 0.01
+        loss.backward()
+        res.append(([o.detach().clone() for o in out], {k: v.grad.detach().clone() for k, v in G.named_parameters() if v.grad is not None},
+                    {k: v.detach().clone() for k, v in G.state_dict().items()}))
+    (o1, g1, s1), (o2, g2, s2) = res
+    for a, r in zip(o1, o2):
+        close(a, r, 2e-5, "output")
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        a, r = g1[k].double(), g2[k].double()
+        # fp32 spread of this net: 1.5e-3; biases in front of a BatchNorm have a mathematically zero gradient (noise ~1e-8)
+        assert float((a - r).norm()) <= 2e-3 * float(r.norm()) + 1e-6, k
+    for k in s1:
+        if k.endswith(("running_mean", "running_var")):
+            close(s1[k], s2[k], 1e-5, k)
+        elif k.endswith("num_batches_tracked"):
+            assert int(s1[k]) == int(s2[k]), k
