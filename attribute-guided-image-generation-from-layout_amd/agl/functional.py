@@ -19,6 +19,18 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Tape of BatchNorm statistic updates (agl.generator's two-pass schedule): while BN_TAPE is a list, every training-mode
+# statistics call appends a closure that re-applies exactly the same running-statistics update (it re-runs the cheap
+# statistics kernel on the saved input), so a later pass can reuse the recorded activations and still advance the
+# running statistics as if the layers had been evaluated again.
+BN_TAPE = None
+
+
+def bn_tape_replay(tape):
+    for fn in tape:
+        fn()
+
+
 def _slot(p):
     """Gradient slot of a parameter owned by a flat arena (agl.flat.FlatParams marks them): backward kernels then
     accumulate straight into the arena and return None, instead of handing autograd a temporary that it adds to
@@ -121,6 +133,8 @@ class _NormAct(torch.autograd.Function):
         x = _c(x)
         if training:
             mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
+            if BN_TAPE is not None and rmean is not None:
+                BN_TAPE.append(lambda: L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt))
         else:
             mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
         p0c = _c(p0) if p0 is not None else None
@@ -394,9 +408,13 @@ class _LayoutStage1(torch.autograd.Function):
             mean, rstd = f(Cc), f(Cc)
         else:
             mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
-        L.call("agl_layout1_levels", L.ptr(u), L.ptr(masks), L.ptr(labels, torch.int64), L.ptr(table), L.ptr(area), L.ptr(mean),
-               L.ptr(rstd), L.ptr(A), L.ptr(B), L.ptr(D), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt, torch.int64), O, Cc, R, BN_EPS,
-               BN_MOMENTUM, int(training), L.stream())
+        def levels(area, mean, rstd, A, B, D):
+            L.call("agl_layout1_levels", L.ptr(u), L.ptr(masks), L.ptr(labels, torch.int64), L.ptr(table), L.ptr(area), L.ptr(mean),
+                   L.ptr(rstd), L.ptr(A), L.ptr(B), L.ptr(D), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt, torch.int64), O, Cc, R, BN_EPS,
+                   BN_MOMENTUM, int(training), L.stream())
+        levels(area, mean, rstd, A, B, D)
+        if training and BN_TAPE is not None and rmean is not None:      # replay into scratch outputs: only the running stats move
+            BN_TAPE.append(lambda: levels(f(O), f(Cc), f(Cc), f(O, Cc), f(O, Cc), f(O, Cc)))
         Wr = f(Co * 16, Cc, 1, 1)
         L.call("agl_layout1_permute", L.ptr(w2), L.ptr(Wr), Co, Cc, 1, L.stream())
         WB = L.conv2d_fwd(B.view(O, Cc, 1, 1), Wr)

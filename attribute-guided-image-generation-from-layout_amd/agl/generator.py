@@ -122,16 +122,23 @@ class CropEncoder(nn.Module):
         self.fc_logvar = A.Linear(d * 16, z_dim)
 
     def forward(self, imgs, objs=None, eps=None):
+        mu, logvar = self.trunk(imgs, objs)
+        return self.sample(mu, logvar, eps), mu, logvar
+
+    def trunk(self, imgs, objs=None):
+        """Everything up to (mu, logvar): independent of the random draw."""
         x = imgs
         for conv, bn in ((self.c1, self.bn1), (self.c2, self.bn2), (self.c3, self.bn3), (self.c4, self.bn4),
                          (self.conv5, self.bn5)):
             x = bn(conv(x), objs, relu=True)
         x = F.sum_hw(x, False, 1.0 / (x.shape[2] * x.shape[3]))
-        mu, logvar = self.fc_mu(x), self.fc_logvar(x)
+        return self.fc_mu(x), self.fc_logvar(x)
+
+    @staticmethod
+    def sample(mu, logvar, eps=None):
         if eps is None:
             eps = get_z_random(mu.size(0), mu.size(1))
-        z = F.reparameterize(mu, logvar, eps.to(mu.device))
-        return z, mu, logvar
+        return F.reparameterize(mu, logvar, eps.to(mu.device))
 
 
 class GlobalEncoder(nn.Module):
@@ -316,33 +323,66 @@ class Generator(nn.Module):
 
     def forward(self, imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est,
                 eps: Optional[Sequence[torch.Tensor]] = None):
+        sh = self.part_a(imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est)
+        e = self.draw_eps(sh, eps)
+        rec = self.part_rec(sh, e[0])
+        self.part_b(sh)
+        return self.outputs(sh, rec, e)
+
+    # The forward pass in four parts.  Only part_rec and the two re-parameterisations of `outputs` depend on the random
+    # draws eps; part_a and part_b depend on the inputs and the weights alone.  A training iteration evaluates the
+    # generator twice with unchanged weights (train64.py:195 and :280), so agl.trainer evaluates part_a / part_b once,
+    # keeps their graph, and runs part_rec twice.  Per BatchNorm layer the order of batches (rec, rand, shift) is the
+    # reference's in either schedule.
+    def part_a(self, imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est):
         A._need_device(imgs)
         dev = imgs.device
-        e = list(eps) if eps is not None else [None, None, None]
-        o2i_dev = obj_to_img.to(dev)
-        plan = SequencePlan(obj_to_img, dev)
-        s = self.obj_size
-        crops_input = F.crop_boxes(imgs, boxes, o2i_dev, s)
-        z_rec, mu, logvar = self.crop_encoder(crops_input, objs, e[0])
-        objs_att = self.attribute_encoder(objs, attribute)
-        objs_att_est = self.attribute_encoder(objs, attribute_est)
+        sh = dict(imgs=imgs, objs=objs, boxes=boxes, masks=masks, obj_to_img=obj_to_img, z_rand=z_rand,
+                  masks_shift=masks_shift, boxes_shift=boxes_shift, o2i_dev=obj_to_img.to(dev),
+                  plan=SequencePlan(obj_to_img, dev))
+        sh["crops_input"] = F.crop_boxes(imgs, boxes, sh["o2i_dev"], self.obj_size)
+        sh["mu"], sh["logvar"] = self.crop_encoder.trunk(sh["crops_input"], objs)
+        sh["objs_att"] = self.attribute_encoder(objs, attribute)
+        sh["objs_att_est"] = self.attribute_encoder(objs, attribute_est)
+        return sh
+
+    @staticmethod
+    def draw_eps(sh, eps=None):
+        """The three crop-encoder draws of one forward pass, in the reference's order (CPU generator)."""
+        if eps is not None:
+            return list(eps)
+        O, zd = sh["mu"].shape
+        return [get_z_random(O, zd) for _ in range(3)]
+
+    def part_rec(self, sh, eps0):
+        z_rec = self.crop_encoder.sample(sh["mu"], sh["logvar"], eps0)
+        h_rec = self.layout_encoder(sh["objs_att_est"], sh["masks"], sh["obj_to_img"], z_rec, sh["objs"], sh["plan"])
+        img_rec = self.decoder(h_rec, self.global_encoder(h_rec))
+        crops_input_rec = F.crop_boxes(img_rec, sh["boxes"], sh["o2i_dev"], self.obj_size)
+        return img_rec, crops_input_rec
+
+    def part_b(self, sh):
+        objs, o2i = sh["objs"], sh["obj_to_img"]
+        calls = [(sh["objs_att"], sh["masks"], sh["z_rand"]), (sh["objs_att"], sh["masks_shift"], sh["z_rand"])]
         if self.batch_clstm:
-            h_rec, h_rand, h_shift = self.layout_encoder.forward_many(
-                [(objs_att_est, masks, z_rec), (objs_att, masks, z_rand), (objs_att, masks_shift, z_rand)], obj_to_img, objs)
+            h_rand, h_shift = self.layout_encoder.forward_many(calls, o2i, objs)
         else:
-            h_rec = self.layout_encoder(objs_att_est, masks, obj_to_img, z_rec, objs, plan)
-            h_rand = self.layout_encoder(objs_att, masks, obj_to_img, z_rand, objs, plan)
-            h_shift = self.layout_encoder(objs_att, masks_shift, obj_to_img, z_rand, objs, plan)
-        g_rec = self.global_encoder(h_rec)
+            h_rand, h_shift = [self.layout_encoder(a, m, o2i, z, objs, sh["plan"]) for (a, m, z) in calls]
         g_rand = self.global_encoder(h_rand)
         g_shift = self.global_encoder(h_shift)
-        img_rec = self.decoder(h_rec, g_rec)
-        img_rand = self.decoder(h_rand, g_rand)
-        img_shift = self.decoder(h_shift, g_shift)
-        crops_rand = F.crop_boxes(img_rand, boxes, o2i_dev, s)
-        _, z_rand_rec, _ = self.crop_encoder(crops_rand, objs, e[1])
-        crops_input_rec = F.crop_boxes(img_rec, boxes, o2i_dev, s)
-        crops_shift = F.crop_boxes(img_shift, boxes_shift, o2i_dev, s)
-        _, z_rand_shift, _ = self.crop_encoder(crops_shift, objs, e[2])
-        return (crops_input, crops_input_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift, mu, logvar,
-                z_rand_rec, z_rand_shift)
+        sh["img_rand"] = self.decoder(h_rand, g_rand)
+        sh["img_shift"] = self.decoder(h_shift, g_shift)
+        s = self.obj_size
+        sh["crops_rand"] = F.crop_boxes(sh["img_rand"], sh["boxes"], sh["o2i_dev"], s)
+        sh["mu_rand"], sh["lv_rand"] = self.crop_encoder.trunk(sh["crops_rand"], objs)
+        sh["crops_shift"] = F.crop_boxes(sh["img_shift"], sh["boxes_shift"], sh["o2i_dev"], s)
+        sh["mu_shift"], sh["lv_shift"] = self.crop_encoder.trunk(sh["crops_shift"], objs)
+        return sh
+
+    def outputs(self, sh, rec, eps):
+        # The reference keeps the SECOND value the crop encoder returns (`_, z_rand_rec, _ = self.crop_encoder(...)`,
+        # generator_obj_att.py:639,644), i.e. mu — the samples drawn with eps[1], eps[2] are discarded there (the draws
+        # are still consumed from the CPU generator, which draw_eps reproduces).
+        img_rec, crops_input_rec = rec
+        return (sh["crops_input"], crops_input_rec, sh["crops_rand"], sh["crops_shift"], img_rec, sh["img_rand"],
+                sh["img_shift"], sh["mu"], sh["logvar"], sh["mu_rand"], sh["mu_shift"])

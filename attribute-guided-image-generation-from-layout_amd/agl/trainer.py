@@ -4,8 +4,12 @@ is the same with the 128 px modules).  See SURVEY.md §8(H).
 
 What is kept exactly: the order of network calls (so BatchNorm running statistics and spectral-norm
 u/v advance identically), the loss set and weights, Adam(2e-4, (.5,.999)) on all four networks.
-Legal savings taken: the D-step generator forward builds no autograd graph (all its outputs are
-detached in the reference, :195-240); D weight gradients are not computed in the G step (the
+Legal savings taken: the generator is evaluated twice per iteration with unchanged weights (:195 and :280) and only
+the reconstruction branch depends on the fresh random draws, so the draw-independent parts (crop-encoder trunks,
+attribute encoder, the `rand` and `shift` branches) are evaluated ONCE, their graph is kept across the D step, and
+the second evaluation recomputes the reconstruction branch only; the BatchNorm running statistics of the reused
+layers are advanced a second time by replaying their statistics kernels (agl.functional.BN_TAPE), in the
+reference's per-layer order.  The D-step reconstruction branch builds no autograd graph; D weight gradients are not computed in the G step (the
 reference zeroes them before use, :254-256); loss values/gradients come from fused kernels; the three
 D optimisers are one fused Adam launch over one flat arena (identical hyper-parameters and step count).
 Host data preparation (attribute estimate loop :162-166, attribute swap :170-188) is the batch
@@ -47,7 +51,7 @@ def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
 
 class Trainer:
     def __init__(self, netG, netD_image, netD_object, netD_att, pos_weight: torch.Tensor, *, lambdas: Optional[dict] = None,
-                 group=None, estimate_attributes: bool = False):
+                 group=None, estimate_attributes: bool = False, reuse_generator_pass: bool = True):
         self.netG, self.netDi, self.netDo, self.netDa = netG, netD_image, netD_object, netD_att
         dev = next(netG.parameters()).device
         if dev.type != "cuda":
@@ -67,6 +71,9 @@ class Trainer:
         # True: derive attribute_est on device from the pre-step D_att logits (train64.py:156-166);
         # False (default): take the batch's attribute_est (what the parity fixtures pin).
         self.estimate_attributes = estimate_attributes
+        # True: evaluate the draw-independent generator parts once per iteration (see the module docstring);
+        # False: two full generator evaluations like the reference loop (A/B tests).
+        self.reuse_generator_pass = reuse_generator_pass
         self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
         self._d_ready = None
         self._g_ready = None
@@ -81,6 +88,38 @@ class Trainer:
     def _gen(self, b, eps):
         return self.netG(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
                          b["masks_shift"], b["boxes_shift"], b["attribute_est"], eps=eps)
+
+    def _gen_first(self, b, eps):
+        """First generator evaluation of the iteration: draw-independent parts with a graph and a BatchNorm tape,
+        the reconstruction branch without a graph.  Returns (outputs, state for _gen_second)."""
+        G = self.netG
+        tape_a, tape_b = [], []
+        try:
+            F.BN_TAPE = tape_a
+            sh = G.part_a(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                          b["masks_shift"], b["boxes_shift"], b["attribute_est"])
+            F.BN_TAPE = None
+            e = G.draw_eps(sh, eps)
+            with torch.no_grad():
+                rec = G.part_rec(sh, e[0])
+            F.BN_TAPE = tape_b
+            G.part_b(sh)
+        finally:
+            F.BN_TAPE = None
+        with torch.no_grad():
+            out = G.outputs(sh, rec, e)
+        return tuple(t.detach() for t in out), (sh, tape_a, tape_b)
+
+    def _gen_second(self, state, eps):
+        """Second evaluation: the recorded layers advance their running statistics again (same batches), the
+        reconstruction branch is recomputed with the new draws, this time with a graph."""
+        G = self.netG
+        sh, tape_a, tape_b = state
+        e = G.draw_eps(sh, eps)
+        F.bn_tape_replay(tape_a)          # crop-encoder trunk on the real crops, attribute encoder
+        rec = G.part_rec(sh, e[0])
+        F.bn_tape_replay(tape_b)          # rand / shift branches and the two crop-encoder trunks after them
+        return G.outputs(sh, rec, e)
 
     def _reduce_and_step(self, flat: FlatParams):
         """All-reduce the arena's gradients (side stream) and apply Adam there; returns the event the main
@@ -125,8 +164,12 @@ class Trainer:
         self._g_ready = None
 
         # ---- D step (train64.py:191-262)
-        with torch.no_grad():
-            out = self._gen(b, eps_d)
+        gen_state = None
+        if self.reuse_generator_pass and self.netG.training:
+            out, gen_state = self._gen_first(b, eps_d)
+        else:
+            with torch.no_grad():
+                out = self._gen(b, eps_d)
         crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift = out[:7]
         self.flat_d.zero_grad()
         heads, grads = [], []
@@ -156,7 +199,9 @@ class Trainer:
         # ---- G step (train64.py:280-370)
         self.flat_d.set_requires_grad(False)
         try:
-            out = self._gen(b, eps_g)           # overlaps the D all-reduce + Adam (side stream)
+            # (overlaps the D all-reduce + Adam on the side stream)
+            out = self._gen_second(gen_state, eps_g) if gen_state is not None else self._gen(b, eps_g)
+            gen_state = None
             (crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift,
              mu, logvar, z_rand_rec, z_rand_shift) = out
             self._wait(self._d_ready)

@@ -450,3 +450,41 @@ def test_batched_convlstm_equals_per_call():
             close(s1[k], s2[k], 1e-5, k)
         elif k.endswith("num_batches_tracked"):
             assert int(s1[k]) == int(s2[k]), k
+
+
+def test_generator_pass_reuse_equals_two_full_passes():
+    """Trainer(reuse_generator_pass=True) evaluates the draw-independent generator parts once per iteration and
+    replays the BatchNorm statistics of the reused layers; it must match the plain schedule (two full generator
+    passes).  After the FIRST iteration both schedules ran on identical weights: losses and every BatchNorm running
+    statistic / counter must agree to rounding.  After the second, weights differ by Adam sign flips of noise-level
+    gradients (2*lr per element and step), so the comparison is at that granularity."""
+    from agl import synth
+    from agl.trainer import Trainer, batch_to_device
+    pw = torch.from_numpy(synth.make_pos_weight())
+    bn = synth.make_batch(4, 64, seed=31, objs_per_image=[3, 2, 4, 1])
+    b = batch_to_device(bn, DEV)
+    O = bn["objs"].shape[0]
+    gen = torch.Generator().manual_seed(12)
+    eps = [[torch.randn(O, 64, generator=gen) for _ in range(3)] for _ in range(4)]
+    runs = []
+    for flag in (True, False):
+        nets = build_nets(False)
+        tr = Trainer(*nets, pw, reuse_generator_pass=flag)
+        snaps = []
+        for it in range(2):
+            tr.step(b, eps[2 * it], eps[2 * it + 1])
+            tr.finish()
+            snaps.append((tr.loss_dict(), [{k: v.detach().cpu().clone() for k, v in n.state_dict().items()} for n in nets]))
+        runs.append(snaps)
+    for it, (stat_tol, w_tol) in enumerate(((1e-5, 4.1e-4), (2e-3, 8.2e-4))):
+        (l1, s1), (l2, s2) = runs[0][it], runs[1][it]
+        for k, v in l2.items():
+            assert abs(l1[k] - v) <= (2e-5 if it == 0 else 2e-4) * max(1.0, abs(v)), (it, k, l1[k], v)
+        for a, r in zip(s1, s2):
+            for k in r:
+                if k.endswith("num_batches_tracked"):
+                    assert int(a[k]) == int(r[k]), (it, k)
+                elif k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+                    close(a[k], r[k], stat_tol, f"iteration {it}: {k}")
+                else:
+                    assert float((a[k].double() - r[k].double()).abs().max()) <= w_tol + 1e-5 * float(r[k].abs().max()), (it, k)
