@@ -490,6 +490,16 @@ __global__ void slab_reduce(const float* __restrict__ slabs, float* __restrict__
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// dw[co][ci][kh][kw] (+)= t[ci][co][ks-1-kh][ks-1-kw]
+__global__ void flip_transpose_w(const float* __restrict__ t, float* __restrict__ dw, int Cout, int Cin, int ks, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kk = ks * ks;
+  if (i >= (long)Cout * Cin * kk) return;
+  const int tap = (int)(i % kk), ci = (int)(i / kk % Cin), co = (int)(i / ((long)kk * Cin));
+  const float v = t[((long)ci * Cout + co) * kk + (kk - 1 - tap)];
+  dw[i] = accumulate ? dw[i] + v : v;
+}
+
 // out[o] = epilogue(sum_z part[z][o]); channel of o = (o / HW) % C
 __global__ void splitk_epilogue(const float* __restrict__ part, float* __restrict__ out, long n, int splits, int HW, int C,
                                 const float* __restrict__ bias, const float* __restrict__ pos_mask, int accumulate, int relu) {
@@ -505,9 +515,9 @@ __global__ void splitk_epilogue(const float* __restrict__ part, float* __restric
 }
 
 // Reduction splits for the forward / input-gradient passes.  Two reasons to cut K: (1) the output grid alone cannot
-// fill the chip (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails); (2) wave quantisation — with 3
-// resident workgroups per CU there are 768 slots, and e.g. 788 tiles cost two full rounds; s-way splitting turns that
-// into ceil(788 s / 768) rounds of 1/s the length.  A small cost model picks s: rounds x per-round time + the slab
+// fill the chip (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails); (2) wave quantisation — with 4
+// resident workgroups per CU there are 1024 slots, and e.g. 1050 tiles cost two full rounds; s-way splitting turns that
+// into ceil(1050 s / 1024) rounds of 1/s the length.  A small cost model picks s: rounds x per-round time + the slab
 // traffic of the deterministic split (s writes + s reads of the output).
 static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
@@ -560,59 +570,86 @@ int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, 
 // ------------------------------------------------------------------ few-output-channel direct convolution
 // Convolutions with <= 4 output channels (decoder c4/c7: 64->3 k7; and the input gradients of the 3-channel first
 // layers: CropEncoder.c1, OptimizedBlock.resi[0], decoder.c5) would waste 29 of 32 MFMA rows and re-gather every
-// tap from HBM.  Here a workgroup owns a 16x16 output tile of one image, stages each input channel's
-// (16+ks-1)^2 patch in LDS once and accumulates the <= 4 outputs per pixel on the VALU; the filter taps are
-// wave-uniform (scalar loads).  The weight tensor is addressed by strides so the same kernel evaluates the
-// input-gradient form (flipped taps, channel roles swapped).  Stride 1 only.
-template <int KS>
+// tap from HBM.  Here a workgroup owns a TY x (4*TXT) output tile of one image (16x64, or 32x32 on narrow maps), stages
+// CB input channels' patches in LDS and accumulates on the VALU.  Each thread owns FOUR horizontally adjacent pixels:
+// one row segment of 4+ks-1 patch values (16-byte LDS reads) feeds 4*ks*Cout FMAs, so the kernel is FMA-bound rather
+// than LDS-bound (one value per 3 FMAs with a pixel per thread: 9.6 TFLOP/s).  Filter taps are wave-uniform scalar
+// loads.  The weight tensor is addressed by strides so the same kernel evaluates the input-gradient form (flipped
+// taps, channel roles swapped).  Stride 1 only.
+template <int KS, int TXT>
 __global__ __launch_bounds__(256) void small_cout_conv(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ pos_mask,
                                                        float* __restrict__ y, int Cin, int H, int W, int Cout, int OH, int OW,
                                                        int pad, int s_co, int s_ci, int flip, int relu, int accumulate) {
-  constexpr int T = 16, P = T + KS - 1, CB = 4;
-  __shared__ float patch[CB][P * P];
-  const int tiles_x = (OW + T - 1) / T;
-  const int n = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * T, tx0 = (blockIdx.x % tiles_x) * T;
-  const int tx = threadIdx.x % T, ty = threadIdx.x / T;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int PX = 4, TX = TXT * PX, TY = 256 / TXT, CB = 4;
+  constexpr int PH = TY + KS - 1, PWV = TX + KS - 1, PITCH = (PWV + 3) / 4 * 4, PS = PH * PITCH;
+  constexpr int SEG = PX + KS - 1, SEGV = (SEG + 3) / 4;           // row segment a thread reads, in float4s
+  __shared__ __attribute__((aligned(16))) float patch[CB * PS + 4];
+  __shared__ __attribute__((aligned(16))) float wl[CB * KS * KS * 4];   // [c][tap][o padded to 4]: one 16-byte broadcast read per tap
+  const int tiles_x = (OW + TX - 1) / TX;
+  const int n = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * TY, tx0 = (blockIdx.x % tiles_x) * TX;
+  const int tx = threadIdx.x % TXT, ty = threadIdx.x / TXT;
+  float acc[4][PX];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int q = 0; q < PX; ++q) acc[o][q] = 0.f;
   const float* xn = x + (long)n * Cin * H * W;
   for (int c0 = 0; c0 < Cin; c0 += CB) {
     __syncthreads();
-    for (int e = threadIdx.x; e < CB * P * P; e += 256) {
-      const int c = e / (P * P), r = e - c * (P * P);
-      const int iy = ty0 - pad + r / P, ix = tx0 - pad + r % P;
+    for (int e = threadIdx.x; e < CB * PH * PWV; e += 256) {
+      const int c = e / (PH * PWV), r = e - c * (PH * PWV), py = r / PWV, pxx = r - py * PWV;
+      const int iy = ty0 - pad + py, ix = tx0 - pad + pxx;
       float v = 0.f;
       if (c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[(long)(c0 + c) * H * W + (long)iy * W + ix];
-      patch[c][r] = v;
+      patch[c * PS + py * PITCH + pxx] = v;
+    }
+    for (int e = threadIdx.x; e < CB * KS * KS * 4; e += 256) {
+      const int c = e / (KS * KS * 4), t = (e >> 2) % (KS * KS), o = e & 3;
+      const int tap = flip ? KS * KS - 1 - t : t;
+      wl[e] = (c0 + c < Cin && o < Cout) ? w[(long)(c0 + c) * s_ci + (long)o * s_co + tap] : 0.f;
     }
     __syncthreads();
     const int cn = min(CB, Cin - c0);
     for (int c = 0; c < cn; ++c) {
-      const float* wc = w + (long)(c0 + c) * s_ci;
 #pragma unroll
-      for (int kh = 0; kh < KS; ++kh)
+      for (int kh = 0; kh < KS; ++kh) {
+        float seg[SEGV * 4];
+        const float4* row = reinterpret_cast<const float4*>(patch + c * PS + (ty + kh) * PITCH + PX * tx);
+#pragma unroll
+        for (int v4 = 0; v4 < SEGV; ++v4) {
+          const float4 t = row[v4];
+          seg[4 * v4 + 0] = t.x; seg[4 * v4 + 1] = t.y; seg[4 * v4 + 2] = t.z; seg[4 * v4 + 3] = t.w;
+        }
 #pragma unroll
         for (int kw = 0; kw < KS; ++kw) {
-          const float v = patch[c][(ty + kh) * P + tx + kw];
-          const int t = flip ? (KS - 1 - kh) * KS + (KS - 1 - kw) : kh * KS + kw;
+          const float4 w4 = *reinterpret_cast<const float4*>(wl + ((c * KS + kh) * KS + kw) * 4);
+          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-          for (int o = 0; o < 4; ++o)
-            if (o < Cout) acc[o] = fmaf(v, wc[(long)o * s_co + t], acc[o]);
+          for (int o = 0; o < 4; ++o)       // all four lanes of outputs: rows o >= Cout of wl are zero (no branch in the hot loop)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) acc[o][q] = fmaf(seg[q + kw], wv[o], acc[o][q]);
         }
+      }
     }
   }
-  const int oy = ty0 + ty, ox = tx0 + tx;
-  if (oy < OH && ox < OW) {
+  const int oy = ty0 + ty;
+  if (oy < OH) {
 #pragma unroll
     for (int o = 0; o < 4; ++o)
       if (o < Cout) {
-        const long idx = ((long)n * Cout + o) * OH * OW + (long)oy * OW + ox;
-        float v = acc[o];
-        if (bias) v += bias[o];
-        if (pos_mask && !(pos_mask[idx] > 0.f)) v = 0.f;
-        if (accumulate) v += y[idx];
-        if (relu) v = fmaxf(v, 0.f);
-        y[idx] = v;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+          const int ox = tx0 + PX * tx + q;
+          if (ox >= OW) continue;
+          const long idx = ((long)n * Cout + o) * OH * OW + (long)oy * OW + ox;
+          float v = acc[o][q];
+          if (bias) v += bias[o];
+          if (pos_mask && !(pos_mask[idx] > 0.f)) v = 0.f;
+          if (accumulate) v += y[idx];
+          if (relu) v = fmaxf(v, 0.f);
+          y[idx] = v;
+        }
       }
   }
 }
@@ -621,9 +658,15 @@ int launch_small_cout(const float* x, const float* w, const float* bias, const f
                       int W, int Cout, int ks, int pad, int s_co, int s_ci, int flip, int relu, int accumulate, hipStream_t st,
                       const char* name) {
   const int OH = H + 2 * pad - ks + 1, OW = W + 2 * pad - ks + 1;
-  dim3 g(agl_cdiv(OH, 16) * agl_cdiv(OW, 16), N);
-#define AGL_SC(KS_) case KS_: hipLaunchKernelGGL((small_cout_conv<KS_>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, \
-                                                 Cout, OH, OW, pad, s_co, s_ci, flip, relu, accumulate); break;
+  const bool wide = OW > 32;                       // 16 x 64 tiles on wide maps, 32 x 32 otherwise
+  dim3 g(wide ? agl_cdiv(OH, 16) * agl_cdiv(OW, 64) : agl_cdiv(OH, 32) * agl_cdiv(OW, 32), N);
+#define AGL_SC(KS_)                                                                                                        \
+  case KS_:                                                                                                                \
+    if (wide) hipLaunchKernelGGL((small_cout_conv<KS_, 16>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, Cout, OH, OW, \
+                                 pad, s_co, s_ci, flip, relu, accumulate);                                                 \
+    else hipLaunchKernelGGL((small_cout_conv<KS_, 8>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, Cout, OH, OW, pad,  \
+                            s_co, s_ci, flip, relu, accumulate);                                                           \
+    break;
   switch (ks) { AGL_SC(1) AGL_SC(3) AGL_SC(4) AGL_SC(5) AGL_SC(7) default: return AGL_ERR_ARG; }
 #undef AGL_SC
   AGL_CHECK_LAUNCH(name);
@@ -1007,7 +1050,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
 }
 
 // Number of reduction splits for bwd-weight and the (BK-aligned) reduction length of each; every split z < splits owns
-// a non-empty range [z*per, min(R,(z+1)*per)).  Same quantisation-aware cost model as fwd_splits (768 slots).
+// a non-empty range [z*per, min(R,(z+1)*per)).  Same quantisation-aware cost model as fwd_splits.
 // Weight-gradient GEMMs use a 256x128 (Cout multiple of 256) or 128x256 (Cout <= 128) tile where it fits (2 workgroups
 // per CU, 8 accumulators per wave): both operands are long streams there and the larger tile moves 25 % fewer bytes per
 // FLOP through LDS (+8-16 % measured); forward and input-gradient passes measured no gain (or a loss) and stay on 128x128.
@@ -1042,7 +1085,28 @@ static int bww_splits(int Cout, long Nc, long R, long* per_out) {
   return (int)s;
 }
 
+// Weight gradients of convolutions with <= 4 output channels (decoder c4 / c7) would use 3 of 32 MFMA rows.  With the
+// operand roles swapped — dw[co][ci][kh][kw] = dw'[ci][co][ks-1-kh][ks-1-kw], where dw' is the weight gradient of the
+// convolution that maps dy (as input, pad ks-1-pad) to x (as output gradient) — the GEMM has M = Cin rows instead.
+static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
+  return Cout <= 4 && Cin >= 32 && stride == 1 && up == 0 && !in_relu;
+}
+
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
+  if (bww_swapped(Cin, Cout, 1, 0, 0)) {     // (upper bound: the entry point decides with the real stride / flags)
+    long inner = 0;                                  // the input extent depends on the padding: cover every legal one
+    for (int pad = 0; pad < ks; ++pad) {
+      const int H = OH + ks - 1 - 2 * pad, W = OW + ks - 1 - 2 * pad;
+      if (H <= 0 || W <= 0) break;
+      const long need = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
+      if (need > inner) inner = need;
+    }
+    long Nc0 = (long)Cin * ks * ks, R0 = (long)N * OH * OW;
+    int s0 = bww_splits(Cout, Nc0, R0, nullptr);
+    const long plain = s0 > 1 ? (long)s0 * Cout * Nc0 * 4 : 0;
+    const long swapped = inner + (long)Cin * Cout * ks * ks * 4;
+    return swapped > plain ? swapped : plain;
+  }
   long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
   int s = bww_splits(Cout, Nc, R, nullptr);
   return s > 1 ? (long)s * Cout * Nc * 4 : 0;
@@ -1055,6 +1119,22 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (bww_swapped(Cin, Cout, stride, up_log2, in_relu)) {
+    const long inner = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
+    const long tmp_bytes = (long)Cin * Cout * ks * ks * 4;
+    if (!ws || ws_bytes < inner + tmp_bytes) {
+      agl_set_error("agl_conv2d_bwd_weight: workspace too small (%ld < %ld)", ws_bytes, inner + tmp_bytes);
+      return AGL_ERR_WORKSPACE;
+    }
+    float* tmp = (float*)((char*)ws + inner);
+    int rc = agl_conv2d_bwd_weight(x, dy, tmp, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, stream);
+    if (rc != AGL_OK) return rc;
+    const long n = (long)Cout * Cin * ks * ks;
+    hipLaunchKernelGGL(flip_transpose_w, dim3(agl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dw, Cout, Cin, ks,
+                       accumulate);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(flip)");
+    return AGL_OK;
+  }
   const long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
   long per = 0;
   const int splits = bww_splits(Cout, Nc, R, &per);

@@ -281,8 +281,13 @@ def test_second_step_lockstep_vs_oracle():
         close(a, r, 1e-3, "G output, second step")
     for net, P in ((G, ob.Pg), (Di, ob.Pi), (Do, ob.Po), (Da, ob.Pa)):
         for k, v in net.state_dict().items():
-            if k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+            if k.endswith(("running_mean", "running_var")):
                 close(v, P[k], 2e-4, k)
+            elif k.endswith(("weight_u", "weight_v")):
+                # the G-step power iterations run on D weights that Adam updated inside this iteration: an element whose
+                # gradient is at rounding-noise level moves by +-lr in either implementation (2*lr = 4e-4 apart), which
+                # shows up at ~4e-4 relative-to-max in u/v (seen 1 run in 6); a wrong power iteration is an O(1) error
+                close(v, P[k], 2e-3, k)
             elif not v.is_floating_point():
                 assert int(v) == int(P[k]), k
 

@@ -340,7 +340,8 @@ def test_patch_conv_upsampled_input_and_addend():
         close(a, r, 1e-4, "patch up+addend " + n)
 
 
-@pytest.mark.parametrize("shape", [(393, 64, 66, 128, 4, 2, 1), (393, 512, 8, 512, 5, 1, 2), (64, 128, 64, 128, 3, 1, 1), (393, 256, 8, 512, 3, 1, 1)])
+@pytest.mark.parametrize("shape", [(393, 64, 66, 128, 4, 2, 1), (393, 512, 8, 512, 5, 1, 2), (64, 128, 64, 128, 3, 1, 1), (393, 256, 8, 512, 3, 1, 1),
+                                   (64, 64, 64, 3, 7, 1, 3), (32, 128, 128, 3, 7, 1, 3), (393, 3, 32, 64, 7, 1, 3)])
 def test_conv_adjoint_identities_at_full_size(shape):
     """Oracle-free properties at BASELINE config-2 sizes (batch 64 / 393 objects): the three convolution passes are
     mutually adjoint — <conv(x,w), g> = <x, bwd_data(g,w)> = <w, bwd_weight(g,x)> — and the forward pass is linear."""
