@@ -25,6 +25,8 @@ SIGNATURES = {
     "agl_set_conv_precision": (_I, [_I]),
     "agl_get_conv_precision": (_I, []),
     "agl_set_conv_patch": (_I, [_I]),
+    "agl_set_conv_pos": (_I, [_I]),
+    "agl_conv2d_fwd_ws_bytes": (_L, [_I] * 9),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
     "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
     "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
@@ -196,7 +198,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
         out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
     else:
         assert tuple(out.shape) == (N, Cout, OH, OW)
-    need = load().agl_conv2d_splitk_ws_bytes(Cout, N * OH * OW, 1, Cin * ks * ks, out.numel())
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
     call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
@@ -216,6 +218,8 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     tpa = ks // stride
     need = load().agl_conv2d_splitk_ws_bytes(Cin, N * (-(-IH // stride)) * (-(-IW // stride)), stride * stride,
                                              Cout * tpa * tpa, out.numel())
+    if stride == 1 and (IH, IW) == (OH, OW):      # position-major path on small maps (forward form with flipped taps)
+        need = max(need, load().agl_conv2d_fwd_ws_bytes(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0))
     ws = workspace(need, dy.device) if need else None
     call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), stream())

@@ -16,6 +16,7 @@
 // the staging writes and the 32-lane fragment reads stay (nearly) bank-conflict free.
 #include "agl_internal.h"
 #include <math.h>
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -61,6 +62,7 @@ struct FwdProb {
     if (splits > 1) { kbeg = z * per_split; kend = min(K, kbeg + per_split); part += (long)z * slab; }
     return kbeg < kend;
   }
+  __device__ void tile(int, int) {}
   __device__ const float* a_ptr() const { return w; }
   __device__ const float* b_ptr() const { return x; }
   __device__ float fix_a(float v) const { return v; }
@@ -135,6 +137,7 @@ struct BwdDataProb {
     if (splits > 1) { kbeg = sp * per_split; kend = min(kend, kbeg + per_split); part += (long)sp * slab; }
     return Nc > 0 && kbeg < kend;
   }
+  __device__ void tile(int, int) {}
   __device__ const float* a_ptr() const { return w; }
   __device__ const float* b_ptr() const { return dy; }
   __device__ float fix_a(float v) const { return v; }
@@ -210,6 +213,7 @@ struct BwdWeightProb {
     out += (long)z * slab;
     return kbeg < kend;
   }
+  __device__ void tile(int, int) {}
   __device__ const float* a_ptr() const { return dy; }
   __device__ const float* b_ptr() const { return x; }
   __device__ float fix_a(float v) const { return v; }
@@ -248,6 +252,225 @@ struct BwdWeightProb {
     if (m < M && c.ok) out[(long)m * Nc + c.n] = v;
   }
 };
+
+// ------------------------------------------------------------------ position-major forward (small maps)
+// On 4x4 / 8x8 maps a large share of the im2col taps multiply padding (5x5 pad 2 on 8x8: 28 %; 4x4 stride 2 on
+// 4x4 -> 2x2: 44 %).  With the operands transposed to position-major form — Xt[pos][ci][img], Wt[tap][co][ci],
+// Yt[q][co][img] — the convolution is, per output position q, a sum of PLAIN matrix products over the taps that fall
+// inside the map:  Yt[q] = sum_{tap valid for q} Wt[tap] * Xt[pos(q,tap)],  so a GEMM column tile (128 images at one
+// position) simply never visits the padded taps.  The valid taps of a position form a rectangle
+// [kh_lo..kh_hi] x [kw_lo..kw_hi]; the reduction index is k = (tap_index, ci).  The transposes cost two passes over
+// tensors that are tiny at these map sizes.
+template <int KS>
+struct PosFwdProb {
+  static constexpr bool BIG_TILES = false;
+  static constexpr bool A_KFAST = true;   // Wt: ci contiguous
+  static constexpr bool B_KFAST = false;  // Xt: images contiguous
+  const float* xt; const float* wt; const float* bias; float* yt;
+  int N, Cin, cin_shift, H, W, Cout, OH, OW, stride, pad, relu;
+  int M, Nc, kbeg, kend;            // Nc = Q * N: GEMM columns are (position, image), position-major
+  int sp, kh_lo, kw_lo, nkw, inv_nkw;
+  unsigned a_bytes, b_bytes;
+  int splits; long slab; float* part;
+
+  __device__ bool setup(int bz) {
+    sp = bz;
+    if (splits > 1) part += (long)sp * slab;
+    return true;
+  }
+  // A column tile covers one output position, or the tail of one and the head of the next (N is not a multiple of the
+  // tile width): its taps are the bounding rectangle of those positions' valid taps; a lane whose own position lacks a
+  // tap of the rectangle reads zero (out-of-range offset).
+  __device__ void tile(int bn0, int bn) {
+    const int q_lo = bn0 / N, q_hi = (min(bn0 + bn, Nc) - 1) / N;
+    int kh_hi = -1, kw_hi = -1;
+    kh_lo = KS; kw_lo = KS;
+    for (int q = q_lo; q <= q_hi; ++q) {
+      const int oh = q / OW, ow = q - oh * OW, ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+      kh_lo = min(kh_lo, max(0, -ih0)); kh_hi = max(kh_hi, min(KS - 1, H - 1 - ih0));
+      kw_lo = min(kw_lo, max(0, -iw0)); kw_hi = max(kw_hi, min(KS - 1, W - 1 - iw0));
+    }
+    nkw = kw_hi - kw_lo + 1;
+    inv_nkw = 65536 / nkw + 1;                       // j / nkw == (j * inv_nkw) >> 16 for j < 64
+    const int Kq = (kh_hi - kh_lo + 1) * nkw * Cin;
+    const int per = ((Kq + splits - 1) / splits + BK - 1) / BK * BK;
+    kbeg = sp * per; kend = min(Kq, kbeg + per);
+    if (kend < kbeg) kend = kbeg;                    // an empty split still stores its (zero) slab
+  }
+  __device__ const float* a_ptr() const { return wt; }
+  __device__ const float* b_ptr() const { return xt; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return v; }
+  __device__ void decode(int k, int& ci, int& kh, int& kw) const {
+    const int j = k >> cin_shift;
+    ci = k - (j << cin_shift);
+    const int th = (j * inv_nkw) >> 16;
+    kh = kh_lo + th; kw = kw_lo + j - th * nkw;
+  }
+  struct RowA { int base; bool ok; };
+  struct KA { int off; bool ok; };
+  __device__ RowA row_a(int m) const { return {m * Cin, m < M}; }
+  __device__ KA k_a(int k) const {
+    KA s; s.ok = k < kend; int ci, kh, kw;
+    decode(s.ok ? k : 0, ci, kh, kw);
+    s.off = (kh * KS + kw) * Cout * Cin + ci; return s;
+  }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(r.base + k.off) * 4u : OOB; }
+  struct RowB { int img, ih0, iw0; bool ok; };
+  struct KB { int coff, kh, kw; bool ok; };
+  __device__ RowB row_b(int n) const {
+    RowB r; r.ok = n < Nc;
+    const int nn = r.ok ? n : 0, q = nn / N, oh = q / OW, ow = q - oh * OW;
+    r.img = nn - q * N; r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
+    return r;
+  }
+  __device__ KB k_b(int k) const {
+    KB s; s.ok = k < kend; int ci;
+    decode(s.ok ? k : 0, ci, s.kh, s.kw);
+    s.coff = ci * N; return s;
+  }
+  __device__ unsigned off_b(const RowB& r, const KB& k) const {
+    const int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
+    const bool ok = r.ok & k.ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+    return ok ? (unsigned)((ih * W + iw) * Cin * N + k.coff + r.img) * 4u : OOB;
+  }
+  struct Col { long off; bool ok; };
+  __device__ Col col(int n) const {
+    Col c; c.ok = n < Nc;
+    const int nn = c.ok ? n : 0, q = nn / N;
+    c.off = (long)q * Cout * N + (nn - q * N); return c;
+  }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) {
+      const long o = c.off + (long)m * N;
+      if (splits > 1) { part[o] = v; return; }
+      if (bias) v += bias[m];
+      if (relu) v = fmaxf(v, 0.f);
+      yt[o] = v;
+    }
+  }
+};
+
+// Weight gradient in position-major form: per tap, dWt[tap] = sum over the output positions q whose tap falls inside
+// the map of dYt[q] * Xt[pos(q,tap)]^T — reduction index k = (valid position, image); padded taps contribute nothing
+// and are never visited.  grid z = tap * splits + split.
+template <int KS>
+struct PosBwwProb {
+  static constexpr bool BIG_TILES = true;
+  static constexpr bool A_KFAST = true;   // both operands: images (the reduction index) contiguous
+  static constexpr bool B_KFAST = true;
+  const float* dyt; const float* xt; float* dwt; float* part;
+  int N, Cin, H, W, Cout, OH, OW, stride, pad;
+  int M, Nc, kbeg, kend;
+  int kh, kw, oh_lo, ow_lo, now;
+  unsigned a_bytes, b_bytes;
+  int splits; long slab;
+  float* out;
+
+  __device__ bool setup(int bz) {
+    const int tap = bz / splits, sp = bz - tap * splits;
+    kh = tap / KS; kw = tap - kh * KS;
+    // ih = oh*stride - pad + kh in [0, H)
+    oh_lo = max(0, (pad - kh + stride - 1) / stride); ow_lo = max(0, (pad - kw + stride - 1) / stride);
+    const int oh_hi = min(OH - 1, (H - 1 + pad - kh) / stride), ow_hi = min(OW - 1, (W - 1 + pad - kw) / stride);
+    const int noh = (H - 1 + pad - kh < 0) ? 0 : max(0, oh_hi - oh_lo + 1);
+    now = (W - 1 + pad - kw < 0) ? 0 : max(0, ow_hi - ow_lo + 1);
+    const int K = noh * now * N;
+    const int per = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    kbeg = sp * per; kend = min(K, kbeg + per);
+    if (kend < kbeg) kend = kbeg;
+    if (now == 0) now = 1;
+    out = (splits > 1 ? part + (long)sp * slab : dwt) + (long)tap * Cout * Cin;
+    return true;
+  }
+  __device__ void tile(int, int) {}
+  __device__ const float* a_ptr() const { return dyt; }
+  __device__ const float* b_ptr() const { return xt; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return v; }
+  __device__ void decode(int k, int& img, int& oh, int& ow) const {
+    const int qi = k / N;
+    img = k - qi * N;
+    const int t = qi / now;
+    oh = oh_lo + t; ow = ow_lo + qi - t * now;
+  }
+  struct RowA { int base; bool ok; };
+  struct KA { int base; bool ok; };
+  __device__ RowA row_a(int m) const { return {m * N, m < M}; }
+  __device__ KA k_a(int k) const {
+    KA s; s.ok = k < kend; int img, oh, ow;
+    decode(s.ok ? k : 0, img, oh, ow);
+    s.base = (oh * OW + ow) * Cout * N + img; return s;
+  }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(k.base + r.base) * 4u : OOB; }
+  struct RowB { int base; bool ok; };
+  struct KB { int base; bool ok; };
+  __device__ RowB row_b(int n) const { return {n * N, n < Nc}; }
+  __device__ KB k_b(int k) const {
+    KB s; s.ok = k < kend; int img, oh, ow;
+    decode(s.ok ? k : 0, img, oh, ow);
+    s.base = ((oh * stride - pad + kh) * W + ow * stride - pad + kw) * Cin * N + img; return s;
+  }
+  __device__ unsigned off_b(const RowB& r, const KB& k) const { return (r.ok & k.ok) ? (unsigned)(k.base + r.base) * 4u : OOB; }
+  struct Col { int n; bool ok; };
+  __device__ Col col(int n) const { return {n, n < Nc}; }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) out[(long)m * Nc + c.n] = v;
+  }
+};
+
+// dw[(a*B + b)*KK + t] (+)= dwt[(t*A + a)*B + b]
+__global__ void tap_major_to_w_k(const float* __restrict__ dwt, float* __restrict__ dw, int A, int B, int KK, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)A * B * KK) return;
+  const int t = (int)(i % KK), b = (int)(i / KK % B), a = (int)(i / ((long)KK * B));
+  const float v = dwt[((long)t * A + a) * B + b];
+  dw[i] = accumulate ? dw[i] + v : v;
+}
+
+// xt[(p*C + c)*N + n] = x[(n*C + c)*HW + p]  (optional ReLU); block = one channel x 64 images, HW <= 64
+__global__ __launch_bounds__(256) void nchw_to_pcn_k(const float* __restrict__ x, float* __restrict__ xt, int N, int C, int HW, int in_relu) {
+  __shared__ float t[64][65];
+  const int c = blockIdx.x, n0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * HW; e += 256) {
+    const int nl = e / HW, p = e - nl * HW, n = n0 + nl;
+    float v = n < N ? x[((long)n * C + c) * HW + p] : 0.f;
+    t[nl][p] = in_relu ? fmaxf(v, 0.f) : v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * HW; e += 256) {
+    const int p = e >> 6, nl = e & 63, n = n0 + nl;
+    if (n < N) xt[((long)p * C + c) * N + n] = t[nl][p];
+  }
+}
+// y[(n*C + c)*HW + p] (+)= yt[(p*C + c)*N + n], optionally masked by pos_mask (same layout as y)
+__global__ __launch_bounds__(256) void pcn_to_nchw_k(const float* __restrict__ yt, float* __restrict__ y, const float* __restrict__ pos_mask,
+                                                     int N, int C, int HW, int accumulate) {
+  __shared__ float t[64][65];
+  const int c = blockIdx.x, n0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * HW; e += 256) {
+    const int p = e >> 6, nl = e & 63, n = n0 + nl;
+    t[nl][p] = n < N ? yt[((long)p * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * HW; e += 256) {
+    const int nl = e / HW, p = e - nl * HW, n = n0 + nl;
+    if (n < N) {
+      const long o = ((long)n * C + c) * HW + p;
+      float v = t[nl][p];
+      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+      y[o] = accumulate ? y[o] + v : v;
+    }
+  }
+}
+// wt[(t*A + a)*B + b] = w[...]: mode 0: w[a][b][t] (forward: a = co, b = ci);  mode 1: w[b][a][t];  mode 2: w[b][a][KK-1-t]
+// (input gradient of a stride-1 convolution = forward convolution of dy with flipped taps and swapped channel roles)
+__global__ void w_to_tap_major_k(const float* __restrict__ w, float* __restrict__ wt, int A, int B, int KK, int mode) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)A * B * KK) return;
+  const int b = (int)(i % B), a = (int)(i / B % A), t = (int)(i / ((long)A * B));
+  wt[i] = mode == 0 ? w[((long)a * B + b) * KK + t] : (mode == 1 ? w[((long)b * A + a) * KK + t] : w[((long)b * A + a) * KK + (KK - 1 - t)]);
+}
 
 // ------------------------------------------------------------------ workgroup -> tile, XCD-aware
 // The grid is 1-D; workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an XCD and its L2).  Tiles
@@ -300,6 +523,7 @@ __global__ __launch_bounds__(NT, (BM * BN > 128 * 128) ? 2 : 4) void igemm_f32(P
   if (!p.setup(bz)) return;
   const int bm0 = by * BM, bn0 = bx * BN;
   if (bm0 >= p.M || bn0 >= p.Nc) return;
+  p.tile(bn0, BN);                                   // tile-dependent reduction range (position-major problems)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -543,6 +767,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
+int g_use_pos = 1;            // agl_set_conv_pos(0): no position-major path on small maps (A/B tests)
 int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
 int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
 
@@ -920,6 +1145,74 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
   return AGL_OK;
 }
 
+// ---- position-major path (small maps): eligibility, scratch layout, forward launcher
+// Eligibility.  The transposes are a fixed cost per activation byte, so the path pays only where the arithmetic intensity
+// is high and the padded share large: measured +20 % on the 5x5 / 8x8 ConvLSTM input convolutions (512->512: 3.33 ->
+// 2.67 ms), +9 % on 512->1024 4x4/s2 at 4x4, nothing on the 3x3 discriminator layers (their transposes cost what the
+// skipped taps save) — so it is taken for 5x5 kernels only.
+static bool pos_ok(int N, int Cred, int H, int W, int Crow, int ks, int up) {   // Cred: reduction channels, Crow: GEMM rows
+  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && ks == 5 && N >= 96 && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
+         Crow >= 64;
+}
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+// valid taps summed over the output positions of a ks/stride/pad convolution on an H x W map
+static long pos_valid_taps(int H, int W, int OH, int OW, int ks, int stride, int pad) {
+  long rows = 0, cols = 0;
+  for (int o = 0; o < OH; ++o) { const int i0 = o * stride - pad; rows += std::min(ks - 1, H - 1 - i0) - std::max(0, -i0) + 1; }
+  for (int o = 0; o < OW; ++o) { const int i0 = o * stride - pad; cols += std::min(ks - 1, W - 1 - i0) - std::max(0, -i0) + 1; }
+  return rows * cols;
+}
+struct PosPlan { long xt, wt, yt, slabs; int splits; long total() const { return (xt + wt + yt + slabs) * 4; } };
+static PosPlan pos_fwd_plan(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
+  const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1, Q = OH * OW;
+  PosPlan pl;
+  pl.xt = (long)N * Cin * H * W; pl.wt = (long)Cout * Cin * ks * ks; pl.yt = (long)N * Cout * Q;
+  const int Kavg = (int)(pos_valid_taps(H, W, OH, OW, ks, stride, pad) * Cin / Q);
+  pl.splits = fwd_splits(Cout, (long)N * Q, 1, Kavg, nullptr);
+  pl.slabs = pl.splits > 1 ? (long)pl.splits * pl.yt : 0;
+  return pl;
+}
+static int launch_transpose_in(const float* x, float* xt, int N, int C, int HW, int in_relu, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_to_pcn_k, dim3(C, agl_cdiv(N, 64)), dim3(256), 0, st, x, xt, N, C, HW, in_relu);
+  AGL_CHECK_LAUNCH("position-major transpose (in)");
+  return AGL_OK;
+}
+static int launch_transpose_out(const float* yt, float* y, const float* pos_mask, int N, int C, int HW, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(pcn_to_nchw_k, dim3(C, agl_cdiv(N, 64)), dim3(256), 0, st, yt, y, pos_mask, N, C, HW, accumulate);
+  AGL_CHECK_LAUNCH("position-major transpose (out)");
+  return AGL_OK;
+}
+static int pos_conv_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, int N, int Cin, int H, int W, int Cout,
+                        int ks, int stride, int pad, int in_relu, int relu, int accumulate, hipStream_t st, int wmode = 0,
+                        const float* pos_mask = nullptr) {
+  const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1, Q = OH * OW, KK = ks * ks;
+  const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
+  float* xt = (float*)ws; float* wt = xt + pl.xt; float* yt = wt + pl.wt; float* slabs = yt + pl.yt;
+  int rc = launch_transpose_in(x, xt, N, Cin, H * W, in_relu, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(w_to_tap_major_k, dim3(agl_cdiv(pl.wt, 256)), dim3(256), 0, st, w, wt, Cout, Cin, KK, wmode);
+  AGL_CHECK_LAUNCH("agl_conv2d_fwd(position-major weights)");
+  rc = AGL_ERR_ARG;
+#define AGL_PF(KS_)                                                                                             \
+  case KS_: {                                                                                                   \
+    PosFwdProb<KS_> p;                                                                                          \
+    p.xt = xt; p.wt = wt; p.bias = bias; p.yt = yt; p.N = N; p.Cin = Cin; p.cin_shift = ilog2(Cin); p.H = H; p.W = W;  \
+    p.Cout = Cout; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad; p.relu = relu; p.M = Cout; p.Nc = N * Q; \
+    p.kbeg = 0; p.kend = 0; p.a_bytes = (unsigned)(pl.wt * 4); p.b_bytes = (unsigned)(pl.xt * 4);               \
+    p.splits = pl.splits; p.slab = pl.yt; p.part = slabs;                                                        \
+    rc = launch_igemm(p, Cout, (long)N * Q, pl.splits, st, "agl_conv2d_fwd(position-major)");                   \
+  } break;
+  switch (ks) { AGL_PF(3) AGL_PF(4) AGL_PF(5) AGL_PF(7) }
+#undef AGL_PF
+  if (rc != AGL_OK) return rc;
+  if (pl.splits > 1) {
+    hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(pl.yt, 256)), dim3(256), 0, st, (const float*)slabs, yt, pl.yt, pl.splits, N, Cout,
+                       bias, (const float*)nullptr, 0, relu);
+    AGL_CHECK_LAUNCH("agl_conv2d_fwd(position-major split-K epilogue)");
+  }
+  return launch_transpose_out(yt, y, pos_mask, N, Cout, Q, accumulate, st);
+}
+
 bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 
 }  // namespace
@@ -934,12 +1227,27 @@ int agl_set_conv_precision(int mode) {
 }
 int agl_get_conv_precision(void) { return g_conv_precision; }
 int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; return AGL_OK; }
+int agl_set_conv_pos(int on) { g_use_pos = on ? 1 : 0; return AGL_OK; }
+
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {
   int per;
   const int s = fwd_splits(M, out_pixels, phases, K, &per);
   return s > 1 ? (long)s * out_numel * 4 : 0;
+}
+
+// Scratch the forward pass wants for these extents: the larger of the split-K slabs and, on small maps, the
+// position-major operands (0 = none needed; with less, the pass falls back to paths that need less).
+long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2) {
+  const int Hl = H << up_log2, Wl = W << up_log2;
+  const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
+  long need = agl_conv2d_splitk_ws_bytes(Cout, (long)N * OH * OW, 1, Cin * ks * ks, (long)N * Cout * OH * OW);
+  if (pos_ok(N, Cin, H, W, Cout, ks, up_log2)) {
+    const long pn = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad).total();
+    if (pn > need) need = pn;
+  }
+  return need;
 }
 
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
@@ -957,6 +1265,11 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64)   // (linear layers, HW = 1, stay on the GEMM)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
+  if (pos_ok(N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
+    const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
+    if (ws && ws_bytes >= pl.total())
+      return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st);
+  }
   if (stride == 1 && g_use_patch) {
     PatchArgs a;
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -1007,6 +1320,12 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   if (Cin <= 4 && stride == 1 && IH * IW >= 64)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
+  if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(N, Cout, OH, OW, Cin, ks, 0)) {
+    // "same" convolution: dx = forward convolution of dy with flipped taps, channel roles swapped, pad ks-1-pad
+    const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
+    if (ws && ws_bytes >= pl.total())
+      return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, 2, pos_mask);
+  }
   if (stride == 1 && g_use_patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
     PatchArgs a;
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
@@ -1085,6 +1404,48 @@ static int bww_splits(int Cout, long Nc, long R, long* per_out) {
   return (int)s;
 }
 
+struct PosBwwPlan { long dyt, xt, dwt, slabs; int splits; long total() const { return (dyt + xt + dwt + slabs) * 4; } };
+static PosBwwPlan pos_bww_plan(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad) {
+  PosBwwPlan pl;
+  const int Q = OH * OW, KK = ks * ks;
+  pl.dyt = (long)N * Cout * Q; pl.xt = (long)N * Cin * H * W; pl.dwt = (long)KK * Cout * Cin;
+  const long Kavg = pos_valid_taps(H, W, OH, OW, ks, stride, pad) * N / KK;     // (position, image) pairs per tap
+  pl.splits = bww_splits(Cout, (long)Cin * KK, Kavg, nullptr);
+  if (pl.splits > 64) pl.splits = 64;
+  pl.slabs = pl.splits > 1 ? (long)pl.splits * pl.dwt : 0;
+  return pl;
+}
+static int pos_conv_bww(const float* dy, const float* x, float* dw, void* ws, int N, int Cin, int H, int W, int Cout, int OH, int OW,
+                        int ks, int stride, int pad, int accumulate, hipStream_t st) {
+  const int Q = OH * OW, KK = ks * ks;
+  const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, stride, pad);
+  float* dyt = (float*)ws; float* xt = dyt + pl.dyt; float* dwt = xt + pl.xt; float* slabs = dwt + pl.dwt;
+  int rc = launch_transpose_in(dy, dyt, N, Cout, Q, 0, st);
+  if (rc) return rc;
+  rc = launch_transpose_in(x, xt, N, Cin, H * W, 0, st);
+  if (rc) return rc;
+  rc = AGL_ERR_ARG;
+#define AGL_PW(KS_)                                                                                             \
+  case KS_: {                                                                                                   \
+    PosBwwProb<KS_> p;                                                                                          \
+    p.dyt = dyt; p.xt = xt; p.dwt = dwt; p.part = slabs; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;  \
+    p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad; p.M = Cout; p.Nc = Cin; p.kbeg = 0; p.kend = 0;        \
+    p.a_bytes = (unsigned)(pl.dyt * 4); p.b_bytes = (unsigned)(pl.xt * 4); p.splits = pl.splits; p.slab = pl.dwt; \
+    rc = launch_igemm(p, Cout, Cin, KK * pl.splits, st, "agl_conv2d_bwd_weight(position-major)", bww_big_tile(Cout, Cin)); \
+  } break;
+  switch (ks) { AGL_PW(3) AGL_PW(4) AGL_PW(5) AGL_PW(7) }
+#undef AGL_PW
+  if (rc != AGL_OK) return rc;
+  if (pl.splits > 1) {
+    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(pl.dwt, 256)), dim3(256), 0, st, (const float*)slabs, dwt, pl.dwt, pl.splits, 0);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(position-major reduce)");
+  }
+  hipLaunchKernelGGL(tap_major_to_w_k, dim3(agl_cdiv(pl.dwt, 256)), dim3(256), 0, st, (const float*)dwt, dw, Cout, Cin, KK, accumulate);
+  AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(position-major weights)");
+  return AGL_OK;
+}
+
+
 // Weight gradients of convolutions with <= 4 output channels (decoder c4 / c7) would use 3 of 32 MFMA rows.  With the
 // operand roles swapped — dw[co][ci][kh][kw] = dw'[ci][co][ks-1-kh][ks-1-kw], where dw' is the weight gradient of the
 // convolution that maps dy (as input, pad ks-1-pad) to x (as output gradient) — the GEMM has M = Cin rows instead.
@@ -1093,6 +1454,15 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
 }
 
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
+  long pos_need = 0;
+  if (OH <= 8 && OW <= 8 && ks == 5 && pos_ok(N, 64, OH, OW, Cout, ks, 0) && Cin >= 64)   // stride-1 "same" 5x5 on a small map
+    pos_need = pos_bww_plan(N, Cin, OH, OW, Cout, OH, OW, ks, 1, ks / 2).total();
+  if (pos_need) {
+    long Nc1 = (long)Cin * ks * ks, R1 = (long)N * OH * OW;
+    int s1 = bww_splits(Cout, Nc1, R1, nullptr);
+    const long plain = s1 > 1 ? (long)s1 * Cout * Nc1 * 4 : 0;
+    return pos_need > plain ? pos_need : plain;
+  }
   if (bww_swapped(Cin, Cout, 1, 0, 0)) {     // (upper bound: the entry point decides with the real stride / flags)
     long inner = 0;                                  // the input extent depends on the padding: cover every legal one
     for (int pad = 0; pad < ks; ++pad) {
@@ -1119,6 +1489,12 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
+      pos_ok(N, 64, H, W, Cout, ks, 0)) {
+    const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, 1, pad);
+    if (ws && ws_bytes >= pl.total())
+      return pos_conv_bww(dy, x, dw, ws, N, Cin, H, W, Cout, OH, OW, ks, 1, pad, accumulate, (hipStream_t)stream);
+  }
   if (bww_swapped(Cin, Cout, stride, up_log2, in_relu)) {
     const long inner = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
     const long tmp_bytes = (long)Cin * Cout * ks * ks * 4;

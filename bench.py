@@ -165,7 +165,7 @@ def main():
                 k = (name.replace('agl_conv2d_', ''), dims)
                 agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
             rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2] / 157.3e9))
-            for (nm, dims), (cnt, ms, fl) in rows[:40]:
+            for (nm, dims), (cnt, ms, fl) in rows[:int(os.environ.get("AGL_DUMP_CONV_ROWS", "40"))]:
                 print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/157.3e9:6.2f} ms  dims {dims}', file=sys.stderr)
         c0, c1 = FLOPS_PER_IMAGE[a.res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic, per GPU per step

@@ -362,3 +362,57 @@ def test_conv_adjoint_identities_at_full_size(shape):
     x2 = torch.randn(N, Cin, H, H, device=DEV, generator=gen)
     lin = L.conv2d_fwd(0.5 * x - 2.0 * x2, w, None, s, p)
     close(lin, 0.5 * y - 2.0 * L.conv2d_fwd(x2, w, None, s, p), 2e-5, "linearity")
+
+
+POS_CASES = [
+    # N, Cin, H, Cout, ks, stride, pad        (position-major path: maps <= 8x8, >= 96 images, Cin a power of two)
+    (130, 64, 8, 96, 5, 1, 2),      # ConvLSTM-like
+    (130, 64, 8, 128, 5, 1, 2),
+    (393, 128, 8, 256, 5, 1, 2),
+    (100, 64, 6, 64, 5, 1, 2),      # ragged 6x6 map
+    (393, 128, 8, 64, 3, 1, 1),
+    (100, 256, 4, 128, 3, 1, 1),
+    (200, 64, 8, 128, 4, 2, 1),     # 8 -> 4
+    (129, 128, 4, 256, 4, 2, 1),    # 4 -> 2
+    (97, 64, 6, 64, 3, 1, 1),       # ragged map
+]
+
+
+@pytest.mark.parametrize("case", POS_CASES)
+def test_position_major_conv_vs_torch_and_im2col(case):
+    """Small-map convolutions run as per-position sums of plain matrix products (padded taps are never visited);
+    results must match torch and the im2col/patch kernels (agl_set_conv_pos(0)) to fp32 rounding, including the
+    fused input ReLU, bias, output ReLU and accumulate epilogues."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, s, p = case
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    yr = TF.conv2d(torch.relu(x), w, b, stride=s, padding=p)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = L.conv2d_fwd(xd, wd, bd, s, p, in_relu=True)
+    close(y, yr, 2e-5, "y (input ReLU, bias)")
+    base = rn(*yr.shape, seed=5)
+    y2 = L.conv2d_fwd(xd, wd, None, s, p, out=dev(base).clone(), accumulate=True)
+    close(y2, base + TF.conv2d(x, w, None, stride=s, padding=p), 2e-5, "accumulate")
+    y3 = L.conv2d_fwd(xd, wd, bd, s, p, relu=True)
+    close(y3, torch.relu(TF.conv2d(x, w, b, stride=s, padding=p)), 2e-5, "output ReLU")
+    L.call("agl_set_conv_pos", 0)
+    try:
+        y_ref = L.conv2d_fwd(xd, wd, bd, s, p, in_relu=True)
+    finally:
+        L.call("agl_set_conv_pos", 1)
+    close(y, y_ref, 5e-6, "position-major vs im2col")
+    # input gradient (same path with flipped taps, fused positive mask) and weight gradient (position-major reduction)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yy = TF.conv2d(xr, wr, None, stride=s, padding=p)
+    g = rn(*yy.shape, seed=7)
+    yy.backward(g)
+    gd = dev(g)
+    dx = L.conv2d_bwd_data(gd, wd, (H, H), s, p)
+    close(dx, xr.grad, 1e-4, "dx")
+    dxm = L.conv2d_bwd_data(gd, wd, (H, H), s, p, pos_mask=xd)
+    close(dxm, xr.grad * (x > 0), 1e-4, "dx masked")
+    dw = L.conv2d_bwd_weight(gd, xd, ks, s, p)
+    close(dw, wr.grad, 1e-4, "dw")
+    base_w = rn(*w.shape, seed=9)
+    dw2 = L.conv2d_bwd_weight(gd, xd, ks, s, p, out=dev(base_w).clone(), accumulate=True)
+    close(dw2, base_w + wr.grad, 1e-4, "dw accumulate")
