@@ -767,6 +767,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
+int g_pos_min_n = 96;         // smallest image count for the position-major path (agl_set_conv_pos(n > 1) sets it)
 int g_use_pos = 1;            // agl_set_conv_pos(0): no position-major path on small maps (A/B tests)
 int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
 int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
@@ -1151,7 +1152,7 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
 // 2.67 ms), +9 % on 512->1024 4x4/s2 at 4x4, nothing on the 3x3 discriminator layers (their transposes cost what the
 // skipped taps save) — so it is taken for 5x5 kernels only.
 static bool pos_ok(int N, int Cred, int H, int W, int Crow, int ks, int up) {   // Cred: reduction channels, Crow: GEMM rows
-  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && ks == 5 && N >= 96 && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
+  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && ks == 5 && N >= g_pos_min_n && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
          Crow >= 64;
 }
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
@@ -1227,7 +1228,7 @@ int agl_set_conv_precision(int mode) {
 }
 int agl_get_conv_precision(void) { return g_conv_precision; }
 int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; return AGL_OK; }
-int agl_set_conv_pos(int on) { g_use_pos = on ? 1 : 0; return AGL_OK; }
+int agl_set_conv_pos(int on) { g_use_pos = on ? 1 : 0; if (on > 1) g_pos_min_n = on; return AGL_OK; }
 
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
