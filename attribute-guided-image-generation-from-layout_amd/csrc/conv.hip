@@ -269,6 +269,7 @@ struct PosFwdProb {
   const float* xt; const float* wt; const float* bias; float* yt;
   int N, Cin, cin_shift, H, W, Cout, OH, OW, stride, pad, relu;
   int M, Nc, kbeg, kend;            // Nc = Q * N: GEMM columns are (position, image), position-major
+  int nfull, Q;                     // nfull = N rounded down to whole 128-column tiles (see col_of)
   int sp, kh_lo, kw_lo, nkw, inv_nkw;
   unsigned a_bytes, b_bytes;
   int splits; long slab; float* part;
@@ -278,11 +279,19 @@ struct PosFwdProb {
     if (splits > 1) part += (long)sp * slab;
     return true;
   }
-  // A column tile covers one output position, or the tail of one and the head of the next (N is not a multiple of the
-  // tile width): its taps are the bounding rectangle of those positions' valid taps; a lane whose own position lacks a
-  // tap of the rectangle reads zero (out-of-range offset).
+  // Column order: first, for every position, its images in whole 128-column tiles (nfull per position: tiles that
+  // see ONE position and skip all of its padded taps); then the leftover N - nfull images of all positions packed
+  // together.  A tile's taps are the bounding rectangle of the valid taps of the positions it covers; a lane whose own
+  // position lacks a tap of the rectangle reads zero (out-of-range offset).
+  __device__ void col_of(int n, int& q, int& img) const {
+    const int pure = Q * nfull;
+    if (n < pure) { q = n / nfull; img = n - q * nfull; }
+    else { const int r = n - pure, nrem = N - nfull; q = r / nrem; img = nfull + r - q * nrem; }
+  }
   __device__ void tile(int bn0, int bn) {
-    const int q_lo = bn0 / N, q_hi = (min(bn0 + bn, Nc) - 1) / N;
+    int q_lo, q_hi, dummy;
+    col_of(bn0, q_lo, dummy);
+    col_of(min(bn0 + bn, Nc) - 1, q_hi, dummy);
     int kh_hi = -1, kw_hi = -1;
     kh_lo = KS; kw_lo = KS;
     for (int q = q_lo; q <= q_hi; ++q) {
@@ -320,8 +329,10 @@ struct PosFwdProb {
   struct KB { int coff, kh, kw; bool ok; };
   __device__ RowB row_b(int n) const {
     RowB r; r.ok = n < Nc;
-    const int nn = r.ok ? n : 0, q = nn / N, oh = q / OW, ow = q - oh * OW;
-    r.img = nn - q * N; r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
+    int q;
+    col_of(r.ok ? n : 0, q, r.img);
+    const int oh = q / OW, ow = q - oh * OW;
+    r.ih0 = oh * stride - pad; r.iw0 = ow * stride - pad;
     return r;
   }
   __device__ KB k_b(int k) const {
@@ -337,8 +348,9 @@ struct PosFwdProb {
   struct Col { long off; bool ok; };
   __device__ Col col(int n) const {
     Col c; c.ok = n < Nc;
-    const int nn = c.ok ? n : 0, q = nn / N;
-    c.off = (long)q * Cout * N + (nn - q * N); return c;
+    int q, img;
+    col_of(c.ok ? n : 0, q, img);
+    c.off = (long)q * Cout * N + img; return c;
   }
   __device__ void store(int m, const Col& c, float v) const {
     if (m < M && c.ok) {
@@ -767,6 +779,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
+int g_pos_all_ks = 0;         // experiments: also 3x3 / 4x4 kernels (agl_set_conv_pos(-1))
 int g_pos_min_n = 96;         // smallest image count for the position-major path (agl_set_conv_pos(n > 1) sets it)
 int g_use_pos = 1;            // agl_set_conv_pos(0): no position-major path on small maps (A/B tests)
 int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
@@ -1152,7 +1165,7 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
 // 2.67 ms), +9 % on 512->1024 4x4/s2 at 4x4, nothing on the 3x3 discriminator layers (their transposes cost what the
 // skipped taps save) — so it is taken for 5x5 kernels only.
 static bool pos_ok(int N, int Cred, int H, int W, int Crow, int ks, int up) {   // Cred: reduction channels, Crow: GEMM rows
-  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && ks == 5 && N >= g_pos_min_n && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
+  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && (ks == 5 || (g_pos_all_ks && ks >= 3)) && N >= g_pos_min_n && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
          Crow >= 64;
 }
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
@@ -1200,6 +1213,7 @@ static int pos_conv_fwd(const float* x, const float* w, const float* bias, float
     p.xt = xt; p.wt = wt; p.bias = bias; p.yt = yt; p.N = N; p.Cin = Cin; p.cin_shift = ilog2(Cin); p.H = H; p.W = W;  \
     p.Cout = Cout; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad; p.relu = relu; p.M = Cout; p.Nc = N * Q; \
     p.kbeg = 0; p.kend = 0; p.a_bytes = (unsigned)(pl.wt * 4); p.b_bytes = (unsigned)(pl.xt * 4);               \
+    p.Q = Q; p.nfull = N / 128 * 128;                                                                            \
     p.splits = pl.splits; p.slab = pl.yt; p.part = slabs;                                                        \
     rc = launch_igemm(p, Cout, (long)N * Q, pl.splits, st, "agl_conv2d_fwd(position-major)");                   \
   } break;
@@ -1228,7 +1242,12 @@ int agl_set_conv_precision(int mode) {
 }
 int agl_get_conv_precision(void) { return g_conv_precision; }
 int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; return AGL_OK; }
-int agl_set_conv_pos(int on) { g_use_pos = on ? 1 : 0; if (on > 1) g_pos_min_n = on; return AGL_OK; }
+int agl_set_conv_pos(int on) {
+  g_use_pos = on ? 1 : 0;
+  if (on > 1) g_pos_min_n = on;
+  g_pos_all_ks = on < 0;
+  return AGL_OK;
+}
 
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).

@@ -10,6 +10,8 @@ if os.environ.get("AGL_NOPATCH"):
     L.call("agl_set_conv_patch", 0)
 if os.environ.get("AGL_POS_MIN_N"):
     L.call("agl_set_conv_pos", int(os.environ["AGL_POS_MIN_N"]))
+if os.environ.get("AGL_POS_ALL"):
+    L.call("agl_set_conv_pos", -1)
 if os.environ.get("AGL_NOPOS"):
     L.call("agl_set_conv_pos", 0)
 if os.environ.get("AGL_PREC"):
