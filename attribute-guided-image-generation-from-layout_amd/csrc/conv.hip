@@ -23,6 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
+#ifndef AGL_SPLIT_FIXED
+#define AGL_SPLIT_FIXED 4e-6   // fixed cost (s) the split cost models charge for the extra reduction launch
+#endif
 constexpr int BK = 16;
 #ifndef AGL_GATHER_STEPS
 #define AGL_GATHER_STEPS (BK / 2)   // MFMA k-steps of a slice over which the next slice's gathers are spread
@@ -767,7 +770,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   for (int s = 1; s <= 16; ++s) {
     if (s > 1 && K / s < 128) break;
     const double rounds = ceil((double)tiles * s / slots);
-    double t = rounds * ((double)K / s) * t_k + 4e-6 * (s > 1);
+    double t = rounds * ((double)K / s) * t_k + AGL_SPLIT_FIXED * (s > 1);
     if (s > 1) t += out_bytes * (2.0 * s + 1.0) / 4.0e12;
     if (t < best_t * 0.97) { best_t = t; best = s; }             // need a 3 % win to take a larger split
   }
@@ -1129,7 +1132,7 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
   for (int s = 1; s <= 16 && s <= chunks; ++s) {
     if (s > 1 && (chunks / s) * cb * ks * ks < 128) break;
     const double rounds = ceil((double)tiles * s / 768.0);
-    double t = rounds * ((double)a.Cin * ks * ks / s) * (bm * 128 * 2.0 / 150e9) + 4e-6 * (s > 1);
+    double t = rounds * ((double)a.Cin * ks * ks / s) * (bm * 128 * 2.0 / 150e9) + AGL_SPLIT_FIXED * (s > 1);
     if (s > 1) t += (double)out_numel * 4.0 * (2.0 * s + 1.0) / 4.0e12;
     if (t < best_t * 0.97) { best_t = t; best = s; }
   }
@@ -1412,7 +1415,7 @@ static int bww_splits(int Cout, long Nc, long R, long* per_out) {
   const long smax = R / 256 > 0 ? (R / 256 > 256 ? 256 : R / 256) : 1;
   for (long s = 1; s <= smax; s = s < 16 ? s + 1 : s + s / 8) {
     const double rounds = ceil((double)tiles * s / slots);
-    double t = rounds * ((double)R / s) * t_k + 4e-6 * (s > 1);
+    double t = rounds * ((double)R / s) * t_k + AGL_SPLIT_FIXED * (s > 1);
     if (s > 1) t += out_bytes * (2.0 * s + 1.0) / 4.0e12;
     if (t < best_t * 0.97) { best_t = t; best = s; }
   }
