@@ -44,15 +44,16 @@ class OptimizedBlock(nn.Module):
             self.sc = A.Conv2d(dim_in, dim_out, kernel_size=1, padding=0, bias=True)
 
     def forward(self, x, W=None):
-        h = self.resi[0](x, relu=True, weight=_w(W, self.resi[0]))
+        # h feeds exactly one convolution, which masks its input gradient by h > 0 (no separate ReLU-backward pass)
+        h = self.resi[0](x, relu=True, relu_grad_by_consumer=True, weight=_w(W, self.resi[0]))
         c2 = self.resi[2]
         w2 = _w(W, c2)
         s = x
         if self.downsample:            # conv3x3 + avg-pool == one 4x4 stride-2 conv (2.25x fewer MACs)
-            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias)
+            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias, x_relu=True)
             s = F.avg_pool2(x)
         else:
-            h = c2(h, weight=w2)
+            h = c2(h, x_relu=True, weight=w2)
         return self.sc(s, addend=h, weight=_w(W, self.sc))
 
 
@@ -71,13 +72,13 @@ class ResidualBlock(nn.Module):
     def forward(self, x, W=None):
         if not self.learnable_sc:
             raise NotImplementedError("identity-shortcut blocks are not on the reference path")
-        h = self.resi[1](x, in_relu=True, relu=True, weight=_w(W, self.resi[1]))
+        h = self.resi[1](x, in_relu=True, relu=True, relu_grad_by_consumer=True, weight=_w(W, self.resi[1]))
         c2 = self.resi[3]
         w2 = _w(W, c2)
         if self.downsample:
-            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias)
+            h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias, x_relu=True)
             return self.sc(F.avg_pool2(x, in_relu=True), addend=h, weight=_w(W, self.sc))
-        h = c2(h, weight=w2)
+        h = c2(h, x_relu=True, weight=w2)
         return self.sc(x, in_relu=True, addend=h, weight=_w(W, self.sc))
 
 

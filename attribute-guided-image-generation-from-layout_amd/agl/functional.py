@@ -41,7 +41,7 @@ def _slot(p):
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu):
+    def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu, relu_grad_by_consumer, x_relu):
         ctx.slots = (_slot(w), _slot(bias))
         x, w = _c(x), _c(w)
         if addend is not None:
@@ -50,16 +50,18 @@ class _Conv2d(torch.autograd.Function):
             ctx.mark_dirty(addend)
         else:
             y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, relu)
-        ctx.cfg = (stride, pad, up, in_relu, relu, bias is not None, addend is not None)
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (stride, pad, up, in_relu, relu, bias is not None, addend is not None, relu_grad_by_consumer, x_relu)
+        ctx.save_for_backward(x, w, y if (relu and not relu_grad_by_consumer) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        stride, pad, up, in_relu, relu, has_bias, has_add = ctx.cfg
+        stride, pad, up, in_relu, relu, has_bias, has_add, by_consumer, x_relu = ctx.cfg
         x, w, y = ctx.saved_tensors
         dy = _c(dy)
-        g = L.relu_bwd(dy, y) if relu else dy
+        # relu_grad_by_consumer: the (single) consumer of y masks its input gradient with y > 0 (its x_relu flag), so
+        # dy already is the gradient of the pre-activation and the separate masking pass is skipped
+        g = L.relu_bwd(dy, y) if (relu and not by_consumer) else dy
         ks = w.shape[2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -69,7 +71,7 @@ class _Conv2d(torch.autograd.Function):
                 dx = L.upsample_bwd(dxu, up)
                 assert not in_relu
             else:
-                dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if in_relu else None)
+                dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if (in_relu or x_relu) else None)
         wslot, bslot = ctx.slots
         if ctx.needs_input_grad[1]:
             if wslot is not None:
@@ -82,13 +84,19 @@ class _Conv2d(torch.autograd.Function):
             else:
                 db = L.channel_sum(g)
         dadd = dy if (has_add and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dadd, None, None, None, None, None
+        return dx, dw, db, dadd, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, up=0, in_relu=False, relu=False, addend=None):
+def conv2d(x, w, bias=None, stride=1, padding=0, up=0, in_relu=False, relu=False, addend=None, relu_grad_by_consumer=False,
+           x_relu=False):
     """nn.Conv2d forward (+ optional fused input ReLU / nearest up-sampling of x, output ReLU, and
-    accumulation into `addend`, which is consumed in place)."""
-    return _Conv2d.apply(x, w, bias, addend, stride, padding, up, in_relu, relu)
+    accumulation into `addend`, which is consumed in place).
+
+    A producer/consumer pair can drop the separate ReLU-backward pass: the producer passes relu=True,
+    relu_grad_by_consumer=True and its output must feed exactly ONE convolution, called with x_relu=True, which masks
+    the gradient it returns by x > 0 in its input-gradient epilogue."""
+    assert not (x_relu and up), "x_relu with folded up-sampling is not supported"
+    return _Conv2d.apply(x, w, bias, addend, stride, padding, up, in_relu, relu, relu_grad_by_consumer, x_relu)
 
 
 def linear(x, w, bias=None, relu=False):
@@ -323,9 +331,9 @@ class _PoolFuseWeight(torch.autograd.Function):
         return dw3
 
 
-def conv3x3_avgpool2(x, w3, bias=None, in_relu=False):
+def conv3x3_avgpool2(x, w3, bias=None, in_relu=False, x_relu=False):
     """avg_pool2d(conv2d(x, w3, bias, padding=1), 2) as one 4x4 stride-2 convolution (exact in real arithmetic)."""
-    return conv2d(x, _PoolFuseWeight.apply(w3), bias, 2, 1, 0, in_relu, False, None)
+    return conv2d(x, _PoolFuseWeight.apply(w3), bias, 2, 1, 0, in_relu, False, None, False, x_relu)
 
 
 class _Concat2(torch.autograd.Function):

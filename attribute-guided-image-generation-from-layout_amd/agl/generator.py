@@ -233,10 +233,11 @@ class SPADE(nn.Module):
         f = x.shape[2] // segmap.shape[2]
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
-        actv = self.mlp_shared[0](segmap, relu=True, up=up)
+        # actv feeds exactly one convolution, which masks its input gradient by actv > 0 (no separate ReLU-backward pass)
+        actv = self.mlp_shared[0](segmap, relu=True, up=up, relu_grad_by_consumer=True)
         w = F.concat_rows(self.mlp_gamma.weight, self.mlp_beta.weight)
         b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
-        gb = F.conv2d(actv, w, b, 1, 1)
+        gb = F.conv2d(actv, w, b, 1, 1, x_relu=True)
         n = self.param_free_norm
         return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training)
 

@@ -21,10 +21,10 @@ def _need_device(t):
 class Conv2d(nn.Conv2d):
     """nn.Conv2d container; square kernels 1/3/4/5/7, stride 1/2 (all the path uses)."""
 
-    def forward(self, x, *, in_relu=False, relu=False, up=0, addend=None, weight=None):
+    def forward(self, x, *, in_relu=False, relu=False, up=0, addend=None, weight=None, relu_grad_by_consumer=False, x_relu=False):
         _need_device(x)
         w = self.weight if weight is None else weight
-        return F.conv2d(x, w, self.bias, self.stride[0], self.padding[0], up, in_relu, relu, addend)
+        return F.conv2d(x, w, self.bias, self.stride[0], self.padding[0], up, in_relu, relu, addend, relu_grad_by_consumer, x_relu)
 
 
 class Linear(nn.Linear):

@@ -416,3 +416,27 @@ def test_position_major_conv_vs_torch_and_im2col(case):
     base_w = rn(*w.shape, seed=9)
     dw2 = L.conv2d_bwd_weight(gd, xd, ks, s, p, out=dev(base_w).clone(), accumulate=True)
     close(dw2, base_w + wr.grad, 1e-4, "dw accumulate")
+
+
+def test_relu_gradient_masked_by_consumer():
+    """conv(relu=True, relu_grad_by_consumer=True) -> conv(x_relu=True): the consumer masks its input gradient by
+    x > 0 in the input-gradient epilogue, so the producer skips the ReLU-backward pass; gradients must equal the plain
+    composition (torch reference), for the im2col, patch and fused 4x4/stride-2 consumers."""
+    from agl import functional as F
+    for (N, C0, H, C1, C2, fused_pool) in ((3, 16, 16, 64, 48, False), (2, 8, 8, 32, 24, True), (5, 64, 32, 64, 128, True)):
+        x, w1, b1 = rn(N, C0, H, H), rn(C1, C0, 3, 3, seed=1) * 0.1, rn(C1, seed=2)
+        w2, b2 = rn(C2, C1, 3, 3, seed=3) * 0.1, rn(C2, seed=4)
+        ts = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        h = TF.relu(TF.conv2d(ts[0], ts[1], ts[2], padding=1))
+        y = TF.conv2d(h, ts[3], ts[4], padding=1)
+        if fused_pool:
+            y = TF.avg_pool2d(y, 2)
+        gy = rn(*y.shape, seed=5)
+        y.backward(gy)
+        tg = [dev(t).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        hg = F.conv2d(tg[0], tg[1], tg[2], 1, 1, relu=True, relu_grad_by_consumer=True)
+        yg = F.conv3x3_avgpool2(hg, tg[3], tg[4], x_relu=True) if fused_pool else F.conv2d(hg, tg[3], tg[4], 1, 1, x_relu=True)
+        close(yg, y, 3e-5, "y")
+        yg.backward(dev(gy))
+        for nm, a, r in zip(("dx", "dw1", "db1", "dw2", "db2"), tg, ts):
+            close(a.grad, r.grad, 2e-4, nm)
