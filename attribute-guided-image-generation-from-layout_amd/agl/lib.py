@@ -46,6 +46,8 @@ SIGNATURES = {
     "agl_axpby": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "agl_gather_rows": (_I, [_P, _P, _P, _L, _L, _I, _P]),
     "agl_scatter_rows": (_I, [_P, _P, _P, _L, _L, _P]),
+    "agl_box2_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
+    "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_upsample_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
@@ -215,7 +217,7 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     if out is None:
         assert not accumulate
         out = torch.empty((N, Cin, IH, IW), dtype=torch.float32, device=dy.device)
-    tpa = ks // stride
+    tpa = -(-ks // stride)
     need = load().agl_conv2d_splitk_ws_bytes(Cin, N * (-(-IH // stride)) * (-(-IW // stride)), stride * stride,
                                              Cout * tpa * tpa, out.numel())
     if stride == 1 and (IH, IW) == (OH, OW):      # position-major path on small maps (forward form with flipped taps)
@@ -334,6 +336,20 @@ def scatter_rows(src, rows, out):
     ln = src.numel() // src.shape[0]
     call("agl_scatter_rows", ptr(src), ptr(rows, torch.int64), ptr(out), rows.numel(), ln, stream())
     return out
+
+
+def box2_fwd(x):
+    N, Cc, H, W = x.shape
+    xb = torch.empty((N, Cc, H + 1, W + 1), dtype=torch.float32, device=x.device)
+    call("agl_box2_fwd", ptr(x), ptr(xb), N * Cc, H, W, stream())
+    return xb
+
+
+def box2_bwd(dxb, mask=None):
+    N, Cc, HB, WB = dxb.shape
+    dx = torch.empty((N, Cc, HB - 1, WB - 1), dtype=torch.float32, device=dxb.device)
+    call("agl_box2_bwd", ptr(dxb), ptr(mask), ptr(dx), N * Cc, HB - 1, WB - 1, stream())
+    return dx
 
 
 def avgpool2_fwd(x, in_relu=False):

@@ -198,6 +198,106 @@ struct BwdDataProb {
   }
 };
 
+// Input gradient of a strided convolution whose kernel size is not a multiple of the stride (3x3 stride 2: the
+// down-sampling discriminator blocks in box-filter form): one launch z-slice per stride phase, the phase's taps are
+// kh = kh0 + S*th with a phase-dependent count (2x2, 2x1, 1x2, 1x1 taps for 3x3/s2 — 9 in total, no zero taps).
+template <int KS, int S>
+struct BwdDataGenProb {
+  static constexpr bool BIG_TILES = false;
+  static constexpr bool A_KFAST = false;
+  static constexpr bool B_KFAST = false;
+  const float* dy; const float* w; float* dx; const float* bias; const float* pos_mask;
+  int N, Cin, IH, IW, Cout, OH, OW, pad;
+  int accumulate, relu;
+  int M, Nc, kbeg, kend;
+  int IHW, OHW, ph, pw, kh0, kw0, ohb, owb, IHp, IWp, tsw, tt;
+  unsigned inv_tt, inv_tsw;
+  unsigned a_bytes, b_bytes;
+  int splits; long slab; float* part;
+
+  __device__ bool setup(int zz) {
+    const int z = zz / splits, sp = zz - z * splits;
+    ph = z / S; pw = z - ph * S;
+    IHp = (IH - ph + S - 1) / S; IWp = (IW - pw + S - 1) / S;
+    kh0 = (ph + pad) % S; kw0 = (pw + pad) % S;
+    ohb = (ph + pad - kh0) / S; owb = (pw + pad - kw0) / S;
+    const int tsh = kh0 < KS ? (KS - kh0 + S - 1) / S : 0;
+    tsw = kw0 < KS ? (KS - kw0 + S - 1) / S : 0;
+    tt = tsh * tsw;
+    Nc = N * IHp * IWp; M = Cin;
+    if (Nc <= 0) return false;
+    if (tsw == 0) tsw = 1;
+    inv_tt = tt > 1 ? (unsigned)((0x100000000ULL + tt - 1) / tt) : 0u;
+    inv_tsw = 65536u / tsw + 1u;
+    const int K = Cout * tt;
+    const int per = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    kbeg = sp * per; kend = min(K, kbeg + per);
+    if (kend < kbeg) kend = kbeg;                    // an empty split still stores its (zero) slab
+    if (splits > 1) part += (long)sp * slab;
+    return true;
+  }
+  __device__ void tile(int, int) {}
+  __device__ const float* a_ptr() const { return w; }
+  __device__ const float* b_ptr() const { return dy; }
+  __device__ float fix_a(float v) const { return v; }
+  __device__ float fix_b(float v) const { return v; }
+  __device__ void decode(int k, int& co, int& th, int& tw) const {
+    co = tt > 1 ? (int)__umulhi((unsigned)k, inv_tt) : k;
+    const int r = k - co * tt;
+    th = (int)(((unsigned)r * inv_tsw) >> 16);
+    tw = r - th * tsw;
+  }
+  struct RowA { int base; bool ok; };
+  struct KA { int off; bool ok; };
+  __device__ RowA row_a(int m) const { return {m * KS * KS, m < M}; }
+  __device__ KA k_a(int k) const {
+    KA s; s.ok = k < kend; int co, th, tw;
+    decode(s.ok ? k : 0, co, th, tw);
+    s.off = co * Cin * KS * KS + (kh0 + S * th) * KS + (kw0 + S * tw);
+    return s;
+  }
+  __device__ unsigned off_a(const RowA& r, const KA& k) const { return (r.ok & k.ok) ? (unsigned)(r.base + k.off) * 4u : OOB; }
+  struct RowB { int base, oh0, ow0; bool ok; };
+  struct KB { int coff, th, tw; bool ok; };
+  __device__ RowB row_b(int n) const {
+    RowB r; r.ok = n < Nc; int nn = r.ok ? n : 0;
+    int per = IHp * IWp;
+    int img = nn / per, q = nn - img * per;
+    int a = q / IWp, b = q - a * IWp;
+    r.base = img * Cout * OHW; r.oh0 = a + ohb; r.ow0 = b + owb;
+    return r;
+  }
+  __device__ KB k_b(int k) const {
+    KB s; s.ok = k < kend; int co;
+    decode(s.ok ? k : 0, co, s.th, s.tw); s.coff = co * OHW;
+    return s;
+  }
+  __device__ unsigned off_b(const RowB& r, const KB& k) const {
+    const int oh = r.oh0 - k.th, ow = r.ow0 - k.tw;
+    const bool ok = r.ok & k.ok & ((unsigned)oh < (unsigned)OH) & ((unsigned)ow < (unsigned)OW);
+    return ok ? (unsigned)(r.base + k.coff + oh * OW + ow) * 4u : OOB;
+  }
+  struct Col { long off; bool ok; };
+  __device__ Col col(int n) const {
+    Col c; c.ok = n < Nc; int nn = c.ok ? n : 0;
+    int per = IHp * IWp;
+    int img = nn / per, q = nn - img * per;
+    int a = q / IWp, b = q - a * IWp;
+    c.off = (long)img * Cin * IHW + (long)(a * S + ph) * IW + (b * S + pw); return c;
+  }
+  __device__ void store(int m, const Col& c, float v) const {
+    if (m < M && c.ok) {
+      long o = c.off + (long)m * IHW;
+      if (splits > 1) { part[o] = v; return; }
+      if (bias) v += bias[m];
+      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+      if (accumulate) v += dx[o];
+      if (relu) v = fmaxf(v, 0.f);
+      dx[o] = v;
+    }
+  }
+};
+
 // ------------------------------------------------------------------ backward weight
 template <int KS>
 struct BwdWeightProb {
@@ -1333,7 +1433,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
                         long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
                         int relu, int accumulate, void* stream) {
   AGL_REQUIRE(dy && w && dx, "agl_conv2d_bwd_data: null pointer");
-  AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && ks == 4)), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
+  AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && (ks == 4 || ks == 3))), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
   AGL_REQUIRE((IH + 2 * pad - ks) / stride + 1 == OH && (IW + 2 * pad - ks) / stride + 1 == OW,
               "agl_conv2d_bwd_data: inconsistent extents IH=%d IW=%d OH=%d OW=%d", IH, IW, OH, OW);
@@ -1359,7 +1459,8 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     if (prc >= 0) return prc;
   }
   const long out_numel = (long)N * Cin * IH * IW;
-  const int phases = stride * stride, Kp = Cout * (ks / stride) * (ks / stride);
+  const int tpa = (ks + stride - 1) / stride;                    // taps per axis of the fullest stride phase
+  const int phases = stride * stride, Kp = Cout * tpa * tpa;
   int per = 0, rc = AGL_ERR_ARG;
   int splits = fwd_splits(Cin, (long)N * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride), phases, Kp, &per);
   if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; per = Kp; }
@@ -1373,7 +1474,15 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     p.splits = splits; p.per_split = per; p.slab = out_numel; p.part = (float*)ws;                                  \
     rc = launch_igemm(p, Cin, maxNc, S_ * S_ * splits, st, "agl_conv2d_bwd_data");                                  \
   }
-  if (stride == 2) AGL_BWD(4, 2)
+  if (stride == 2 && ks == 3) {
+    BwdDataGenProb<3, 2> p;
+    p.dy = dy; p.w = w; p.dx = dx; p.bias = bias; p.pos_mask = pos_mask; p.N = N; p.Cin = Cin; p.IH = IH; p.IW = IW; p.Cout = Cout;
+    p.OH = OH; p.OW = OW; p.pad = pad; p.accumulate = accumulate; p.relu = relu; p.IHW = IH * IW; p.OHW = OH * OW;
+    p.a_bytes = (unsigned)((long)Cout * Cin * 9 * 4); p.b_bytes = (unsigned)((long)N * Cout * OH * OW * 4);
+    long maxNc = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2);
+    p.splits = splits; p.slab = out_numel; p.part = (float*)ws; p.kbeg = 0; p.kend = 0; p.M = Cin; p.Nc = 0;
+    rc = launch_igemm(p, Cin, maxNc, 4 * splits, st, "agl_conv2d_bwd_data(3x3 stride 2)");
+  } else if (stride == 2) AGL_BWD(4, 2)
   else switch (ks) {
     case 1: AGL_BWD(1, 1) break;
     case 3: AGL_BWD(3, 1) break;

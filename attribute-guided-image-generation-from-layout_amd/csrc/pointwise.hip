@@ -502,6 +502,36 @@ __global__ __launch_bounds__(256) void deprocess_u8_k(const float* __restrict__ 
   }
 }
 
+// 2x2 box filter at stride 1 over the zero-extended map: xb[j][i] = (x[j-1][i-1] + x[j-1][i] + x[j][i-1] + x[j][i]) / 4 for
+// j, i in [0, H] x [0, W] (out-of-range x = 0).  avg_pool2(conv3x3(x, pad 1)) equals a 3x3 STRIDE-2 convolution without
+// padding of xb (agl.functional.conv3x3_avgpool2): 9 taps per output instead of the 16 of the fused 4x4 form.
+__global__ void box2_fwd_k(const float* __restrict__ x, float* __restrict__ xb, long NC, int H, int W) {
+  const int HB = H + 1, WB = W + 1;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * HB * WB) return;
+  const int ix = (int)(i % WB), iy = (int)(i / WB % HB);
+  const long nc = i / ((long)WB * HB);
+  const float* p = x + nc * H * W;
+  float s = 0.f;
+  if (iy > 0 && ix > 0) s += p[(iy - 1) * W + ix - 1];
+  if (iy > 0 && ix < W) s += p[(iy - 1) * W + ix];
+  if (iy < H && ix > 0) s += p[iy * W + ix - 1];
+  if (iy < H && ix < W) s += p[iy * W + ix];
+  xb[i] = 0.25f * s;
+}
+// dx[j][i] = (dxb[j][i] + dxb[j][i+1] + dxb[j+1][i] + dxb[j+1][i+1]) / 4, optionally masked by mask > 0 (ReLU backward)
+__global__ void box2_bwd_k(const float* __restrict__ dxb, const float* __restrict__ mask, float* __restrict__ dx, long NC, int H, int W) {
+  const int WB = W + 1;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * H * W) return;
+  const int ix = (int)(i % W), iy = (int)(i / W % H);
+  const long nc = i / ((long)W * H);
+  const float* p = dxb + nc * (H + 1) * WB + (long)iy * WB + ix;
+  float v = 0.25f * (p[0] + p[1] + p[WB] + p[WB + 1]);
+  if (mask && !(mask[i] > 0.f)) v = 0.f;
+  dx[i] = v;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -742,6 +772,20 @@ int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, i
   hipLaunchKernelGGL(deprocess_u8_k, dim3(N), dim3(256), 0, (hipStream_t)stream, x, out, C, HW, rescale, inv_std[0], inv_std[1],
                      inv_std[2], mean[0], mean[1], mean[2]);
   AGL_CHECK_LAUNCH("agl_deprocess_u8");
+  return AGL_OK;
+}
+
+int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream) {
+  AGL_REQUIRE(x && xb && NC > 0 && H > 0 && W > 0, "agl_box2_fwd: bad argument");
+  LAUNCH1D(box2_fwd_k, NC * (H + 1) * (W + 1), x, xb, NC, H, W);
+  AGL_CHECK_LAUNCH("agl_box2_fwd");
+  return AGL_OK;
+}
+
+int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H, int W, void* stream) {
+  AGL_REQUIRE(dxb && dx && NC > 0 && H > 0 && W > 0, "agl_box2_bwd: bad argument");
+  LAUNCH1D(box2_bwd_k, NC * H * W, dxb, mask, dx, NC, H, W);
+  AGL_CHECK_LAUNCH("agl_box2_bwd");
   return AGL_OK;
 }
 

@@ -96,6 +96,10 @@ int agl_axpby(const float* a, const float* b, float alpha, float beta, float* ou
 int agl_gather_rows(const float* src, const long long* rows, float* out, long R, long len, int accumulate, void* stream);
 int agl_scatter_rows(const float* src, const long long* rows, float* out, long R, long len, void* stream);
 /* F.avg_pool2d(k=2) (discriminator.py:25-26) / nn.AdaptiveAvgPool2d(8) on 16x16 (generator_obj_att128.py:486) */
+/* 2x2 stride-1 box filter over the zero-extended map ((H+1) x (W+1) outputs): avg_pool2(conv3x3(x, pad 1)) is the 3x3
+ * stride-2 unpadded convolution of it (models/discriminator.py:25-26,90-97 down-sampling blocks) */
+int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream);
+int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H, int W, void* stream);
 int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream);
 int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate,
                      void* stream);

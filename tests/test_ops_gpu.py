@@ -440,3 +440,31 @@ def test_relu_gradient_masked_by_consumer():
         yg.backward(dev(gy))
         for nm, a, r in zip(("dx", "dw1", "db1", "dw2", "db2"), tg, ts):
             close(a.grad, r.grad, 2e-4, nm)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16, 24), (2, 64, 32, 128), (5, 128, 8, 256), (4, 256, 4, 64), (130, 64, 2, 64)])
+def test_conv3x3_avgpool_box_form(shape):
+    """avg_pool2(conv3x3(x)) as a 3x3 stride-2 convolution of the box-filtered, zero-extended input: forward and all
+    gradients against torch, and against the pooled-filter (4x4 stride-2) form."""
+    from agl import functional as F
+    N, Cin, H, Cout = shape
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5), rn(Cout, seed=2)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = TF.avg_pool2d(TF.conv2d(xr, wr, br, padding=1), 2)
+    gy = rn(*yr.shape, seed=3)
+    yr.backward(gy)
+    outs = []
+    for box in (True, False):
+        F.BOX_FORM = box
+        try:
+            xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+            yg = F.conv3x3_avgpool2(xg, wg, bg)
+            yg.backward(dev(gy))
+        finally:
+            F.BOX_FORM = True
+        close(yg, yr, 3e-5, f"y (box={box})")
+        close(xg.grad, xr.grad, 1e-4, f"dx (box={box})")
+        close(wg.grad, wr.grad, 1e-4, f"dw (box={box})")
+        close(bg.grad, br.grad, 1e-4, f"db (box={box})")
+        outs.append(yg.detach())
+    close(outs[0], outs[1], 2e-5, "box form vs pooled-filter form")
