@@ -5,6 +5,8 @@ sequence of libagl.so launches (agl.lib).  Reference call sites are cited per op
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -371,7 +373,10 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         x, xb, w3 = ctx.saved_tensors
         dy = _c(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and BOX_BWD:
+            dxb = L.conv2d_bwd_data(dy, w3, (xshape[2] + 1, xshape[3] + 1), 2, 0)
+            dx = L.box2_bwd(dxb, x if x_relu else None)
+        elif ctx.needs_input_grad[0]:
             w4 = torch.empty(w3.shape[:2] + (4, 4), dtype=torch.float32, device=w3.device)
             L.call("agl_pool_fuse_weight_fwd", L.ptr(w3), L.ptr(w4), w3.shape[0] * w3.shape[1], L.stream())
             dx = L.conv2d_bwd_data(dy, w4, (xshape[2], xshape[3]), 2, 1, pos_mask=x if x_relu else None)
@@ -390,6 +395,7 @@ class _Conv3x3AvgPool(torch.autograd.Function):
 
 
 BOX_FORM = True     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
+BOX_BWD = os.environ.get("AGL_BOX_BWD", "0") == "1"   # input gradient through the 3x3/stride-2 phases + box transpose
 
 
 def conv3x3_avgpool2(x, w3, bias=None, in_relu=False, x_relu=False):

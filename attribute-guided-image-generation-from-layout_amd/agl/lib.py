@@ -27,6 +27,7 @@ SIGNATURES = {
     "agl_set_conv_patch": (_I, [_I]),
     "agl_set_conv_pos": (_I, [_I]),
     "agl_conv2d_fwd_ws_bytes": (_L, [_I] * 9),
+    "agl_conv2d_bwd_data_ws_bytes": (_L, [_I] * 10),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
     "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
     "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
@@ -217,11 +218,7 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     if out is None:
         assert not accumulate
         out = torch.empty((N, Cin, IH, IW), dtype=torch.float32, device=dy.device)
-    tpa = -(-ks // stride)
-    need = load().agl_conv2d_splitk_ws_bytes(Cin, N * (-(-IH // stride)) * (-(-IW // stride)), stride * stride,
-                                             Cout * tpa * tpa, out.numel())
-    if stride == 1 and (IH, IW) == (OH, OW):      # position-major path on small maps (forward form with flipped taps)
-        need = max(need, load().agl_conv2d_fwd_ws_bytes(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0))
+    need = load().agl_conv2d_bwd_data_ws_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad)
     ws = workspace(need, dy.device) if need else None
     call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), stream())

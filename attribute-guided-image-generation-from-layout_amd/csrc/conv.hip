@@ -214,6 +214,9 @@ struct BwdDataGenProb {
   unsigned inv_tt, inv_tsw;
   unsigned a_bytes, b_bytes;
   int splits; long slab; float* part;
+  int tap_split;     // 1: a phase with tt taps uses (splits / TTMAX) * tt of the `splits` slabs, so every workgroup reduces
+                     // over the same length (the phases are 4:2:2:1 in size); its remaining slabs are stored as zeros
+  static constexpr int TTMAX = ((KS + S - 1) / S) * ((KS + S - 1) / S);
 
   __device__ bool setup(int zz) {
     const int z = zz / splits, sp = zz - z * splits;
@@ -230,8 +233,9 @@ struct BwdDataGenProb {
     inv_tt = tt > 1 ? (unsigned)((0x100000000ULL + tt - 1) / tt) : 0u;
     inv_tsw = 65536u / tsw + 1u;
     const int K = Cout * tt;
-    const int per = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-    kbeg = sp * per; kend = min(K, kbeg + per);
+    const int s_p = tap_split ? (splits / TTMAX) * tt : splits;
+    const int per = s_p > 0 ? ((K + s_p - 1) / s_p + BK - 1) / BK * BK : 0;
+    kbeg = sp * per; kend = sp < s_p ? min(K, kbeg + per) : kbeg;
     if (kend < kbeg) kend = kbeg;                    // an empty split still stores its (zero) slab
     if (splits > 1) part += (long)sp * slab;
     return true;
@@ -1427,6 +1431,38 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   return AGL_OK;
 }
 
+// 3x3 stride-2 input gradient: split plan.  Small maps: tap-proportional splits (balanced workgroups, 4*s slabs);
+// larger maps: uniform splits.
+static int bwd32_plan(int N, int Cin, int IH, int IW, int Cout, int* tap_split) {
+  const long maxNc = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2);
+  if (IH <= 9 && IW <= 9) {
+    *tap_split = 1;
+    return 4 * fwd_splits(Cin, maxNc, 9, Cout, nullptr);        // nine (phase, tap) slices of K = Cout each
+  }
+  *tap_split = 0;
+  return fwd_splits(Cin, maxNc, 4, Cout * 9 / 4, nullptr);
+}
+
+// Scratch the input-gradient pass wants (split-K slabs, position-major operands on small maps).
+long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad) {
+  const long out_numel = (long)N * Cin * IH * IW;
+  long need;
+  if (stride == 2 && ks == 3) {
+    int ts;
+    const int s = bwd32_plan(N, Cin, IH, IW, Cout, &ts);
+    need = s > 1 ? (long)s * out_numel * 4 : 0;
+  } else {
+    const int tpa = (ks + stride - 1) / stride;
+    need = agl_conv2d_splitk_ws_bytes(Cin, (long)N * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride), stride * stride,
+                                      Cout * tpa * tpa, out_numel);
+  }
+  if (stride == 1 && IH == OH && IW == OW && pos_ok(N, Cout, OH, OW, Cin, ks, 0)) {
+    const long pn = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad).total();
+    if (pn > need) need = pn;
+  }
+  return need;
+}
+
 // dx[N,Cin,IH,IW] = conv2d_backward_input(dy[N,Cout,OH,OW], w[Cout,Cin,ks,ks]).  Also the forward of
 // ConvTranspose2d (weight [C_in_T = Cout][C_out_T = Cin][ks][ks]).
 int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
@@ -1463,7 +1499,9 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   const int phases = stride * stride, Kp = Cout * tpa * tpa;
   int per = 0, rc = AGL_ERR_ARG;
   int splits = fwd_splits(Cin, (long)N * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride), phases, Kp, &per);
-  if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; per = Kp; }
+  int tap_split = 0;
+  if (stride == 2 && ks == 3) splits = bwd32_plan(N, Cin, IH, IW, Cout, &tap_split);
+  if (splits > 1 && (!ws || ws_bytes < (long)splits * out_numel * 4)) { splits = 1; per = Kp; tap_split = 0; }
 #define AGL_BWD(KS_, S_)                                                                                            \
   {                                                                                                                 \
     BwdDataProb<KS_, S_> p;                                                                                         \
@@ -1481,6 +1519,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     p.a_bytes = (unsigned)((long)Cout * Cin * 9 * 4); p.b_bytes = (unsigned)((long)N * Cout * OH * OW * 4);
     long maxNc = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2);
     p.splits = splits; p.slab = out_numel; p.part = (float*)ws; p.kbeg = 0; p.kend = 0; p.M = Cin; p.Nc = 0;
+    p.tap_split = tap_split;
     rc = launch_igemm(p, Cin, maxNc, 4 * splits, st, "agl_conv2d_bwd_data(3x3 stride 2)");
   } else if (stride == 2) AGL_BWD(4, 2)
   else switch (ks) {

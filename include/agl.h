@@ -40,6 +40,7 @@ int agl_get_conv_precision(void);
 int agl_set_conv_patch(int on);
 int agl_set_conv_pos(int on);   /* 0: no position-major path on <= 8x8 maps (A/B tests) */
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
+long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,

@@ -44,6 +44,9 @@ CONV_CASES = [
     (2, 16, 6, 6, 20, 1, 1, 1),       # 1x1 with padding (LayoutEncoder c0)
     (70, 170, 1, 1, 128, 1, 1, 0),    # Linear as 1x1
     (1, 3, 10, 12, 8, 3, 1, 1),       # first D conv, ragged
+    (3, 64, 17, 17, 128, 3, 2, 0),    # 3x3 stride 2 (box form of conv3x3 + avg-pool): phases of 4:2:2:1 taps
+    (40, 32, 5, 5, 64, 3, 2, 0),      # ... on a small map (tap-proportional splits)
+    (2, 16, 9, 7, 24, 3, 2, 1),       # ... padded, ragged
 ]
 
 
