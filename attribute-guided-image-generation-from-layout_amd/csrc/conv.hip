@@ -889,6 +889,7 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
 int g_pos_all_ks = 0;         // experiments: also 3x3 / 4x4 kernels (agl_set_conv_pos(-1))
 int g_pos_min_n = 96;         // smallest image count for the position-major path (agl_set_conv_pos(n > 1) sets it)
 int g_use_pos = 1;            // agl_set_conv_pos(0): no position-major path on small maps (A/B tests)
+int g_use_patch_s2 = 1;       // stride-2 forward form of the patch kernel (agl_set_conv_patch(2) = stride-1 only)
 int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
 int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
 
@@ -1030,7 +1031,7 @@ int launch_small_cout(const float* x, const float* w, const float* bias, const f
 struct PatchArgs {
   const float* x; const float* w; const float* bias; const float* pos_mask; float* y; float* part;
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up); OH, OW: output map
-  int pad, up, in_relu, relu, accumulate;
+  int pad, up, in_relu, relu, accumulate, stride;
   int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
   int splits, c_per_split;
   long slab;
@@ -1038,9 +1039,11 @@ struct PatchArgs {
 };
 
 // WVEC: the weight slice of a row is contiguous in memory (forward pass): stage it with coalesced 16-byte loads.
-template <int KS, int TW, int TH, int TI, int CB, int BM, bool WVEC>
+// S: convolution stride (forward form only): the patch covers S*(T-1)+KS input rows/columns and a lane's pixel offset
+// is S*(py*PW + px) — the 4x4/stride-2 encoder layers and the 3x3/stride-2 box form of the discriminator blocks.
+template <int KS, int TW, int TH, int TI, int CB, int BM, bool WVEC, int S = 1>
 __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
-  constexpr int BN = 128, PH = TH + KS - 1, PW = TW + KS - 1, PS = PH * PW, KC = CB * KS * KS;
+  constexpr int BN = 128, PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, PS = PH * PW, KC = CB * KS * KS;
   constexpr int NP = TI * CB * PS, PL = (NP + NT - 1) / NT, WL = (KC * BM + NT - 1) / NT;
   constexpr int LDW = BM + 1;                                  // odd pitch: both staging patterns stay (nearly) conflict free
   constexpr int QR = KC / 4, WV = (QR * BM + NT - 1) / NT;     // WVEC: float4 per row, float4 loads per thread
@@ -1077,7 +1080,7 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
   for (int i = 0; i < PL; ++i) {
     const int e = tid + NT * i;
     const int ti = e / (CB * PS), r = e - ti * (CB * PS), c = r / PS, q = r - c * PS, yy = q / PW, xx = q - yy * PW;
-    const int img = img0 + ti, ly = ty0 - p.pad + yy, lx = tx0 - p.pad + xx;
+    const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
     const bool ok = e < NP && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
     poff_src[i] = ok ? (unsigned)(((img * p.Cin + c) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB;
   }
@@ -1148,7 +1151,7 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
   for (int jt = 0; jt < WTN; ++jt) {
     const int j = wn * 32 * WTN + 32 * jt + l31;
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
-    ppix[jt] = ti * (CB * PS) + py * PW + px;
+    ppix[jt] = ti * (CB * PS) + S * (py * PW + px);
   }
   const int arow0 = wm * 32 * WTM + l31;
 
@@ -1217,9 +1220,11 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
 // returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back to the im2col kernel)
 int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   if (g_conv_precision != 0) return -1;                       // fp32 path only (bf16 mode uses the im2col kernel)
-  if (ks != 3) return -1;                                     // 5x5 (ConvLSTM at 8x8): measured no faster than im2col
+  const bool s2 = a.stride == 2;
+  if (s2 && (a.flip || a.up || (ks != 3 && ks != 4) || !g_use_patch_s2)) return -1;
+  if (!s2 && ks != 3) return -1;                              // 5x5 (ConvLSTM at 8x8): measured no faster than im2col
   if (a.flip && a.OW < 32) return -1;                         // input-gradient form: wins on >= 32-wide maps only
-  const int cb = ks == 3 ? 8 : 2;
+  const int cb = s2 ? 4 : 8;
   if (a.Cin % cb != 0 || a.Cout < 48) return -1;
   int geo;
   if (a.OW >= 16 && a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
@@ -1251,11 +1256,21 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
     if (bm == 64) hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, CB_, 64, WV_>), g, dim3(NT), 0, st, a);     \
     else hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, CB_, 128, WV_>), g, dim3(NT), 0, st, a);            \
   } while (0)
-  if (ks == 3 && !a.flip) {       // forward: weight rows contiguous -> vector staging
+#define AGL_PC2(KS_, TW_, TH_, TI_)                                                                             \
+  do {                                                                                                          \
+    if (bm == 64) hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, 4, 64, true, 2>), g, dim3(NT), 0, st, a);   \
+    else hipLaunchKernelGGL((patch_conv<KS_, TW_, TH_, TI_, 4, 128, true, 2>), g, dim3(NT), 0, st, a);          \
+  } while (0)
+  if (s2 && ks == 3) {
+    if (geo == 0) AGL_PC2(3, 16, 8, 1); else if (geo == 1) AGL_PC2(3, 8, 8, 2); else AGL_PC2(3, 4, 4, 8);
+  } else if (s2) {
+    if (geo == 0) AGL_PC2(4, 16, 8, 1); else if (geo == 1) AGL_PC2(4, 8, 8, 2); else AGL_PC2(4, 4, 4, 8);
+  } else if (ks == 3 && !a.flip) {       // forward: weight rows contiguous -> vector staging
     if (geo == 0) AGL_PC(3, 16, 8, 1, 8, true); else if (geo == 1) AGL_PC(3, 8, 8, 2, 8, true); else AGL_PC(3, 4, 4, 8, 8, true);
   } else {
     AGL_PC(3, 16, 8, 1, 8, false);
   }
+#undef AGL_PC2
 #undef AGL_PC
   AGL_CHECK_LAUNCH(name);
   if (splits > 1) {
@@ -1348,7 +1363,7 @@ int agl_set_conv_precision(int mode) {
   return AGL_OK;
 }
 int agl_get_conv_precision(void) { return g_conv_precision; }
-int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; return AGL_OK; }
+int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; g_use_patch_s2 = on == 1; return AGL_OK; }
 int agl_set_conv_pos(int on) {
   g_use_pos = on ? 1 : 0;
   if (on > 1) g_pos_min_n = on;
@@ -1397,10 +1412,11 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (ws && ws_bytes >= pl.total())
       return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st);
   }
-  if (stride == 1 && g_use_patch) {
+  if (g_use_patch) {
     PatchArgs a;
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu; a.accumulate = accumulate;
+    a.stride = stride;
     a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0;
     a.x_bytes = (unsigned)((long)N * Cin * H * W * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
     const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_fwd(patch)");
@@ -1489,6 +1505,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     PatchArgs a;
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
+    a.stride = 1;
     a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1;
     a.x_bytes = (unsigned)((long)N * Cout * OH * OW * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
     const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_bwd_data(patch)");

@@ -471,3 +471,23 @@ def test_conv3x3_avgpool_box_form(shape):
         close(bg.grad, br.grad, 1e-4, f"db (box={box})")
         outs.append(yg.detach())
     close(outs[0], outs[1], 2e-5, "box form vs pooled-filter form")
+
+
+@pytest.mark.parametrize("case", [(4, 64, 32, 128, 4, 1), (5, 32, 16, 64, 4, 1), (9, 16, 8, 96, 4, 1), (4, 64, 33, 128, 3, 0), (6, 32, 17, 64, 3, 0),
+                                  (10, 24, 9, 72, 3, 0), (2, 128, 64, 64, 4, 1)])
+def test_patch_conv_stride2_forward(case):
+    """4x4/stride-2 and 3x3/stride-2 forward convolutions on the LDS-patch kernel (stride template): against torch and
+    against the im2col kernel (agl_set_conv_patch(2) = stride-1 patches only), with bias / input ReLU / output ReLU."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, p = case
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    yr = TF.relu(TF.conv2d(TF.relu(x), w, b, stride=2, padding=p))
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = L.conv2d_fwd(xd, wd, bd, 2, p, in_relu=True, relu=True)
+    close(y, yr, 2e-5, "y")
+    L.call("agl_set_conv_patch", 2)
+    try:
+        y_ref = L.conv2d_fwd(xd, wd, bd, 2, p, in_relu=True, relu=True)
+    finally:
+        L.call("agl_set_conv_patch", 1)
+    close(y, y_ref, 5e-6, "patch vs im2col")

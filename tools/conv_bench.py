@@ -8,6 +8,8 @@ from agl import lib as L
 dev = "cuda:0"
 if os.environ.get("AGL_NOPATCH"):
     L.call("agl_set_conv_patch", 0)
+if os.environ.get("AGL_NOPATCH_S2"):
+    L.call("agl_set_conv_patch", 2)
 if os.environ.get("AGL_POS_MIN_N"):
     L.call("agl_set_conv_pos", int(os.environ["AGL_POS_MIN_N"]))
 if os.environ.get("AGL_POS_ALL"):
@@ -38,6 +40,9 @@ SHAPES = [
     ("SPADE3.sh 64>128 k3 @64", N, 64, 64, 128, 3, 1, 1),
     ("DEC.dc3(as conv) 64>128 k4s2 @64", N, 64, 64, 128, 4, 2, 1),
     ("DEC.c4 64>3 k7 @64", N, 64, 64, 3, 7, 1, 3),
+    ("Dobj.1 box 64>128 k3s2 @33", O, 64, 33, 128, 3, 2, 0),
+    ("Dobj.2 box 128>256 k3s2 @17", O, 128, 17, 256, 3, 2, 0),
+    ("Dobj.3 box 256>512 k3s2 @9", O, 256, 9, 512, 3, 2, 0),
     ("Dimg.0b 64>64 k3 @64", N, 64, 64, 64, 3, 1, 1),
     ("Dimg.1b 64>128 k3 @32", N, 64, 32, 128, 3, 1, 1),
     ("Dobj.0a 3>64 k3 @32", O, 3, 32, 64, 3, 1, 1),
