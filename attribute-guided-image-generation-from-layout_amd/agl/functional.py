@@ -353,9 +353,10 @@ class _Conv3x3AvgPool(torch.autograd.Function):
     """avg_pool2d(conv2d(x, w3, bias, padding=1), 2) with the cheapest exact form per pass:
       forward         3x3 stride-2 convolution of the box-filtered zero-extended input xb      (9 taps per output)
       weight gradient 3x3 stride-2 weight gradient against xb                                  (9 taps)
-      input gradient  4x4 stride-2 input gradient with the pooled filter w4 (four equally sized stride phases of 2x2
-                      taps; the 3x3/stride-2 phases are 4:2:2:1 in size and measured slower on the small maps), with the
-                      ReLU mask of a producer that left its ReLU backward to this consumer (x_relu)."""
+      input gradient  maps >= 16 wide: 3x3 stride-2 input gradient w.r.t. xb (stride phases of 4:2:2:1 taps, 9 in total)
+                      followed by the transposed box filter; smaller maps: 4x4 stride-2 input gradient with the pooled
+                      filter w4 (four equally sized phases of 2x2 taps — the unequal phases measured slower there);
+                      either way with the ReLU mask of a producer that left its ReLU backward to this consumer."""
 
     @staticmethod
     def forward(ctx, x, w3, bias, x_relu):
@@ -373,7 +374,7 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         x, xb, w3 = ctx.saved_tensors
         dy = _c(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0] and BOX_BWD:
+        if ctx.needs_input_grad[0] and (BOX_BWD or xshape[2] >= BOX_BWD_MIN):
             dxb = L.conv2d_bwd_data(dy, w3, (xshape[2] + 1, xshape[3] + 1), 2, 0)
             dx = L.box2_bwd(dxb, x if x_relu else None)
         elif ctx.needs_input_grad[0]:
@@ -396,6 +397,8 @@ class _Conv3x3AvgPool(torch.autograd.Function):
 
 BOX_FORM = True     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
 BOX_BWD = os.environ.get("AGL_BOX_BWD", "0") == "1"   # input gradient through the 3x3/stride-2 phases + box transpose
+BOX_BWD_MIN = int(os.environ.get("AGL_BOX_BWD_MIN", "16"))   # ... used from this map size up (measured: 0.24 vs 0.34 ms at
+                                                             # 32x32 and 16x16, but 0.48 vs 0.30 ms at 8x8)
 
 
 def conv3x3_avgpool2(x, w3, bias=None, in_relu=False, x_relu=False):
