@@ -349,6 +349,65 @@ class _Box2(torch.autograd.Function):
         return L.box2_bwd(_c(dxb), x), None
 
 
+_grid_maps = {}
+
+
+def _grid_map(kind: str, blocks: int, f: int, device):
+    """Index maps between the grids of an image made of `blocks` constant f x f blocks per axis (a nearest up-sampled
+    map) and of 3x3 convolutions of it, cached on the device as (map, range starts of the inverse):
+      'up3'   8  -> 3 per block : every block three times (a 3x3 convolution of this grid takes, at offsets 0/1/2 of a
+              block, exactly the values it takes at the first / an interior / the last row of the f-fold up-sampling);
+      '3to5'  3 per block -> 5 per block: classes (first, second, interior, last but one, last) read (0, 1, 1, 1, 2);
+      '5tof'  5 per block -> f per block: rows 0, 1, 2..f-3, f-2, f-1 read classes 0, 1, 2, 3, 4   (f >= 5);
+      '3tof'  3 per block -> f per block: rows 0, 1..f-2, f-1 read classes 0, 1, 2                 (f >= 3)."""
+    key = (kind, blocks, f, str(device))
+    if key not in _grid_maps:
+        if kind == "up3":
+            src, per, pat = blocks, 3, [0, 0, 0]
+            m = [b for b in range(blocks) for _ in range(3)]
+        else:
+            pat = {"3to5": [0, 1, 1, 1, 2], "5tof": [0, 1] + [2] * (f - 4) + [3, 4], "3tof": [0] + [1] * (f - 2) + [2]}[kind]
+            spb = {"3to5": 3, "5tof": 5, "3tof": 3}[kind]            # source cells per block
+            src = blocks * spb
+            m = [b * spb + c for b in range(blocks) for c in pat]
+        lo = [0] * (src + 1)
+        for v in m:
+            lo[v + 1] += 1
+        for i in range(src):
+            lo[i + 1] += lo[i]
+        _grid_maps[key] = (torch.tensor(m, dtype=torch.int32, device=device), torch.tensor(lo, dtype=torch.int32, device=device), src)
+    return _grid_maps[key]
+
+
+class _GridGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, lo):
+        x = _c(x)
+        N, Cc, h, w = x.shape
+        H = m.numel()
+        assert h == w == lo.numel() - 1
+        y = torch.empty((N, Cc, H, H), dtype=torch.float32, device=x.device)
+        L.call("agl_grid_gather_fwd", L.ptr(x), L.ptr(m, torch.int32), L.ptr(m, torch.int32), L.ptr(y), N * Cc, h, w, H, H, L.stream())
+        ctx.save_for_backward(lo)
+        ctx.shape = (N, Cc, h, w, H)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lo,) = ctx.saved_tensors
+        N, Cc, h, w, H = ctx.shape
+        dx = torch.empty((N, Cc, h, w), dtype=torch.float32, device=dy.device)
+        L.call("agl_grid_gather_bwd", L.ptr(_c(dy)), L.ptr(lo, torch.int32), L.ptr(lo, torch.int32), L.ptr(dx), N * Cc, h, w, H, H, L.stream())
+        return dx, None, None
+
+
+def grid_gather(x, kind: str, blocks: int, f: int = 0):
+    """Square-map index gather along both axes with one of the cached maps of _grid_map."""
+    m, lo, src = _grid_map(kind, blocks, f, x.device)
+    assert x.shape[2] == x.shape[3] == src, (x.shape, kind, blocks, f)
+    return _GridGather.apply(x, m, lo)
+
+
 class _Conv3x3AvgPool(torch.autograd.Function):
     """avg_pool2d(conv2d(x, w3, bias, padding=1), 2) with the cheapest exact form per pass:
       forward         3x3 stride-2 convolution of the box-filtered zero-extended input xb      (9 taps per output)

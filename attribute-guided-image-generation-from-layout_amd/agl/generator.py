@@ -229,15 +229,34 @@ class SPADE(nn.Module):
         self.mlp_gamma = A.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
         self.mlp_beta = A.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
 
+    block_grids = True     # False: both convolutions on the full-resolution grid (A/B tests)
+
     def forward(self, x, segmap, relu=False):
         f = x.shape[2] // segmap.shape[2]
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
-        # actv feeds exactly one convolution, which masks its input gradient by actv > 0 (no separate ReLU-backward pass)
-        actv = self.mlp_shared[0](segmap, relu=True, up=up, relu_grad_by_consumer=True)
+        assert segmap.shape[2] == segmap.shape[3]
         w = F.concat_rows(self.mlp_gamma.weight, self.mlp_beta.weight)
         b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
-        gb = F.conv2d(actv, w, b, 1, 1, x_relu=True)
+        nb = segmap.shape[2]
+        if self.block_grids and f >= 4:
+            # The f-fold nearest up-sampling of the segmentation map is constant on f x f blocks, so a 3x3 convolution of
+            # it takes only 3 distinct values per block and axis (first row / interior / last row), and a 3x3
+            # convolution of THAT only 5 (rows 0, 1, interior, f-2, f-1).  Both convolutions therefore run on class
+            # grids — 3 cells per block for mlp_shared, 5 per block for gamma|beta when f >= 8 — and the results are
+            # expanded by index maps; values are the ones the full-resolution convolutions produce (same taps, same
+            # order), gradients are summed over each class (agl_grid_gather_bwd).  64 px: 24x24 / 40x40 instead of
+            # 64x64 for SPADE_3; 128 px: 24x24 / 80x80 instead of 128x128.
+            a3 = self.mlp_shared[0](F.grid_gather(segmap, "up3", nb), relu=True)
+            if f >= 8:
+                gb5 = F.conv2d(F.grid_gather(a3, "3to5", nb), w, b, 1, 1)
+                gb = F.grid_gather(gb5, "5tof", nb, f)
+            else:
+                gb = F.conv2d(F.grid_gather(a3, "3tof", nb, f), w, b, 1, 1)
+        else:
+            # actv feeds exactly one convolution, which masks its input gradient by actv > 0 (no separate ReLU-backward pass)
+            actv = self.mlp_shared[0](segmap, relu=True, up=up, relu_grad_by_consumer=True)
+            gb = F.conv2d(actv, w, b, 1, 1, x_relu=True)
         n = self.param_free_norm
         return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training)
 

@@ -47,6 +47,8 @@ SIGNATURES = {
     "agl_axpby": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "agl_gather_rows": (_I, [_P, _P, _P, _L, _L, _I, _P]),
     "agl_scatter_rows": (_I, [_P, _P, _P, _L, _L, _P]),
+    "agl_grid_gather_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_grid_gather_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_box2_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
     "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),

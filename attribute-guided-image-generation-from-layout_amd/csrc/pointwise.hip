@@ -532,6 +532,30 @@ __global__ void box2_bwd_k(const float* __restrict__ dxb, const float* __restric
   dx[i] = v;
 }
 
+// y[nc][Y][X] = x[nc][my[Y]][mx[X]] for monotone index maps (nearest up-sampling by any factor, and the block-class
+// grids of agl.generator.SPADE).  Backward: dx[nc][i][j] = sum of dy over the preimage rectangle [ylo[i], ylo[i+1]) x
+// [xlo[j], xlo[j+1]) — every cell has one owner and a fixed order (deterministic, no atomics).
+__global__ void grid_gather_fwd_k(const float* __restrict__ x, const int* __restrict__ my, const int* __restrict__ mx, float* __restrict__ y,
+                                  long NC, int h, int w, int H, int W) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * H * W) return;
+  const int X = (int)(i % W), Y = (int)(i / W % H);
+  const long nc = i / ((long)W * H);
+  y[i] = x[(nc * h + my[Y]) * w + mx[X]];
+}
+__global__ void grid_gather_bwd_k(const float* __restrict__ dy, const int* __restrict__ ylo, const int* __restrict__ xlo, float* __restrict__ dx,
+                                  long NC, int h, int w, int H, int W) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NC * h * w) return;
+  const int xj = (int)(i % w), yi = (int)(i / w % h);
+  const long nc = i / ((long)w * h);
+  const float* p = dy + nc * H * W;
+  float s = 0.f;
+  for (int Y = ylo[yi]; Y < ylo[yi + 1]; ++Y)
+    for (int X = xlo[xj]; X < xlo[xj + 1]; ++X) s += p[(long)Y * W + X];
+  dx[i] = s;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, ...)                                                                   \
@@ -786,6 +810,20 @@ int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H,
   AGL_REQUIRE(dxb && dx && NC > 0 && H > 0 && W > 0, "agl_box2_bwd: bad argument");
   LAUNCH1D(box2_bwd_k, NC * H * W, dxb, mask, dx, NC, H, W);
   AGL_CHECK_LAUNCH("agl_box2_bwd");
+  return AGL_OK;
+}
+
+int agl_grid_gather_fwd(const float* x, const int* map_y, const int* map_x, float* y, long NC, int h, int w, int H, int W, void* stream) {
+  AGL_REQUIRE(x && map_y && map_x && y && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0, "agl_grid_gather_fwd: bad argument");
+  LAUNCH1D(grid_gather_fwd_k, NC * H * W, x, map_y, map_x, y, NC, h, w, H, W);
+  AGL_CHECK_LAUNCH("agl_grid_gather_fwd");
+  return AGL_OK;
+}
+
+int agl_grid_gather_bwd(const float* dy, const int* lo_y, const int* lo_x, float* dx, long NC, int h, int w, int H, int W, void* stream) {
+  AGL_REQUIRE(dy && lo_y && lo_x && dx && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0, "agl_grid_gather_bwd: bad argument");
+  LAUNCH1D(grid_gather_bwd_k, NC * h * w, dy, lo_y, lo_x, dx, NC, h, w, H, W);
+  AGL_CHECK_LAUNCH("agl_grid_gather_bwd");
   return AGL_OK;
 }
 

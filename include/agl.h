@@ -101,6 +101,11 @@ int agl_scatter_rows(const float* src, const long long* rows, float* out, long R
  * stride-2 unpadded convolution of it (models/discriminator.py:25-26,90-97 down-sampling blocks) */
 int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream);
 int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H, int W, void* stream);
+/* y[nc][Y][X] = x[nc][map_y[Y]][map_x[X]] for monotone non-decreasing index maps (device int arrays of H / W entries);
+ * backward sums dy over each source cell's preimage: lo_y / lo_x hold h+1 / w+1 range starts (lo[h] = H).  Nearest
+ * up-sampling (models/spade/networks/normalization.py:100) and the block-class grids of the SPADE restructure. */
+int agl_grid_gather_fwd(const float* x, const int* map_y, const int* map_x, float* y, long NC, int h, int w, int H, int W, void* stream);
+int agl_grid_gather_bwd(const float* dy, const int* lo_y, const int* lo_x, float* dx, long NC, int h, int w, int H, int W, void* stream);
 int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream);
 int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate,
                      void* stream);

@@ -491,3 +491,42 @@ def test_patch_conv_stride2_forward(case):
     finally:
         L.call("agl_set_conv_patch", 1)
     close(y, y_ref, 5e-6, "patch vs im2col")
+
+
+def test_grid_gather_and_spade_block_grids():
+    """agl_grid_gather_fwd/bwd against torch indexing for every cached map kind, and SPADE with the two convolutions on
+    the block-class grids (3 / 5 cells per constant block) against the same module on the full-resolution grid:
+    outputs and all gradients must agree to fp32 rounding for f = 4 (3-class grid only), 8 and 16."""
+    from agl import functional as F
+    from agl.generator import SPADE
+    for kind, blocks, f in (("up3", 8, 0), ("3to5", 8, 0), ("5tof", 8, 8), ("5tof", 4, 16), ("3tof", 8, 4)):
+        m, lo, src = F._grid_map(kind, blocks, f, torch.device(DEV))
+        x = rn(2, 3, src, src).to(DEV).requires_grad_(True)
+        y = F.grid_gather(x, kind, blocks, f)
+        mi = m.long()
+        ref = x.detach()[:, :, mi][:, :, :, mi]
+        assert torch.equal(y, ref), kind
+        g = rn(*y.shape, seed=1).to(DEV)
+        y.backward(g)
+        xr = x.detach().clone().requires_grad_(True)
+        xr[:, :, mi][:, :, :, mi].backward(g)
+        close(x.grad, xr.grad, 1e-5, "grid_gather backward " + kind)
+    for C, S in ((32, 32), (16, 64), (8, 128)):
+        torch.manual_seed(C)
+        sp = SPADE(C, 64).to(DEV)
+        x0, seg0 = rn(2, C, S, S), rn(2, 64, 8, 8, seed=3)
+        gy = rn(2, C, S, S, seed=4).to(DEV)
+        res = []
+        for flag in (True, False):
+            sp.block_grids = flag
+            sp.zero_grad()
+            x, seg = dev(x0).requires_grad_(True), dev(seg0).requires_grad_(True)
+            y = sp(x, seg, relu=True)
+            y.backward(gy)
+            res.append((y.detach(), x.grad, seg.grad, [p.grad.clone() for p in sp.parameters()]))
+        (y1, dx1, ds1, gp1), (y2, dx2, ds2, gp2) = res
+        close(y1, y2, 1e-5, f"SPADE y S={S}")
+        close(dx1, dx2, 1e-5, f"SPADE dx S={S}")
+        close(ds1, ds2, 2e-4, f"SPADE dseg S={S}")
+        for a, r in zip(gp1, gp2):
+            close(a, r, 2e-4, f"SPADE parameter gradient S={S}")
