@@ -78,3 +78,32 @@ def test_oracle_estimate_and_deprocess_small_cases():
     b2 = OH.imagenet_deprocess_batch(torch.zeros(1, 3, 1, 1), rescale=False)
     assert b2.view(-1).tolist() == [int(np.float32(0.485) * np.float32(255)), int(np.float32(0.456) * np.float32(255)),
                                     int(np.float32(0.406) * np.float32(255))]
+
+
+def test_spade_block_class_index_maps():
+    """Host-side index maps of the SPADE restructure (agl.functional._grid_map): composing 'up3' -> conv -> '3to5' ->
+    conv -> '5tof' must reproduce, row by row, the classes a 3x3 convolution sees on an f-fold nearest up-sampling:
+    checked by brute force on 1-D signals with a 3-tap box convolution (the maps act per axis)."""
+    from agl import functional as F
+    cpu = torch.device("cpu")
+    for blocks, f in ((8, 8), (8, 16), (4, 8)):
+        g = torch.Generator().manual_seed(f + blocks)
+        seg = torch.randn(blocks, generator=g)
+        conv = lambda v: torch.nn.functional.conv1d(v.view(1, 1, -1), torch.tensor([[[0.3, -1.1, 0.7]]]), padding=1).view(-1)
+        full = seg.repeat_interleave(f)
+        a_full = torch.relu(conv(full))
+        gb_full = conv(a_full)
+        m_up3, lo_up3, _ = F._grid_map("up3", blocks, 0, cpu)
+        m35, lo35, _ = F._grid_map("3to5", blocks, 0, cpu)
+        m5f, lo5f, src5 = F._grid_map("5tof", blocks, f, cpu)
+        m3f, _, _ = F._grid_map("3tof", blocks, f, cpu)
+        a3 = torch.relu(conv(seg[m_up3.long()]))
+        assert torch.allclose(a3[m3f.long()], a_full, atol=1e-6)
+        gb5 = conv(a3[m35.long()])
+        assert src5 == 5 * blocks and gb5.numel() == 5 * blocks
+        assert torch.allclose(gb5[m5f.long()], gb_full, atol=1e-6)
+        for m, lo in ((m_up3, lo_up3), (m35, lo35), (m5f, lo5f)):      # range starts of the inverse map
+            mm = m.tolist()
+            assert mm == sorted(mm) and lo[0] == 0 and lo[-1] == len(mm)
+            for i in range(len(lo) - 1):
+                assert all(mm[j] == i for j in range(int(lo[i]), int(lo[i + 1])))
