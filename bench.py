@@ -112,7 +112,8 @@ def main():
     torch.manual_seed(0)                         # identical initial weights on every rank
     nets, obj_size = build_nets(a.res, dev)
     pw = torch.from_numpy(synth.make_pos_weight())
-    tr = Trainer(*nets, pw)
+    # attribute_est is derived on device from the pre-step D_att logits, as the reference loop does (train64.py:156-166)
+    tr = Trainer(*nets, pw, estimate_attributes=True)
     bn = synth.make_batch(per_gpu, a.res, seed=a.seed + rank)
     b = batch_to_device(bn, dev)
     O = int(bn["objs"].shape[0])
