@@ -87,6 +87,9 @@ def main():
                     help="MFMA arithmetic of the convolutions: exact fp32 (BASELINE config 2) or bf16 operands with fp32 "
                          "accumulation (configs 3/5); statistics, SN, losses and Adam are fp32 either way")
     ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
+    ap.add_argument("--two-generator-passes", action="store_true",
+                    help="evaluate the whole generator twice per iteration like the reference loop instead of reusing the "
+                         "draw-independent parts of the first evaluation (identical results; reported for comparison)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     a = ap.parse_args()
 
@@ -113,7 +116,7 @@ def main():
     nets, obj_size = build_nets(a.res, dev)
     pw = torch.from_numpy(synth.make_pos_weight())
     # attribute_est is derived on device from the pre-step D_att logits, as the reference loop does (train64.py:156-166)
-    tr = Trainer(*nets, pw, estimate_attributes=True)
+    tr = Trainer(*nets, pw, estimate_attributes=True, reuse_generator_pass=not a.two_generator_passes)
     bn = synth.make_batch(per_gpu, a.res, seed=a.seed + rank)
     b = batch_to_device(bn, dev)
     O = int(bn["objs"].shape[0])
@@ -188,7 +191,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.res}x{a.res} G+D train step, batch={per_gpu}/GPU, {a.dtype}, synthetic VG-shaped batch "
                                       f"(P~U{{3..9}}, O={O} objects on rank 0), random-init weights",
-                          "global_batch": per_gpu * world, "objects_rank0": O, "parallelism": f"dp{world}"},
+                          "global_batch": per_gpu * world, "objects_rank0": O, "parallelism": f"dp{world}", "generator_schedule": "two full passes" if a.two_generator_passes else "draw-independent parts evaluated once"},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
