@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void sn_finish_v(const AglSnBatch L, float eps
   double ss = 0.0;
   for (int k = threadIdx.x; k < l.cols; k += 256) {
     float t = 0.f;
-    for (int c = 0; c < nch; ++c) t += part[(long)c * l.cols + k];
+#pragma unroll 8
+    for (int c = 0; c < nch; ++c) t += part[(long)c * l.cols + k];      // (unrolled: the loads of a batch are in flight together)
     l.tmp[k] = t;
     ss += (double)t * t;
   }
