@@ -39,7 +39,8 @@ def load_model(model, model_dir=None, appendix=None, iter='l'):
             print('models dir is empty')
         print('train from scratch.')
         return 0
-    files = [f for f in os.listdir(model_dir) if f.endswith('.pkl') and _iter_of(f) is not None]
+    # network checkpoints only: `iter-<n>_optim.pkl` (save_optimizer below) is not a state_dict and must never be a candidate
+    files = [f for f in os.listdir(model_dir) if f.endswith('.pkl') and not f.endswith('_optim.pkl') and _iter_of(f) is not None]
     if iter == 'l':
         cands = [f for f in files if appendix is None or appendix in f]
         if not cands:

@@ -22,17 +22,16 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "agl_version": (_I, []),
     "agl_last_error": (C.c_char_p, []),
-    "agl_set_conv_precision": (_I, [_I]),
-    "agl_get_conv_precision": (_I, []),
-    "agl_set_conv_patch": (_I, [_I]),
-    "agl_set_conv_pos": (_I, [_I]),
     "agl_conv2d_fwd_ws_bytes": (_L, [_I] * 9),
     "agl_conv2d_bwd_data_ws_bytes": (_L, [_I] * 10),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
-    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
-    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P]),
+    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
-    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 14 + [_P]),
+    "agl_conv2d_fwd_flops": (C.c_double, [_I] * 10),
+    "agl_conv2d_bwd_data_flops": (C.c_double, [_I] * 11),
+    "agl_conv2d_bwd_weight_flops": (C.c_double, [_I] * 13),
     "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
     "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P]),
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
@@ -80,7 +79,9 @@ SIGNATURES = {
     "agl_bce_logits_const": (_I, [_P, _L, _F, _F, _P, _P, _P]),
     "agl_bce_logits_posw": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
-    "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P]),
+    "agl_l1_rows_ws_bytes": (_L, []),
+    "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P, _L, _P]),
+    "agl_hinge_loss": (_I, [_P, _L, _I, _F, _P, _P, _P]),
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "agl_rasterize_boxes": (_I, [_P, _P, _I, _I, _P]),
     "agl_attr_estimate": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -118,44 +119,83 @@ def load() -> C.CDLL:
     return lib
 
 
-# Optional per-launch timing (bench.py's roofline leg): when EVENT_LOG is a list, every call whose name starts
-# with one of EVENT_PREFIXES is bracketed by HIP events on the current stream (the stream it is launched on).
+# Optional per-launch timing (bench.py's roofline legs): when EVENT_LOG is a list, every call whose name is in
+# EVENT_NAMES is bracketed by HIP events on the current stream (the stream it is launched on); each entry is
+# (name, start, end, work, dims) with work = executed FLOPs for the convolution family (agl_conv2d_*_flops, i.e. the
+# dense count minus the padded taps the position-major path skips) or algorithmic HBM bytes for the normalisation family.
 EVENT_LOG = None
-EVENT_PREFIXES = ("agl_conv2d_",)
+EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight", "agl_bn_stats", "agl_norm_apply_fwd", "agl_norm_bwd"}
+
+# Convolution flags passed with every agl_conv2d_* call (include/agl.h AGL_CONV_*).  This is host-side state of the
+# Python binding only — the C ABI has no process-wide switches.
+CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS = 1, 2, 4, 8, 16
+CONV_FLAGS = 0
 
 
-def conv_flops(name, args) -> float:
-    """Executed FLOPs (2*MAC) of one convolution launch, from its C-ABI arguments."""
+class conv_flags:
+    """Context manager: `with conv_flags(CONV_BF16): ...` runs the enclosed convolutions with these flags."""
+
+    def __init__(self, flags: int):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        global CONV_FLAGS
+        self.prev, CONV_FLAGS = CONV_FLAGS, self.flags
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_FLAGS
+        CONV_FLAGS = self.prev
+        return False
+
+
+def set_conv_precision(mode: str):
+    """Default arithmetic of the convolutions this binding launches: 'f32' exact fp32 MFMA, 'bf16' bf16 MFMA operands
+    with fp32 accumulation.  (Sets the AGL_CONV_BF16 bit of CONV_FLAGS, which travels with every call.)"""
+    global CONV_FLAGS
+    bit = {"f32": 0, "fp32": 0, "bf16": CONV_BF16}[mode]
+    CONV_FLAGS = (CONV_FLAGS & ~CONV_BF16) | bit
+
+
+def work_of(name, args) -> float:
+    """Executed FLOPs (convolutions) or algorithmic HBM bytes (normalisation family) of one logged call."""
+    lib = load()
     if name == "agl_conv2d_fwd":
-        N, Cin, H, W, Cout, ks, stride, pad, up = args[6:15]
-        OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
-    elif name == "agl_conv2d_bwd_data":
-        N, Cin, _, _, Cout, OH, OW, ks = args[7:15]
-    elif name == "agl_conv2d_bwd_weight":
-        N, Cin, _, _, Cout, OH, OW, ks = args[5:13]
-    else:
-        return 0.0
-    return 2.0 * N * OH * OW * Cout * Cin * ks * ks
+        return lib.agl_conv2d_fwd_flops(*args[6:15], args[18])
+    if name == "agl_conv2d_bwd_data":
+        return lib.agl_conv2d_bwd_data_flops(*args[7:17], args[19])
+    if name == "agl_conv2d_bwd_weight":
+        return lib.agl_conv2d_bwd_weight_flops(*args[5:17], args[18])
+    if name == "agl_bn_stats":                       # one read of x (SURVEY 8d: 4*N*C*HW)
+        return 4.0 * args[1] * args[2] * args[3]
+    if name == "agl_norm_apply_fwd":                 # x read + y write (+ gamma|beta planes for SPADE, + residual)
+        mode, res, N, Cc, HW = args[3], args[7], args[10], args[11], args[12]
+        return 4.0 * N * Cc * HW * (2 + (2 if mode == 3 else 0) + (1 if res is not None else 0))
+    if name == "agl_norm_bwd":                       # dy, x (+y if relu, + gamma|beta) read twice (sums, then apply); dx (+ d gamma|beta) written
+        mode, relu, N, Cc, HW = args[5], args[9], args[14], args[15], args[16]
+        reads = 2 + (1 if relu else 0) + (2 if mode == 3 else 0)
+        return 4.0 * N * Cc * HW * (2 * reads + 1 + (2 if mode == 3 else 0))
+    return 0.0
+
+
+CALL_COUNT = 0      # C-ABI calls issued through call() (bench.py reports calls per training iteration)
 
 
 def call(name: str, *args):
+    global CALL_COUNT
+    CALL_COUNT += 1
     lib = load()
     log = EVENT_LOG
-    if log is not None and name.startswith(EVENT_PREFIXES):
+    if log is not None and name in EVENT_NAMES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        log.append((name, e0, e1, conv_flops(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-14:]))
+        log.append((name, e0, e1, work_of(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-15:]))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.agl_last_error().decode()}")
-
-
-def set_conv_precision(mode: str):
-    """'f32': exact fp32 MFMA convolutions (default).  'bf16': bf16 MFMA operands, fp32 accumulation."""
-    call("agl_set_conv_precision", {"f32": 0, "fp32": 0, "bf16": 1}[mode])
 
 
 # --------------------------------------------------------------------------- helpers
@@ -207,7 +247,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
     ws = workspace(need, x.device) if need else None
     call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
-         int(in_relu), int(relu), int(accumulate), stream())
+         int(in_relu), int(relu), int(accumulate), CONV_FLAGS, stream())
     return out
 
 
@@ -223,7 +263,7 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     need = load().agl_conv2d_bwd_data_ws_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad)
     ws = workspace(need, dy.device) if need else None
     call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), ws.data_ptr() if ws is not None else None,
-         ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), stream())
+         ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), CONV_FLAGS, stream())
     return out
 
 
@@ -239,7 +279,7 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
     ws = workspace(need, dy.device) if need else None
     call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up, int(in_relu),
-         int(accumulate), stream())
+         int(accumulate), CONV_FLAGS, stream())
     return out
 
 

@@ -23,6 +23,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import functional as F
+from . import lib as L
 from . import losses as LS
 from .dp import GradSync
 from .flat import FlatParams
@@ -51,7 +52,8 @@ def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
 
 class Trainer:
     def __init__(self, netG, netD_image, netD_object, netD_att, pos_weight: torch.Tensor, *, lambdas: Optional[dict] = None,
-                 group=None, estimate_attributes: bool = False, reuse_generator_pass: bool = True):
+                 group=None, estimate_attributes: bool = False, reuse_generator_pass: bool = True,
+                 conv_dtype: str = "f32"):
         self.netG, self.netDi, self.netDo, self.netDa = netG, netD_image, netD_object, netD_att
         dev = next(netG.parameters()).device
         if dev.type != "cuda":
@@ -74,6 +76,15 @@ class Trainer:
         # True: evaluate the draw-independent generator parts once per iteration (see the module docstring);
         # False: two full generator evaluations like the reference loop (A/B tests).
         self.reuse_generator_pass = reuse_generator_pass
+        # arithmetic of the MFMA convolutions inside step(): "f32" exact fp32 (BASELINE config 2) or "bf16" operands with
+        # fp32 accumulation (configs 3/5); passed per call through the C ABI (AGL_CONV_BF16), never a process-wide switch
+        self.conv_flags = {"f32": 0, "fp32": 0, "bf16": L.CONV_BF16}[conv_dtype]
+        self._in_step = False
+        # With data parallelism step() returns while the G all-reduce + Adam still run on the side stream.  Readers of
+        # the weights outside step() (state_dict / checkpoint.save_model, eval or user forwards) join it first.
+        for net in (netG, netD_image, netD_object, netD_att):
+            net.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.finish())
+            net.register_forward_pre_hook(lambda module, args: None if self._in_step else self.finish())
         self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
         self._d_ready = None
         self._g_ready = None
@@ -145,11 +156,22 @@ class Trainer:
     # ------------------------------------------------------------------ the step
     def step(self, b: Dict[str, torch.Tensor], eps_d: Optional[Sequence[torch.Tensor]] = None,
              eps_g: Optional[Sequence[torch.Tensor]] = None):
+        self._in_step = True
+        try:
+            with L.conv_flags(self.conv_flags):
+                return self._step(b, eps_d, eps_g)
+        finally:
+            self._in_step = False
+
+    def _step(self, b, eps_d, eps_g):
         lam = self.lam
         objs = b["objs"]
         N = b["imgs"].shape[0]
         n_swap = math.floor(N / 3)                                        # train64.py:170
-        o2i_dev = b["obj_to_img"].to(self.dev)
+        o2i = b["obj_to_img"]
+        if not o2i.is_cuda and o2i.numel() and (int(o2i.min()) < 0 or int(o2i.max()) >= N):
+            raise IndexError(f"obj_to_img must lie in [0, {N})")
+        o2i_dev = o2i.to(self.dev)
         s = self.netG.obj_size
 
         # ---- pre-step attribute-estimate forward (train64.py:160-161); independent of G, so the previous
@@ -158,7 +180,6 @@ class Trainer:
             crops_real = F.crop_boxes(b["imgs"], b["boxes"], o2i_dev, s)
             att_logits = self.netDa(crops_real)
             if self.estimate_attributes:
-                from . import lib as L
                 b = dict(b, attribute_est=L.attr_estimate(att_logits, b["attribute"]))
         self._wait(self._g_ready)
         self._g_ready = None

@@ -886,22 +886,35 @@ static int fwd_splits(int M, long Nc, int Z, int K, int* per_out) {
   return s;
 }
 
-int g_pos_all_ks = 0;         // experiments: also 3x3 / 4x4 kernels (agl_set_conv_pos(-1))
-int g_pos_min_n = 96;         // smallest image count for the position-major path (agl_set_conv_pos(n > 1) sets it)
-int g_use_pos = 1;            // agl_set_conv_pos(0): no position-major path on small maps (A/B tests)
-int g_use_patch_s2 = 1;       // stride-2 forward form of the patch kernel (agl_set_conv_patch(2) = stride-1 only)
-int g_use_patch = 1;          // agl_set_conv_patch(0) routes every convolution through the im2col kernel (A/B tests)
-int g_conv_precision = 0;   // 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulation (agl_set_conv_precision)
+// Per-call options (the `flags` argument of the agl_conv2d_* entry points; include/agl.h AGL_CONV_*).
+struct ConvOpts {
+  int prec;          // 0 = fp32 MFMA, 1 = bf16 MFMA operands with fp32 accumulation
+  bool patch;        // LDS-patch kernel allowed
+  bool patch_s2;     // ... also its stride-2 forward form
+  bool pos;          // position-major path on small maps allowed
+  bool pos_all_ks;   // experiments: position-major also for 3x3 / 4x4 kernels
+};
+constexpr int kPosMinN = 96;    // smallest image count for the position-major path
+static ConvOpts conv_opts(int flags) {
+  ConvOpts o;
+  o.prec = (flags & 1) ? 1 : 0;
+  o.patch = !(flags & 2);
+  o.patch_s2 = o.patch && !(flags & 4);
+  o.pos = !(flags & 8);
+  o.pos_all_ks = (flags & 16) != 0;
+  return o;
+}
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false};
 
 template <class P>
-int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int big_tile = 0) {
+int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
   AGL_REQUIRE(Nc > 0 && Nc < (1L << 31) && M > 0, "%s: bad GEMM extents M=%d Nc=%ld", name, M, Nc);
 #define AGL_LAUNCH(BM_, BN_)                                                                      \
   do {                                                                                            \
     const long gx_ = agl_cdiv(Nc, BN_), gy_ = agl_cdiv(M, BM_);                                   \
     AGL_REQUIRE(gx_ * gy_ * Z < (1L << 31), "%s: grid too large", name);                          \
     dim3 g((unsigned)(gx_ * gy_ * Z));                                                            \
-    if (g_conv_precision) hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 1>), g, dim3(NT), 0, st, p, (int)gx_, (int)gy_, Z); \
+    if (prec) hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 1>), g, dim3(NT), 0, st, p, (int)gx_, (int)gy_, Z); \
     else hipLaunchKernelGGL((igemm_f32<P, BM_, BN_, 0>), g, dim3(NT), 0, st, p, (int)gx_, (int)gy_, Z);                  \
   } while (0)
   if (M <= 32) AGL_LAUNCH(32, 256);
@@ -1218,10 +1231,10 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
 }
 
 // returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back to the im2col kernel)
-int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st, const char* name) {
-  if (g_conv_precision != 0) return -1;                       // fp32 path only (bf16 mode uses the im2col kernel)
+int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st, const char* name, const ConvOpts& co) {
+  if (co.prec != 0) return -1;                       // fp32 path only (bf16 mode uses the im2col kernel)
   const bool s2 = a.stride == 2;
-  if (s2 && (a.flip || a.up || (ks != 3 && ks != 4) || !g_use_patch_s2)) return -1;
+  if (s2 && (a.flip || a.up || (ks != 3 && ks != 4) || !co.patch_s2)) return -1;
   if (!s2 && ks != 3) return -1;                              // 5x5 (ConvLSTM at 8x8): measured no faster than im2col
   if (a.flip && a.OW < 32) return -1;                         // input-gradient form: wins on >= 32-wide maps only
   const int cb = s2 ? 4 : 8;
@@ -1286,8 +1299,8 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
 // is high and the padded share large: measured +20 % on the 5x5 / 8x8 ConvLSTM input convolutions (512->512: 3.33 ->
 // 2.67 ms), +9 % on 512->1024 4x4/s2 at 4x4, nothing on the 3x3 discriminator layers (their transposes cost what the
 // skipped taps save) — so it is taken for 5x5 kernels only.
-static bool pos_ok(int N, int Cred, int H, int W, int Crow, int ks, int up) {   // Cred: reduction channels, Crow: GEMM rows
-  return g_use_pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && (ks == 5 || (g_pos_all_ks && ks >= 3)) && N >= g_pos_min_n && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
+static bool pos_ok(const ConvOpts& co, int N, int Cred, int H, int W, int Crow, int ks, int up) {   // Cred: reduction channels, Crow: GEMM rows
+  return co.pos && up == 0 && H <= 8 && W <= 8 && H * W >= 4 && (ks == 5 || (co.pos_all_ks && ks >= 3)) && N >= kPosMinN && Cred >= 64 && (Cred & (Cred - 1)) == 0 &&
          Crow >= 64;
 }
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
@@ -1319,7 +1332,7 @@ static int launch_transpose_out(const float* yt, float* y, const float* pos_mask
   return AGL_OK;
 }
 static int pos_conv_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, int N, int Cin, int H, int W, int Cout,
-                        int ks, int stride, int pad, int in_relu, int relu, int accumulate, hipStream_t st, int wmode = 0,
+                        int ks, int stride, int pad, int in_relu, int relu, int accumulate, hipStream_t st, int prec, int wmode = 0,
                         const float* pos_mask = nullptr) {
   const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1, Q = OH * OW, KK = ks * ks;
   const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
@@ -1337,7 +1350,7 @@ static int pos_conv_fwd(const float* x, const float* w, const float* bias, float
     p.kbeg = 0; p.kend = 0; p.a_bytes = (unsigned)(pl.wt * 4); p.b_bytes = (unsigned)(pl.xt * 4);               \
     p.Q = Q; p.nfull = N / 128 * 128;                                                                            \
     p.splits = pl.splits; p.slab = pl.yt; p.part = slabs;                                                        \
-    rc = launch_igemm(p, Cout, (long)N * Q, pl.splits, st, "agl_conv2d_fwd(position-major)");                   \
+    rc = launch_igemm(p, Cout, (long)N * Q, pl.splits, st, "agl_conv2d_fwd(position-major)", prec);                   \
   } break;
   switch (ks) { AGL_PF(3) AGL_PF(4) AGL_PF(5) AGL_PF(7) }
 #undef AGL_PF
@@ -1356,22 +1369,6 @@ bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
 
 extern "C" {
 
-// 0: exact fp32 MFMA (default).  1: bf16 MFMA operands (round-to-nearest-even of the fp32 tensors), fp32 accumulate.
-int agl_set_conv_precision(int mode) {
-  AGL_REQUIRE(mode == 0 || mode == 1, "agl_set_conv_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
-  g_conv_precision = mode;
-  return AGL_OK;
-}
-int agl_get_conv_precision(void) { return g_conv_precision; }
-int agl_set_conv_patch(int on) { g_use_patch = on ? 1 : 0; g_use_patch_s2 = on == 1; return AGL_OK; }
-int agl_set_conv_pos(int on) {
-  g_use_pos = on ? 1 : 0;
-  if (on > 1) g_pos_min_n = on;
-  g_pos_all_ks = on < 0;
-  return AGL_OK;
-}
-
-
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {
   int per;
@@ -1385,7 +1382,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
   const int Hl = H << up_log2, Wl = W << up_log2;
   const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
   long need = agl_conv2d_splitk_ws_bytes(Cout, (long)N * OH * OW, 1, Cin * ks * ks, (long)N * Cout * OH * OW);
-  if (pos_ok(N, Cin, H, W, Cout, ks, up_log2)) {
+  if (pos_ok(kDefaultOpts, N, Cin, H, W, Cout, ks, up_log2)) {
     const long pn = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad).total();
     if (pn > need) need = pn;
   }
@@ -1394,8 +1391,9 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
 
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                   void* stream) {
+                   int flags, void* stream) {
   AGL_REQUIRE(x && w && y, "agl_conv2d_fwd: null pointer");
+  const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2) && up_log2 >= 0 && up_log2 <= 4,
               "agl_conv2d_fwd: unsupported ks=%d stride=%d up=%d", ks, stride, up_log2);
   const int Hl = H << up_log2, Wl = W << up_log2;
@@ -1407,19 +1405,19 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64)   // (linear layers, HW = 1, stay on the GEMM)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
-  if (pos_ok(N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
+  if (pos_ok(co, N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
     const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
     if (ws && ws_bytes >= pl.total())
-      return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st);
+      return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st, co.prec);
   }
-  if (g_use_patch) {
+  if (co.patch) {
     PatchArgs a;
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu; a.accumulate = accumulate;
     a.stride = stride;
     a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0;
     a.x_bytes = (unsigned)((long)N * Cin * H * W * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
-    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_fwd(patch)");
+    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_fwd(patch)", co);
     if (prc >= 0) return prc;
   }
   const long out_numel = (long)N * Cout * OH * OW;
@@ -1434,7 +1432,7 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     p.M = Cout; p.Nc = N * OH * OW; p.K = Cin * KS_ * KS_; p.kbeg = 0; p.kend = p.K; p.HW = H * W; p.OHW = OH * OW;  \
     p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);          \
     p.splits = splits; p.per_split = per; p.slab = out_numel; p.part = (float*)ws;                                    \
-    rc = launch_igemm(p, p.M, p.Nc, splits, st, "agl_conv2d_fwd");                                                    \
+    rc = launch_igemm(p, p.M, p.Nc, splits, st, "agl_conv2d_fwd", co.prec);                                                    \
   } break;
   switch (ks) { AGL_FWD(1) AGL_FWD(3) AGL_FWD(4) AGL_FWD(5) AGL_FWD(7) }
 #undef AGL_FWD
@@ -1472,7 +1470,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
     need = agl_conv2d_splitk_ws_bytes(Cin, (long)N * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride), stride * stride,
                                       Cout * tpa * tpa, out_numel);
   }
-  if (stride == 1 && IH == OH && IW == OW && pos_ok(N, Cout, OH, OW, Cin, ks, 0)) {
+  if (stride == 1 && IH == OH && IW == OW && pos_ok(kDefaultOpts, N, Cout, OH, OW, Cin, ks, 0)) {
     const long pn = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad).total();
     if (pn > need) need = pn;
   }
@@ -1483,8 +1481,9 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
 // ConvTranspose2d (weight [C_in_T = Cout][C_out_T = Cin][ks][ks]).
 int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
                         long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
-                        int relu, int accumulate, void* stream) {
+                        int relu, int accumulate, int flags, void* stream) {
   AGL_REQUIRE(dy && w && dx, "agl_conv2d_bwd_data: null pointer");
+  const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && (ks == 4 || ks == 3))), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
   AGL_REQUIRE((IH + 2 * pad - ks) / stride + 1 == OH && (IW + 2 * pad - ks) / stride + 1 == OW,
@@ -1495,20 +1494,20 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   if (Cin <= 4 && stride == 1 && IH * IW >= 64)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
-  if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(N, Cout, OH, OW, Cin, ks, 0)) {
+  if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0)) {
     // "same" convolution: dx = forward convolution of dy with flipped taps, channel roles swapped, pad ks-1-pad
     const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
     if (ws && ws_bytes >= pl.total())
-      return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, 2, pos_mask);
+      return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, co.prec, 2, pos_mask);
   }
-  if (stride == 1 && g_use_patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
+  if (stride == 1 && co.patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
     PatchArgs a;
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
     a.stride = 1;
     a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1;
     a.x_bytes = (unsigned)((long)N * Cout * OH * OW * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
-    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_bwd_data(patch)");
+    const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_bwd_data(patch)", co);
     if (prc >= 0) return prc;
   }
   const long out_numel = (long)N * Cin * IH * IW;
@@ -1527,7 +1526,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     p.a_bytes = (unsigned)((long)Cout * Cin * KS_ * KS_ * 4); p.b_bytes = (unsigned)((long)N * Cout * OH * OW * 4);      \
     long maxNc = (long)N * ((IH + S_ - 1) / S_) * ((IW + S_ - 1) / S_);                                             \
     p.splits = splits; p.per_split = per; p.slab = out_numel; p.part = (float*)ws;                                  \
-    rc = launch_igemm(p, Cin, maxNc, S_ * S_ * splits, st, "agl_conv2d_bwd_data");                                  \
+    rc = launch_igemm(p, Cin, maxNc, S_ * S_ * splits, st, "agl_conv2d_bwd_data", co.prec);                                  \
   }
   if (stride == 2 && ks == 3) {
     BwdDataGenProb<3, 2> p;
@@ -1537,7 +1536,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     long maxNc = (long)N * ((IH + 1) / 2) * ((IW + 1) / 2);
     p.splits = splits; p.slab = out_numel; p.part = (float*)ws; p.kbeg = 0; p.kend = 0; p.M = Cin; p.Nc = 0;
     p.tap_split = tap_split;
-    rc = launch_igemm(p, Cin, maxNc, 4 * splits, st, "agl_conv2d_bwd_data(3x3 stride 2)");
+    rc = launch_igemm(p, Cin, maxNc, 4 * splits, st, "agl_conv2d_bwd_data(3x3 stride 2)", co.prec);
   } else if (stride == 2) AGL_BWD(4, 2)
   else switch (ks) {
     case 1: AGL_BWD(1, 1) break;
@@ -1604,7 +1603,7 @@ static PosBwwPlan pos_bww_plan(int N, int Cin, int H, int W, int Cout, int OH, i
   return pl;
 }
 static int pos_conv_bww(const float* dy, const float* x, float* dw, void* ws, int N, int Cin, int H, int W, int Cout, int OH, int OW,
-                        int ks, int stride, int pad, int accumulate, hipStream_t st) {
+                        int ks, int stride, int pad, int accumulate, hipStream_t st, int prec) {
   const int Q = OH * OW, KK = ks * ks;
   const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, stride, pad);
   float* dyt = (float*)ws; float* xt = dyt + pl.dyt; float* dwt = xt + pl.xt; float* slabs = dwt + pl.dwt;
@@ -1619,7 +1618,7 @@ static int pos_conv_bww(const float* dy, const float* x, float* dw, void* ws, in
     p.dyt = dyt; p.xt = xt; p.dwt = dwt; p.part = slabs; p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;  \
     p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad; p.M = Cout; p.Nc = Cin; p.kbeg = 0; p.kend = 0;        \
     p.a_bytes = (unsigned)(pl.dyt * 4); p.b_bytes = (unsigned)(pl.xt * 4); p.splits = pl.splits; p.slab = pl.dwt; \
-    rc = launch_igemm(p, Cout, Cin, KK * pl.splits, st, "agl_conv2d_bwd_weight(position-major)", bww_big_tile(Cout, Cin)); \
+    rc = launch_igemm(p, Cout, Cin, KK * pl.splits, st, "agl_conv2d_bwd_weight(position-major)", prec, bww_big_tile(Cout, Cin)); \
   } break;
   switch (ks) { AGL_PW(3) AGL_PW(4) AGL_PW(5) AGL_PW(7) }
 #undef AGL_PW
@@ -1643,7 +1642,7 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
 
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
   long pos_need = 0;
-  if (OH <= 8 && OW <= 8 && ks == 5 && pos_ok(N, 64, OH, OW, Cout, ks, 0) && Cin >= 64)   // stride-1 "same" 5x5 on a small map
+  if (OH <= 8 && OW <= 8 && ks == 5 && pos_ok(kDefaultOpts, N, 64, OH, OW, Cout, ks, 0) && Cin >= 64)   // stride-1 "same" 5x5 on a small map
     pos_need = pos_bww_plan(N, Cin, OH, OW, Cout, OH, OW, ks, 1, ks / 2).total();
   if (pos_need) {
     long Nc1 = (long)Cin * ks * ks, R1 = (long)N * OH * OW;
@@ -1672,16 +1671,18 @@ long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, in
 
 // dw[Cout,Cin,ks,ks] (+)= sum_{n,oh,ow} dy * im2col(x).  ws: agl_conv2d_bwd_weight_ws_bytes() bytes (may be null if 0).
 int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H, int W,
-                          int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu, int accumulate, void* stream) {
+                          int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu, int accumulate, int flags,
+                          void* stream) {
   AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
+  const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
   if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
-      pos_ok(N, 64, H, W, Cout, ks, 0)) {
+      pos_ok(co, N, 64, H, W, Cout, ks, 0)) {
     const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, 1, pad);
     if (ws && ws_bytes >= pl.total())
-      return pos_conv_bww(dy, x, dw, ws, N, Cin, H, W, Cout, OH, OW, ks, 1, pad, accumulate, (hipStream_t)stream);
+      return pos_conv_bww(dy, x, dw, ws, N, Cin, H, W, Cout, OH, OW, ks, 1, pad, accumulate, (hipStream_t)stream, co.prec);
   }
   if (bww_swapped(Cin, Cout, stride, up_log2, in_relu)) {
     const long inner = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
@@ -1691,7 +1692,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
       return AGL_ERR_WORKSPACE;
     }
     float* tmp = (float*)((char*)ws + inner);
-    int rc = agl_conv2d_bwd_weight(x, dy, tmp, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, stream);
+    int rc = agl_conv2d_bwd_weight(x, dy, tmp, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, flags, stream);
     if (rc != AGL_OK) return rc;
     const long n = (long)Cout * Cin * ks * ks;
     hipLaunchKernelGGL(flip_transpose_w, dim3(agl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dw, Cout, Cin, ks,
@@ -1721,7 +1722,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     p.OW = OW; p.stride = stride; p.pad = pad; p.up = up_log2; p.in_relu = in_relu; p.M = Cout; p.Nc = (int)Nc; p.HW = H * W;         \
     p.OHW = OH * OW; p.R = (int)R; p.per_split = (int)per; p.slab = (long)Cout * Nc; p.kbeg = 0; p.kend = 0;    \
     p.a_bytes = (unsigned)((long)N * Cout * OH * OW * 4); p.b_bytes = (unsigned)((long)N * Cin * H * W * 4);    \
-    rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight", bww_big_tile(Cout, Nc));                \
+    rc = launch_igemm(p, Cout, Nc, splits, st, "agl_conv2d_bwd_weight", co.prec, bww_big_tile(Cout, Nc));                \
   } break;
   switch (ks) { AGL_BWW(1) AGL_BWW(3) AGL_BWW(4) AGL_BWW(5) AGL_BWW(7) }
 #undef AGL_BWW
@@ -1732,6 +1733,34 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(reduce)");
   }
   return AGL_OK;
+}
+
+// Executed FLOPs (2*MAC) of the launches one call of the entry points above issues for these extents and flags, assuming
+// the workspace the *_ws_bytes functions ask for is provided: dense 2*N*OH*OW*Cout*Cin*ks^2, minus the padded taps the
+// position-major path never visits.  (bench.py's roofline leg divides the sum of these by the measured launch time.)
+double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  const int Hl = H << up_log2, Wl = W << up_log2;
+  const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
+  const bool small = Cout <= 4 && stride == 1 && up_log2 == 0 && OH * OW >= 64;
+  if (!small && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
+    return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, stride, pad);
+  return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
+}
+double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  const bool small = Cin <= 4 && stride == 1 && IH * IW >= 64;
+  if (!small && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))
+    return 2.0 * N * Cout * Cin * (double)pos_valid_taps(OH, OW, IH, IW, ks, 1, ks - 1 - pad);
+  return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
+}
+double agl_conv2d_bwd_weight_flops(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad,
+                                   int up_log2, int in_relu, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
+      pos_ok(co, N, 64, H, W, Cout, ks, 0))
+    return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, 1, pad);
+  return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
 }
 
 }  // extern "C"

@@ -37,35 +37,41 @@ __global__ __launch_bounds__(LT) void bce_const_k(const float* __restrict__ x, l
   if (threadIdx.x == 0) *loss_out = (float)(s / (double)n);
 }
 
-// rows with sum(targets[row]) != 0 are the annotated ones (train64.py:241,323)
+// rows with sum(targets[row]) != 0 are the annotated ones (train64.py:241,323).  Each wave walks rows r = wave, wave+16, ...
+// with its lanes along the attributes; the row's annotated flag is recomputed in the second pass instead of being kept
+// in a fixed-size table, so any number of rows is accepted (the reference has no limit).
 __global__ __launch_bounds__(LT) void bce_posw_k(const float* __restrict__ x, const float* __restrict__ tg,
                                                  const float* __restrict__ pw, long rows, int A, float coef,
                                                  float* __restrict__ loss_out, float* __restrict__ dx) {
   __shared__ double sc[16];
-  __shared__ unsigned char sel[4096];
-
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double cnt = 0.0;
-  for (long r = threadIdx.x; r < rows; r += LT) {
+  for (long r = wave; r < rows; r += 16) {
     float t = 0.f;
-    for (int a = 0; a < A; ++a) t += tg[r * A + a];
-    sel[r] = t != 0.f;
-    cnt += sel[r] ? 1.0 : 0.0;
+    for (int a = lane; a < A; a += 64) t += tg[r * A + a];
+    t = wave_sum(t);                       // targets are multi-hot (>= 0): the sum is zero iff every entry is
+    if (lane == 0 && t != 0.f) cnt += 1.0;
   }
   cnt = block_sum_1024(cnt, sc);
   const double denom = cnt * (double)A;
   const float inv = denom > 0.0 ? (float)(1.0 / denom) : 0.f;
   double s = 0.0;
-  for (long i = threadIdx.x; i < rows * A; i += LT) {
-    const long r = i / A;
-    const int a = (int)(i - r * A);
-    float g = 0.f;
-    if (sel[r]) {
-      const float xi = x[i], t = tg[i];
-      const float lw = (pw[a] - 1.f) * t + 1.f;
-      s += (double)((1.f - t) * xi - lw * log_sigmoid(xi));
-      g = coef * inv * ((1.f - t) - lw * sigmoid_neg(xi));
+  for (long r = wave; r < rows; r += 16) {
+    float t = 0.f;
+    for (int a = lane; a < A; a += 64) t += tg[r * A + a];
+    t = wave_sum(t);
+    const bool sel = t != 0.f;
+    for (int a = lane; a < A; a += 64) {
+      const long i = r * A + a;
+      float g = 0.f;
+      if (sel) {
+        const float xi = x[i], ti = tg[i];
+        const float lw = (pw[a] - 1.f) * ti + 1.f;
+        s += (double)((1.f - ti) * xi - lw * log_sigmoid(xi));
+        g = coef * inv * ((1.f - ti) - lw * sigmoid_neg(xi));
+      }
+      if (dx) dx[i] = g;
     }
-    if (dx) dx[i] = g;
   }
   s = block_sum_1024(s, sc);
   if (threadIdx.x == 0) *loss_out = denom > 0.0 ? (float)(s / denom) : nanf("");
@@ -87,29 +93,65 @@ __global__ __launch_bounds__(LT) void ce_k(const float* __restrict__ lg, const l
     for (int j = lane; j < V; j += 64) se += expf(row[j] - mx);
     se = wave_sum(se);
     const float lse = mx + logf(se);
-    const int y = (int)lab[r];
-    if (lane == 0) acc += (double)(lse - row[y]);
+    const long long yl = lab[r];
+    const bool ok = yl >= 0 && yl < V;            // torch raises on a bad label; here the result is poisoned instead
+    const int y = ok ? (int)yl : 0;
+    if (lane == 0) acc += ok ? (double)(lse - row[y]) : (double)nanf("");
     if (dl)
-      for (int j = lane; j < V; j += 64) dl[r * V + j] = coef * inv * (expf(row[j] - lse) - (j == y ? 1.f : 0.f));
+      for (int j = lane; j < V; j += 64)
+        dl[r * V + j] = ok ? coef * inv * (expf(row[j] - lse) - (j == y ? 1.f : 0.f)) : nanf("");
   }
   acc = block_sum_1024(acc, sc);
   if (threadIdx.x == 0) *loss_out = (float)(acc / (double)R);
 }
 
-__global__ __launch_bounds__(LT) void l1_rows_k(const float* __restrict__ a, const float* __restrict__ b,
-                                                const float* __restrict__ keep, long N, long len, float coef, float denom,
-                                                float* __restrict__ loss_out, float* __restrict__ da) {
+// pass 1: block b sums its contiguous chunk of the N*len elements (fixed order inside the block) into part[b];
+// pass 2 (one wave) adds the partials in block order — deterministic for a given (N, len).
+constexpr int L1_BLOCKS = 256;
+__global__ __launch_bounds__(LT) void l1_rows_part_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ keep, long N, long len, float coef, float denom,
+                                                     double* __restrict__ part, float* __restrict__ da) {
   __shared__ double sc[16];
+  const long n = N * len, per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   double s = 0.0;
   const float inv = 1.0f / ((float)len * denom);
-  for (long i = threadIdx.x; i < N * len; i += LT) {
+  for (long i = lo + threadIdx.x; i < hi; i += LT) {
     const float k = keep ? keep[i / len] : 1.f;
     const float d = a[i] - b[i];
     s += (double)(k * fabsf(d));
     if (da) da[i] = coef * inv * k * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
   }
   s = block_sum_1024(s, sc);
-  if (threadIdx.x == 0) *loss_out = (float)(s / ((double)len * (double)denom));
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void l1_rows_final_k(const double* __restrict__ part, int nb, double scale, float* __restrict__ loss_out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    *loss_out = (float)(s * scale);
+  }
+}
+
+// Hinge GAN losses of the vendored SPADE GANLoss (models/spade/networks/loss.py:65-76) — NOT on the reference's train
+// path (train64.py uses BCE-with-logits); exported because the module surface names them.
+//   mode 0: discriminator, real:  -mean(min(x - 1, 0));   1: discriminator, fake: -mean(min(-x - 1, 0));   2: generator: -mean(x)
+__global__ __launch_bounds__(LT) void hinge_k(const float* __restrict__ x, long n, int mode, float coef, float* __restrict__ loss_out,
+                                              float* __restrict__ dx) {
+  __shared__ double sc[16];
+  double s = 0.0;
+  const float inv = 1.0f / (float)n;
+  for (long i = threadIdx.x; i < n; i += LT) {
+    const float xi = x[i];
+    float v, g;
+    if (mode == 0) { const float m = xi - 1.f; v = fminf(m, 0.f); g = m < 0.f ? -1.f : 0.f; }        // torch.min(a, 0): grad to a where a < 0
+    else if (mode == 1) { const float m = -xi - 1.f; v = fminf(m, 0.f); g = m < 0.f ? 1.f : 0.f; }
+    else { v = xi; g = -1.f; }
+    s += (double)v;
+    if (dx) dx[i] = coef * inv * g;
+  }
+  s = block_sum_1024(s, sc);
+  if (threadIdx.x == 0) *loss_out = (float)(-s / (double)n);
 }
 
 __global__ __launch_bounds__(LT) void kl_k(const float* __restrict__ mu, const float* __restrict__ lv, long n, float coef,
@@ -140,7 +182,6 @@ int agl_bce_logits_const(const float* x, long n, float target, float coef, float
 int agl_bce_logits_posw(const float* x, const float* targets, const float* pos_weight, long rows, int A, float coef,
                         float* loss_out, float* dx, void* stream) {
   AGL_REQUIRE(x && targets && pos_weight && loss_out && rows > 0 && A > 0, "agl_bce_logits_posw: bad argument");
-  AGL_REQUIRE(rows <= 4096, "agl_bce_logits_posw: at most 4096 rows per call (got %ld)", rows);
   hipLaunchKernelGGL(bce_posw_k, dim3(1), dim3(LT), 0, (hipStream_t)stream, x, targets, pos_weight, rows, A, coef, loss_out, dx);
   AGL_CHECK_LAUNCH("agl_bce_logits_posw");
   return AGL_OK;
@@ -154,11 +195,27 @@ int agl_cross_entropy(const float* logits, const long long* labels, long R, int 
   return AGL_OK;
 }
 
+long agl_l1_rows_ws_bytes(void) { return (long)L1_BLOCKS * (long)sizeof(double); }
+
 int agl_l1_rows(const float* a, const float* b, const float* keep, long N, long len, float coef, float denom,
-                float* loss_out, float* da, void* stream) {
+                float* loss_out, float* da, void* ws, long ws_bytes, void* stream) {
   AGL_REQUIRE(a && b && loss_out && N > 0 && len > 0 && denom != 0.f, "agl_l1_rows: bad argument");
-  hipLaunchKernelGGL(l1_rows_k, dim3(1), dim3(LT), 0, (hipStream_t)stream, a, b, keep, N, len, coef, denom, loss_out, da);
+  AGL_REQUIRE(ws && ws_bytes >= agl_l1_rows_ws_bytes(), "agl_l1_rows: workspace too small (%ld < %ld)", ws_bytes, agl_l1_rows_ws_bytes());
+  const long n = N * len;
+  int nb = (int)((n + 4L * LT - 1) / (4L * LT));
+  nb = nb < 1 ? 1 : (nb > L1_BLOCKS ? L1_BLOCKS : nb);
+  hipLaunchKernelGGL(l1_rows_part_k, dim3(nb), dim3(LT), 0, (hipStream_t)stream, a, b, keep, N, len, coef, denom, (double*)ws, da);
   AGL_CHECK_LAUNCH("agl_l1_rows");
+  hipLaunchKernelGGL(l1_rows_final_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)ws, nb,
+                     1.0 / ((double)len * (double)denom), loss_out);
+  AGL_CHECK_LAUNCH("agl_l1_rows(final)");
+  return AGL_OK;
+}
+
+int agl_hinge_loss(const float* x, long n, int mode, float coef, float* loss_out, float* dx, void* stream) {
+  AGL_REQUIRE(x && loss_out && n > 0 && mode >= 0 && mode <= 2, "agl_hinge_loss: bad argument");
+  hipLaunchKernelGGL(hinge_k, dim3(1), dim3(LT), 0, (hipStream_t)stream, x, n, mode, coef, loss_out, dx);
+  AGL_CHECK_LAUNCH("agl_hinge_loss");
   return AGL_OK;
 }
 

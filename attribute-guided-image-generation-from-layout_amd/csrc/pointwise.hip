@@ -46,7 +46,7 @@ __device__ __forceinline__ CropGeom crop_geom(const float* box, int i, int j, in
 }
 
 __global__ void crop_fwd(const float* __restrict__ feats, const float* __restrict__ boxes, const long long* __restrict__ o2i,
-                         float* __restrict__ out, int B, int C, int H, int W, int HH, int WW, int align) {
+                         float* __restrict__ out, int N, int B, int C, int H, int W, int HH, int WW, int align) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   const long total = (long)B * C * HH * WW;
   if (idx >= total) return;
@@ -56,7 +56,11 @@ __global__ void crop_fwd(const float* __restrict__ feats, const float* __restric
   const int c = (int)(t % C);
   const int b = (int)(t / C);
   const CropGeom g = crop_geom(boxes + 4 * b, i, j, HH, WW, H, W, align);
-  const float* src = feats + ((long)o2i[b] * C + c) * H * W;
+  const long long img = o2i[b];
+  // a box that names no image of the batch (models/bilinear.py:122-123 asserts on the host) must not read foreign memory:
+  // the crop is poisoned with NaN instead (this call only enqueues; the Python host validates CPU-resident indices first)
+  if ((unsigned long long)img >= (unsigned long long)N) { out[idx] = nanf(""); return; }
+  const float* src = feats + ((long)img * C + c) * H * W;
   const bool xa = (unsigned)g.x0 < (unsigned)W, xb = (unsigned)(g.x0 + 1) < (unsigned)W;
   const bool ya = (unsigned)g.y0 < (unsigned)H, yb = (unsigned)(g.y0 + 1) < (unsigned)H;
   const float wx0 = 1.f - g.wx1, wy0 = 1.f - g.wy1;
@@ -69,7 +73,7 @@ __global__ void crop_fwd(const float* __restrict__ feats, const float* __restric
 }
 
 __global__ void crop_bwd(const float* __restrict__ dout, const float* __restrict__ boxes, const long long* __restrict__ o2i,
-                         float* __restrict__ dfeats, int B, int C, int H, int W, int HH, int WW, int align) {
+                         float* __restrict__ dfeats, int N, int B, int C, int H, int W, int HH, int WW, int align) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   const long total = (long)B * C * HH * WW;
   if (idx >= total) return;
@@ -79,7 +83,9 @@ __global__ void crop_bwd(const float* __restrict__ dout, const float* __restrict
   const int c = (int)(t % C);
   const int b = (int)(t / C);
   const CropGeom g = crop_geom(boxes + 4 * b, i, j, HH, WW, H, W, align);
-  float* dst = dfeats + ((long)o2i[b] * C + c) * H * W;
+  const long long img = o2i[b];
+  if ((unsigned long long)img >= (unsigned long long)N) return;          // out-of-range box: nothing to scatter into
+  float* dst = dfeats + ((long)img * C + c) * H * W;
   const bool xa = (unsigned)g.x0 < (unsigned)W, xb = (unsigned)(g.x0 + 1) < (unsigned)W;
   const bool ya = (unsigned)g.y0 < (unsigned)H, yb = (unsigned)(g.y0 + 1) < (unsigned)H;
   const float wx0 = 1.f - g.wx1, wy0 = 1.f - g.wy1;
@@ -568,7 +574,7 @@ int agl_crop_fwd(const float* feats, const float* boxes, const long long* box_to
   AGL_REQUIRE(feats && boxes && box_to_img && out, "agl_crop_fwd: null pointer");
   AGL_REQUIRE(N > 0 && B >= 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "agl_crop_fwd: bad extent");
   if (B == 0) return AGL_OK;
-  LAUNCH1D(crop_fwd, (long)B * C * HH * WW, feats, boxes, box_to_img, out, B, C, H, W, HH, WW, align_corners);
+  LAUNCH1D(crop_fwd, (long)B * C * HH * WW, feats, boxes, box_to_img, out, N, B, C, H, W, HH, WW, align_corners);
   AGL_CHECK_LAUNCH("agl_crop_fwd");
   return AGL_OK;
 }
@@ -579,7 +585,7 @@ int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_
   AGL_REQUIRE(dout && boxes && box_to_img && dfeats, "agl_crop_bwd: null pointer");
   AGL_REQUIRE(N > 0 && B >= 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "agl_crop_bwd: bad extent");
   if (B == 0) return AGL_OK;
-  LAUNCH1D(crop_bwd, (long)B * C * HH * WW, dout, boxes, box_to_img, dfeats, B, C, H, W, HH, WW, align_corners);
+  LAUNCH1D(crop_bwd, (long)B * C * HH * WW, dout, boxes, box_to_img, dfeats, N, B, C, H, W, HH, WW, align_corners);
   AGL_CHECK_LAUNCH("agl_crop_bwd");
   return AGL_OK;
 }

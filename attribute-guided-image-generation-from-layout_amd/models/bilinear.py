@@ -14,6 +14,10 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn', al
     if backend == 'jj':
         raise NotImplementedError("the 'jj' backend is never used by the reference training path")
     assert bbox.size(1) == 4 and bbox.size(0) == bbox_to_feats.size(0)
+    if not bbox_to_feats.is_cuda and bbox_to_feats.numel():        # host-resident index (the reference's loop): validate for free
+        lo, hi = int(bbox_to_feats.min()), int(bbox_to_feats.max())
+        if lo < 0 or hi >= feats.size(0):
+            raise IndexError("crop_bbox_batch: bbox_to_feats must lie in [0, %d), got [%d, %d]" % (feats.size(0), lo, hi))
     return _F.crop_boxes(feats, bbox, bbox_to_feats.to(feats.device).long(), HH, WW, align_corners)
 
 

@@ -32,29 +32,40 @@ const char* agl_last_error(void);
  *   in_relu  : relu applied to x while gathering (discriminator.py:71 in-place ReLU).
  *   relu     : relu on the output;  accumulate: y += result (before relu).
  *   ws       : optional split-K scratch (agl_conv2d_splitk_ws_bytes); without it small grids run unsplit.      */
-/* Arithmetic of the MFMA convolutions: 0 = exact fp32 (default, BASELINE config 2), 1 = bf16 operands with fp32
- * accumulation (BASELINE configs 3/5).  Process-wide; everything else (statistics, SN, losses, Adam) stays fp32. */
-int agl_set_conv_precision(int mode);
-int agl_get_conv_precision(void);
-/* 1 (default): stride-1 3x3/5x5 convolutions on power-of-two maps use the LDS-patch kernel; 0: always im2col. */
-int agl_set_conv_patch(int on);
-int agl_set_conv_pos(int on);   /* 0: no position-major path on <= 8x8 maps (A/B tests) */
+/* flags (per call; no process-wide switches):
+ *   AGL_CONV_BF16        MFMA operands rounded to bf16 (RNE), fp32 accumulation (BASELINE configs 3/5); default is exact
+ *                        fp32 MFMA (config 2).  Statistics, SN, losses and Adam are fp32 either way.
+ *   AGL_CONV_NO_PATCH    never use the LDS-patch kernel (A/B tests);  AGL_CONV_NO_PATCH_S2: not its stride-2 form
+ *   AGL_CONV_NO_POS      never use the position-major path on <= 8x8 maps (A/B tests)
+ *   AGL_CONV_POS_ALL_KS  experiments: position-major path also for 3x3 / 4x4 kernels                                  */
+#define AGL_CONV_BF16 1
+#define AGL_CONV_NO_PATCH 2
+#define AGL_CONV_NO_PATCH_S2 4
+#define AGL_CONV_NO_POS 8
+#define AGL_CONV_POS_ALL_KS 16
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                   void* stream);
+                   int flags, void* stream);
 /* Gradient wrt the input of the conv above; ALSO the forward of nn.ConvTranspose2d(k=4,s=2,p=1)
  * (generator_obj_att.py:532,536,540) with w stored [C_in_T][C_out_T][4][4].  pos_mask (optional, shaped
  * like dx): dx is zeroed where pos_mask <= 0 (backward of a fused input ReLU).                      */
 int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
                         long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
-                        int relu, int accumulate, void* stream);
+                        int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
 int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H,
                           int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
-                          int accumulate, void* stream);
+                          int accumulate, int flags, void* stream);
+/* Executed FLOPs (2*MAC) of the launches one such call issues (dense count minus the padded taps the position-major
+ * path skips) — what bench.py's roofline leg divides by the measured launch time. */
+double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags);
+double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
+                                 int flags);
+double agl_conv2d_bwd_weight_flops(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad,
+                                   int up_log2, int in_relu, int flags);
 
 /* ---- batch-statistics normalisation --------------------------------------------------------------
  * nn.BatchNorm2d/1d in training mode (generator_obj_att.py:35,54,57,433,583,585; normalization.py:78):
@@ -78,7 +89,9 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;
- * align_corners as in torch (default 0).  Backward scatter-adds into dfeats (caller zero-fills).      */
+ * align_corners as in torch (default 0).  Backward scatter-adds into dfeats (caller zero-fills).  A box whose
+ * box_to_img is outside [0,N) never touches memory: its crop is filled with NaN / its gradient is dropped (the
+ * reference asserts on the host, bilinear.py:122-123; the Python host mirror validates CPU-resident indices). */
 int agl_crop_fwd(const float* feats, const float* boxes, const long long* box_to_img, float* out, int N, int B, int C,
                  int H, int W, int HH, int WW, int align_corners, void* stream);
 int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C,
@@ -165,18 +178,24 @@ int agl_sn_backward(const void* host_layers, int n_layers, int accumulate, void*
 /* mean(BCEWithLogits(x, target)) with a constant target (F.binary_cross_entropy_with_logits vs full_like) */
 int agl_bce_logits_const(const float* x, long n, float target, float coef, float* loss_out, float* dx, void* stream);
 /* mean over annotated rows (rows whose target row-sum != 0; train64.py:241,323) of BCEWithLogits with
- * pos_weight[A]; dx is written for all rows (zero for unselected ones). rows <= 4096. */
+ * pos_weight[A]; dx is written for all rows (zero for unselected ones). */
 int agl_bce_logits_posw(const float* x, const float* targets, const float* pos_weight, long rows, int A, float coef,
                         float* loss_out, float* dx, void* stream);
-/* F.cross_entropy(logits[R][V], labels[R]) */
+/* F.cross_entropy(logits[R][V], labels[R]); a label outside [0,V) poisons the loss and its gradient row with NaN
+ * (torch raises there; this call only enqueues). */
 int agl_cross_entropy(const float* logits, const long long* labels, long R, int V, float coef, float* loss_out,
                       float* dlogits, void* stream);
 /* sum_n keep[n] * mean_len |a-b| / denom (train64.py:284-287); keep == NULL means all ones */
+long agl_l1_rows_ws_bytes(void);
 int agl_l1_rows(const float* a, const float* b, const float* keep, long N, long len, float coef, float denom,
-                float* loss_out, float* da, void* stream);
+                float* loss_out, float* da, void* ws, long ws_bytes, void* stream);
 /* -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) (train64.py:294-295) */
 int agl_kl_sum(const float* mu, const float* logvar, long n, float coef, float* loss_out, float* dmu, float* dlogvar,
                void* stream);
+
+/* Hinge GAN losses of the vendored SPADE GANLoss (models/spade/networks/loss.py:65-76; NOT on the reference's train path,
+ * which uses BCE-with-logits).  mode 0: D on real, -mean(min(x-1,0)); 1: D on fake, -mean(min(-x-1,0)); 2: G, -mean(x). */
+int agl_hinge_loss(const float* x, long n, int mode, float coef, float* loss_out, float* dx, void* stream);
 
 /* ---- host logic of the loop moved on device: attribute estimate, train64.py:156-166 ------- */
 /* N3: object masks from boxes on device (data/vg_custom_mask.py:136,158: python round(), slice semantics) */

@@ -386,11 +386,125 @@ def full_step(tag, res, n_images, ppi, n_steps):
     print(f"  wrote step{tag}.npz")
 
 
+
+# =========================================================================== eval-mode fixtures
+def eval_mode(tag, res, n_images, ppi):
+    """netG.eval() / netD.eval() forwards of the REFERENCE (running statistics, spectral norm without a power iteration;
+    test64.py:96-101,132-141) on a small batch: pins the oracle's train=False branches and gives the GPU eval test a
+    reference-generated fixture."""
+    print(f"[eval {tag}] {res}px N={n_images} objs/img={ppi}")
+    res128 = res == 128
+    obj_size = 64 if res128 else 32
+    gmod = ref_g128 if res128 else ref_g64
+    batch_np = synth.make_batch(n_images, res, seed=4321, objs_per_image=ppi)
+    b = {k: T(v) for k, v in batch_np.items()}
+    O = b["objs"].shape[0]
+    rb = ReferenceBackend(gmod, res128, obj_size, synth.NUM_OBJECT_CLASSES, synth.NUM_ATTRIBUTES, 64)
+    g = torch.Generator().manual_seed(7)
+    eps = [torch.randn(O, 64, generator=g) for _ in range(3)]
+    # a few training-mode forwards first: the closed-form fill leaves the spectral-norm u/v far from a singular pair
+    # (sigma ~ 1e-3, logits ~ 1e15); three power iterations give the eval forwards a meaningful scale
+    with torch.no_grad():
+        for _ in range(3):
+            rb.netDi(b["imgs"])
+            c0 = rb.crop(b["imgs"], b["boxes"], b["obj_to_img"])
+            rb.netDo(c0, b["objs"])
+            rb.netDa(c0)
+    st = {k: {n: v.clone() for n, v in sd.items()} for k, sd in rb.states().items()}
+    for m in (rb.netG, rb.netDi, rb.netDo, rb.netDa):
+        m.eval()
+    with torch.no_grad():
+        o_ref = rb.gen(b, eps)
+        img = o_ref[5]                                            # img_rand
+        crops = o_ref[2]
+        d_img = rb.netDi(img)
+        d_src, d_cls = rb.netDo(crops, b["objs"])
+        d_att = rb.netDa(crops)
+    # state must be untouched by eval forwards
+    for net, sd in rb.states().items():
+        for k, v in sd.items():
+            assert torch.equal(v, st[net][k]), (net, k)
+    P = {k: sub(v) for k, v in st.items()}
+    with torch.no_grad():
+        o_or = OG.generator(P["G"], b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                            b["masks_shift"], b["boxes_shift"], b["attribute_est"], obj_size=obj_size, res128=res128,
+                            train=False, eps=eps)
+        names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift",
+                 "mu", "logvar", "z_rand_rec", "z_rand_shift"]
+        for n, a, r in zip(names, o_or, o_ref):
+            check(f"eval G out {n}", a, r, 1e-5)
+        check("eval D_img", OG.image_discriminator(P["D_img"], img, False), d_img, 1e-5)
+        s_or, c_or = OG.object_discriminator(P["D_obj"], crops, False)
+        check("eval D_obj src", s_or, d_src, 1e-5)
+        check("eval D_obj cls", c_or, d_cls, 1e-5)
+        check("eval D_att", OG.attribute_discriminator(P["D_att"], crops, False, res128), d_att, 1e-5)
+    out = dict(objs_per_image=np.asarray(ppi), res=np.int64(res), eps=np.stack([np32(e) for e in eps]))
+    for net in ("D_img", "D_obj", "D_att"):          # the advanced u/v the eval forwards used (weights are the closed-form fill)
+        for k, v in st[net].items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                out[f"sn_{net}_{k}"] = np32(v)
+    out.update({"batch_" + k: v for k, v in batch_np.items()})
+    for n, r in zip(names, o_ref):
+        out["out_" + n] = np32(r)
+    out.update(d_img=np32(d_img), d_obj_src=np32(d_src), d_obj_cls=np32(d_cls), d_att=np32(d_att))
+    np.savez_compressed(os.path.join(OUT, f"eval{tag}.npz"), **out)
+    print(f"  wrote eval{tag}.npz")
+
+
+# =========================================================================== checkpoint-saver trace (SURVEY 8f N4)
+def saver_trace():
+    """Drives the REFERENCE's utils/model_saver_iter.py (torch only) through a save / prune / load sequence on a tiny
+    module in a temp dir and records what it did: the directory listing after every save, and for every load the file
+    it read and the iteration it returned.  tests/test_hostlogic_cpu.py replays the trace on agl.checkpoint."""
+    import json
+    import tempfile
+    import types
+    import utils.model_saver_iter as ref_saver        # the reference's (REF precedes everything on sys.path)
+    assert ref_saver.__file__.startswith(REF), ref_saver.__file__
+    print("[saver_trace]")
+    picked = []
+
+    def load_proxy(path, map_location=None):          # the container has no cuda:0 (model_saver_iter.py:39): record + load on CPU
+        picked.append(os.path.basename(path))
+        return torch.load(path, map_location="cpu")
+    ref_saver.torch = types.SimpleNamespace(load=load_proxy, save=torch.save)
+    net = lambda: torch.nn.Linear(3, 2)
+    ops = []
+    with tempfile.TemporaryDirectory() as d:
+        md = os.path.join(d, "models")
+        r = ref_saver.load_model(net(), model_dir=md, appendix="netG", iter="l")
+        ops.append(dict(op="load", iter="l", appendix="netG", returned=r, picked=None, note="dir missing"))
+        seq = [(1000, "netG", 3, 1000), (1000, "netD_image", 3, 1000), (2000, "netG", 3, 1000), (2000, "netD_image", 3, 1000),
+               (3000, "netG", 3, 1000), (4000, "netG", 3, 1000), (4000, "netD_image", 3, 1000), (4500, "netG", 2, 500),
+               (4500, "netD_image", 2, 500), (5000, None, 2, 500)]
+        for it, app, num, stp in seq:
+            ref_saver.save_model(net(), model_dir=md, appendix=app, iter=it, save_num=num, save_step=stp)
+            ops.append(dict(op="save", iter=it, appendix=app, save_num=num, save_step=stp, files_after=sorted(os.listdir(md))))
+        for app in ("netG", "netD_image", None):
+            picked.clear()
+            r = ref_saver.load_model(net(), model_dir=md, appendix=app, iter="l")
+            ops.append(dict(op="load", iter="l", appendix=app, returned=r, picked=picked[-1] if picked else None))
+        picked.clear()
+        r = ref_saver.load_model(net(), model_dir=md, appendix=None, iter=5000)       # only one file of that iteration
+        ops.append(dict(op="load", iter=5000, appendix=None, returned=r, picked=picked[-1] if picked else None))
+        r = ref_saver.load_model(net(), model_dir=md, appendix=None, iter=1234)
+        ops.append(dict(op="load", iter=1234, appendix=None, returned=r, picked=None))
+        r = ref_saver.load_model(net(), model_dir=md, appendix="netG", iter="s")
+        ops.append(dict(op="load", iter="s", appendix="netG", returned=r, picked=None))
+    for o in ops:
+        print("  ", o)
+    with open(os.path.join(OUT, "saver_trace.json"), "w") as f:
+        json.dump(ops, f, indent=1)
+    print("  wrote saver_trace.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ops", action="store_true")
     ap.add_argument("--skip-step64", action="store_true")
     ap.add_argument("--skip-step128", action="store_true")
+    ap.add_argument("--skip-eval", action="store_true")
+    ap.add_argument("--skip-saver", action="store_true")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -401,6 +515,11 @@ def main():
         full_step("64", 64, 4, [3, 9, 5, 7], 2)          # BASELINE config 1
     if not a.skip_step128:
         full_step("128", 128, 2, [4, 6], 1)
+    if not a.skip_eval:
+        eval_mode("64", 64, 3, [4, 2, 6])
+        eval_mode("128", 128, 2, [3, 5])
+    if not a.skip_saver:
+        saver_trace()
 
 
 if __name__ == "__main__":

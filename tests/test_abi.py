@@ -12,7 +12,7 @@ def _header_decls():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"struct AglSnLayer \{.*?\};", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"(?:const char\*|int|long)\s+(agl_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?:const char\*|int|long|double)\s+(agl_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
         decls[m.group(1)] = n

@@ -33,10 +33,53 @@ def test_checkpoint_naming_pruning_and_latest(tmp_path):
     assert list(sd.keys()) == list(m.state_dict().keys())
 
 
+def test_checkpoint_replays_reference_saver_trace(tmp_path, golden_dir):
+    """N4 pinned to the reference: tests/golden/saver_trace.json records what the REFERENCE's utils/model_saver_iter.py
+    did for a save / prune / load sequence (oracle/make_golden.py::saver_trace drives it); agl.checkpoint must leave the
+    same directory listing after every save, read the same file and return the same iteration for every load."""
+    import json
+    from agl import checkpoint as CK
+    ops = json.load(open(os.path.join(golden_dir, "saver_trace.json")))
+    d = str(tmp_path / "models")
+    picked = []
+    real_load = torch.load
+    try:
+        torch.load = lambda path, *a, **k: (picked.append(os.path.basename(path)), real_load(path, *a, **k))[1]
+        for o in ops:
+            if o["op"] == "save":
+                CK.save_model(nn.Linear(3, 2), d, appendix=o["appendix"], iter=o["iter"], save_num=o["save_num"], save_step=o["save_step"])
+                assert sorted(os.listdir(d)) == o["files_after"], o
+            else:
+                picked.clear()
+                r = CK.load_model(nn.Linear(3, 2), d, appendix=o["appendix"], iter=o["iter"])
+                assert r == o["returned"], o
+                assert (picked[-1] if picked else None) == o["picked"], (o, picked)
+    finally:
+        torch.load = real_load
+
+
+def test_latest_model_never_picks_the_optimizer_file(tmp_path):
+    """`iter-<n>_optim.pkl` lives next to the network files; load_model(iter='l', appendix=None) and an
+    explicit iteration must skip it."""
+    from agl import checkpoint as CK
+    d = str(tmp_path / "ck")
+    m = nn.Linear(3, 2)
+    CK.save_model(m, d, appendix=None, iter=1000, save_num=5, save_step=1000)
+    torch.save({"g_m": torch.zeros(3), "g_step": 7}, os.path.join(d, "iter-2000_optim.pkl"))
+    torch.save({"g_m": torch.zeros(3), "g_step": 7}, os.path.join(d, "iter-1000_optim.pkl"))
+    assert CK.load_model(nn.Linear(3, 2), d, appendix=None, iter='l') == 1000
+    assert CK.load_model(nn.Linear(3, 2), d, appendix=None, iter=1000) == 1000
+    assert CK.load_model(nn.Linear(3, 2), d, appendix=None, iter=2000) == 0      # only an optimiser file: scratch
+
+
 def test_dropin_import_paths():
     import utils.model_saver_iter as MS
     from agl import checkpoint as CK
     assert MS.load_model is CK.load_model and MS.save_model is CK.save_model
+    import models.discriminator as MD
+    import models.spade.networks.loss as ML
+    from agl import losses as LS
+    assert MD.loss_hinge_dis is LS.loss_hinge_dis and ML.loss_hinge_gen is LS.loss_hinge_gen
 
 
 def test_swap_rows_match_oracle_loop():

@@ -302,17 +302,14 @@ def test_step_bf16_mode_vs_reference_fixture(tag, res128, golden_dir):
     from agl import lib as L
     from agl.trainer import Trainer, batch_to_device
     g = np.load(os.path.join(golden_dir, f"step{tag}.npz"), allow_pickle=False)
-    L.set_conv_precision("bf16")
-    try:
-        G, Di, Do, Da = build_nets(res128)
-        tr = Trainer(G, Di, Do, Da, torch.from_numpy(g["pos_weight"]))
-        b = batch_to_device({k[len("batch_"):]: g[k] for k in g.files if k.startswith("batch_")}, DEV)
-        tr.step(b, [torch.from_numpy(e) for e in g["s0_eps_d"]], [torch.from_numpy(e) for e in g["s0_eps_g"]])
-        tr.finish()
-        torch.cuda.synchronize()
-        losses = tr.loss_dict()
-    finally:
-        L.set_conv_precision("f32")
+    G, Di, Do, Da = build_nets(res128)
+    tr = Trainer(G, Di, Do, Da, torch.from_numpy(g["pos_weight"]), conv_dtype="bf16")
+    b = batch_to_device({k[len("batch_"):]: g[k] for k in g.files if k.startswith("batch_")}, DEV)
+    tr.step(b, [torch.from_numpy(e) for e in g["s0_eps_d"]], [torch.from_numpy(e) for e in g["s0_eps_g"]])
+    tr.finish()
+    torch.cuda.synchronize()
+    losses = tr.loss_dict()
+    assert L.CONV_FLAGS == 0, "the trainer's conv flags must not leak out of step()"
     for name, ref in zip(g["s0_loss_names"], g["s0_loss_values"]):
         got = losses[str(name)]
         assert abs(got - ref) <= 1e-2 * max(1.0, abs(ref)), (str(name), got, float(ref))
@@ -493,3 +490,123 @@ def test_generator_pass_reuse_equals_two_full_passes():
                     close(a[k], r[k], stat_tol, f"iteration {it}: {k}")
                 else:
                     assert float((a[k].double() - r[k].double()).abs().max()) <= w_tol + 1e-5 * float(r[k].abs().max()), (it, k)
+
+
+@pytest.mark.parametrize("tag", ["64", "128"])
+def test_eval_mode_vs_reference_fixture(tag, golden_dir):
+    """N2 pinned to the reference: tests/golden/eval{64,128}.npz hold the outputs of the REFERENCE's netG.eval() and
+    netD_*.eval() forwards (test64.py:96-101,132-141; generated by oracle/make_golden.py::eval_mode from closed-form
+    weights plus the recorded, power-iterated spectral-norm u/v).  Tolerance 1e-3 relative-to-max per tensor."""
+    g = np.load(os.path.join(golden_dir, f"eval{tag}.npz"))
+    res128 = tag == "128"
+    nets = dict(zip(("G", "D_img", "D_obj", "D_att"), build_nets(res128)))
+    for k, m in nets.items():
+        sd = m.state_dict()
+        for name in sd:
+            key = f"sn_{k}_{name}"
+            if key in g.files:
+                sd[name].copy_(torch.from_numpy(g[key]))
+        m.eval()
+    G, Di, Do, Da = nets["G"], nets["D_img"], nets["D_obj"], nets["D_att"]
+    b = {k[len("batch_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("batch_")}
+    d = {k: (v.to(DEV) if k != "obj_to_img" else v) for k, v in b.items()}
+    eps = [torch.from_numpy(e) for e in g["eps"]]
+    before = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in nets.items()}
+    with torch.no_grad():
+        out = G(d["imgs"], d["objs"], d["boxes"], d["masks"], d["obj_to_img"], d["z"], d["attribute"], d["masks_shift"],
+                d["boxes_shift"], d["attribute_est"], eps=eps)
+        names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift", "mu", "logvar",
+                 "z_rand_rec", "z_rand_shift"]
+        for n, a in zip(names, out):
+            close(a, torch.from_numpy(g["out_" + n]), 1e-3, "eval G " + n)
+        img, crops = torch.from_numpy(g["out_img_rand"]).to(DEV), torch.from_numpy(g["out_crops_rand"]).to(DEV)
+        close(Di(img), torch.from_numpy(g["d_img"]), 1e-3, "eval D_img")
+        src, cls = Do(crops, d["objs"])
+        close(src, torch.from_numpy(g["d_obj_src"]), 1e-3, "eval D_obj src")
+        close(cls, torch.from_numpy(g["d_obj_cls"]), 1e-3, "eval D_obj cls")
+        close(Da(crops), torch.from_numpy(g["d_att"]), 1e-3, "eval D_att")
+    for k, m in nets.items():                       # eval forwards must not move any state
+        for n, v in m.state_dict().items():
+            assert torch.equal(v, before[k][n]), (k, n)
+
+
+def test_full_step_at_config2_size_vs_oracle():
+    """The WHOLE iteration at BASELINE config 2 size (64 px, batch 64, P ~ U{3..9}, O ~ 390) against the CPU oracle on the
+    box's host cores: the size-dependent kernel choices (position-major ConvLSTM path needs >= 96 objects, 256x128 tiles,
+    split-K plans, batched layout-encoder calls) are only met end-to-end, with BatchNorm / spectral-norm state, at this
+    size.  Checked: the 15 logged losses (<= 1e-4 relative for the D losses computed from identical state, 5e-3 for the G
+    losses that follow the discriminators' first lr*sign(g) Adam update), the generated images / latents (<= 2e-3
+    relative-to-max) and every per-tensor gradient norm (<= 1e-2 relative, tensors above 1e-3 of the largest norm)."""
+    from agl import synth
+    from agl.trainer import Trainer, batch_to_device
+    import oracle.step as OS
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    G, Di, Do, Da = build_nets(False)
+    nets = {"G": G, "D_img": Di, "D_obj": Do, "D_att": Da}
+    cpu = lambda net: {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ob = OS.OracleBackend(cpu(G), cpu(Di), cpu(Do), cpu(Da), res128=False, obj_size=32)
+    pw = torch.from_numpy(synth.make_pos_weight())
+    bn = synth.make_batch(64, 64, seed=1234)
+    O = bn["objs"].shape[0]
+    assert O >= 96 * 3
+    gen = torch.Generator().manual_seed(21)
+    eps_d = [torch.randn(O, 64, generator=gen) for _ in range(3)]
+    eps_g = [torch.randn(O, 64, generator=gen) for _ in range(3)]
+    norms, ref_norms = {}, {}
+
+    def grab(which):
+        def f(t):
+            for k in which:
+                norms[k] = np.array([float(q.grad.double().norm()) for q in nets[k].parameters()])
+        return f
+
+    def grab_ref(which):
+        def f(be):
+            st = be.states()
+            for k in which:
+                ref_norms[k] = np.array([float(v.grad.double().norm()) for v in st[k].values() if v.requires_grad])
+        return f
+
+    tr = Trainer(G, Di, Do, Da, pw)
+    tr.on_d_backward, tr.on_g_backward = grab(["D_img", "D_obj", "D_att"]), grab(["G"])
+    tr.step(batch_to_device(bn, DEV), eps_d, eps_g)
+    tr.finish()
+    torch.cuda.synchronize()
+    hip = tr.loss_dict()
+    bc = {k: torch.from_numpy(v) for k, v in bn.items()}
+    ref, out_ref = OS.run_step(ob, bc, pw, eps_d, eps_g, on_d_backward=grab_ref(["D_img", "D_obj", "D_att"]),
+                               on_g_backward=grab_ref(["G"]))
+    for k, r in ref.items():
+        tol = 1e-4 if k.startswith("D/") else 5e-3
+        assert abs(hip[k] - r) <= tol * max(1.0, abs(r)), (k, hip[k], r)
+    for i, (a, r) in enumerate(zip(tr.last_outputs, out_ref)):
+        close(a, r, 2e-3, f"G output {i} at config-2 size")
+    for k in nets:
+        rel = np.abs(norms[k] - ref_norms[k]) / (ref_norms[k] + 1e-9)
+        bad = np.nonzero((rel > 1e-2) & (ref_norms[k] > 1e-3 * ref_norms[k].max()))[0]
+        names = [n for n, _ in nets[k].named_parameters()]
+        assert bad.size == 0, (k, [(names[i], float(norms[k][i]), float(ref_norms[k][i])) for i in bad[:5]])
+
+
+def test_hinge_losses_vs_torch():
+    """loss_hinge_dis / loss_hinge_gen (models/spade/networks/loss.py:65-76; off the reference's train path) against the
+    torch-CPU arithmetic of GANLoss('hinge'): values and gradients <= 1e-6."""
+    from models.discriminator import loss_hinge_dis, loss_hinge_gen
+    g = torch.Generator().manual_seed(3)
+    fake, real = torch.randn(37, generator=g) * 2, torch.randn(37, generator=g) * 2
+    fr, rr = fake.clone().requires_grad_(True), real.clone().requires_grad_(True)
+    ref = -torch.mean(torch.min(rr - 1, torch.zeros_like(rr))) - torch.mean(torch.min(-fr - 1, torch.zeros_like(fr)))
+    ref.backward()
+    fg, rg = fake.to(DEV).requires_grad_(True), real.to(DEV).requires_grad_(True)
+    out = loss_hinge_dis(fg, rg)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    close(fg.grad, fr.grad, 1e-6, "d hinge / d fake")
+    close(rg.grad, rr.grad, 1e-6, "d hinge / d real")
+    f2 = fake.clone().requires_grad_(True)
+    (-f2.mean()).backward()
+    f3 = fake.to(DEV).requires_grad_(True)
+    o3 = loss_hinge_gen(f3)
+    o3.backward()
+    assert abs(float(o3) + float(fake.mean())) <= 1e-6
+    close(f3.grad, f2.grad, 1e-6, "d hinge_gen")

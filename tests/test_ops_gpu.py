@@ -288,13 +288,10 @@ def test_conv2d_bf16_operand_mode(case):
     gy = rn(*yr.shape, seed=3)
     yr.backward(r(gy))                       # reference of the backward passes: rounded dy as well
     y32 = TF.conv2d(x, w, None, stride=s, padding=p)
-    L.set_conv_precision("bf16")
-    try:
+    with L.conv_flags(L.CONV_BF16):
         xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
         yg = F.conv2d(xg, wg, None, s, p)
         yg.backward(dev(gy))
-    finally:
-        L.set_conv_precision("f32")
     close(yg, yr, 2e-5, "y vs fp32 conv of bf16-rounded operands")
     close(yg, y32, 2e-2, "y vs plain fp32")
     close(xg.grad, xr.grad, 1e-4, "dx")
@@ -384,7 +381,7 @@ POS_CASES = [
 @pytest.mark.parametrize("case", POS_CASES)
 def test_position_major_conv_vs_torch_and_im2col(case):
     """Small-map convolutions run as per-position sums of plain matrix products (padded taps are never visited);
-    results must match torch and the im2col/patch kernels (agl_set_conv_pos(0)) to fp32 rounding, including the
+    results must match torch and the im2col/patch kernels (flag AGL_CONV_NO_POS) to fp32 rounding, including the
     fused input ReLU, bias, output ReLU and accumulate epilogues."""
     from agl import lib as L
     N, Cin, H, Cout, ks, s, p = case
@@ -398,11 +395,8 @@ def test_position_major_conv_vs_torch_and_im2col(case):
     close(y2, base + TF.conv2d(x, w, None, stride=s, padding=p), 2e-5, "accumulate")
     y3 = L.conv2d_fwd(xd, wd, bd, s, p, relu=True)
     close(y3, torch.relu(TF.conv2d(x, w, b, stride=s, padding=p)), 2e-5, "output ReLU")
-    L.call("agl_set_conv_pos", 0)
-    try:
+    with L.conv_flags(L.CONV_NO_POS):
         y_ref = L.conv2d_fwd(xd, wd, bd, s, p, in_relu=True)
-    finally:
-        L.call("agl_set_conv_pos", 1)
     close(y, y_ref, 5e-6, "position-major vs im2col")
     # input gradient (same path with flipped taps, fused positive mask) and weight gradient (position-major reduction)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -477,7 +471,7 @@ def test_conv3x3_avgpool_box_form(shape):
                                   (10, 24, 9, 72, 3, 0), (2, 128, 64, 64, 4, 1)])
 def test_patch_conv_stride2_forward(case):
     """4x4/stride-2 and 3x3/stride-2 forward convolutions on the LDS-patch kernel (stride template): against torch and
-    against the im2col kernel (agl_set_conv_patch(2) = stride-1 patches only), with bias / input ReLU / output ReLU."""
+    against the im2col kernel (flag AGL_CONV_NO_PATCH_S2 = stride-1 patches only), with bias / input ReLU / output ReLU."""
     from agl import lib as L
     N, Cin, H, Cout, ks, p = case
     x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
@@ -485,11 +479,8 @@ def test_patch_conv_stride2_forward(case):
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = L.conv2d_fwd(xd, wd, bd, 2, p, in_relu=True, relu=True)
     close(y, yr, 2e-5, "y")
-    L.call("agl_set_conv_patch", 2)
-    try:
+    with L.conv_flags(L.CONV_NO_PATCH_S2):
         y_ref = L.conv2d_fwd(xd, wd, bd, 2, p, in_relu=True, relu=True)
-    finally:
-        L.call("agl_set_conv_patch", 1)
     close(y, y_ref, 5e-6, "patch vs im2col")
 
 
@@ -530,3 +521,134 @@ def test_grid_gather_and_spade_block_grids():
         close(ds1, ds2, 2e-4, f"SPADE dseg S={S}")
         for a, r in zip(gp1, gp2):
             close(a, r, 2e-4, f"SPADE parameter gradient S={S}")
+
+
+def test_crop_rejects_or_poisons_out_of_range_box_index():
+    """a box whose image index is outside [0, N) must never read or scatter into foreign memory.  The
+    drop-in wrapper validates a CPU-resident index like the reference's asserts (bilinear.py:122-123); with a device
+    index the kernel fills that crop with NaN and drops its gradient, the other boxes are unaffected."""
+    from agl import lib as L
+    from models.bilinear import crop_bbox_batch
+    feats = rn(2, 3, 16, 16)
+    boxes = torch.tensor([[0.1, 0.1, 0.6, 0.7], [0.2, 0.0, 0.9, 0.5], [0.0, 0.3, 0.5, 1.0]])
+    with pytest.raises(IndexError):
+        crop_bbox_batch(dev(feats), dev(boxes), torch.tensor([0, 2, 1]), 8)
+    with pytest.raises(IndexError):
+        crop_bbox_batch(dev(feats), dev(boxes), torch.tensor([0, -1, 1]), 8)
+    good = L.crop_fwd(dev(feats), dev(boxes), dev(torch.tensor([0, 1, 1])), 8, 8)
+    bad = L.crop_fwd(dev(feats), dev(boxes), dev(torch.tensor([0, 7, 1])), 8, 8)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad[1]).all() and torch.equal(bad[0], good[0]) and torch.equal(bad[2], good[2])
+    gy = dev(rn(3, 3, 8, 8, seed=2))
+    d_bad = L.crop_bwd(gy, dev(boxes), dev(torch.tensor([0, -3, 1])), (2, 3, 16, 16))
+    gy2 = gy.clone()
+    gy2[1] = 0
+    d_ref = L.crop_bwd(gy2, dev(boxes), dev(torch.tensor([0, 1, 1])), (2, 3, 16, 16))
+    close(d_bad, d_ref.cpu(), 1e-6, "gradient of the valid boxes only")
+
+
+def test_loss_kernels_large_rows_and_bad_labels():
+    """the attribute BCE takes any number of rows (was capped at 4096 by an LDS table); an out-of-range class
+    label poisons the cross-entropy with NaN instead of reading out of bounds; the multi-block L1 equals torch."""
+    from agl import losses as LS
+    g = torch.Generator().manual_seed(5)
+    rows, A = 5000, 106
+    x = torch.randn(rows, A, generator=g)
+    t = (torch.rand(rows, A, generator=g) < 0.02).float()
+    t[::3] = 0                                          # un-annotated rows
+    pw = torch.rand(A, generator=g) * 20 + 1
+    sel = t.sum(1) != 0
+    xr = x.clone().requires_grad_(True)
+    ref = TF.binary_cross_entropy_with_logits(xr[sel], t[sel], pos_weight=pw)
+    ref.backward()
+    slot = torch.zeros(1, device=DEV)
+    dx = LS.bce_posw(dev(x), dev(t), dev(pw), 1.0, slot)
+    assert abs(float(slot) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    close(dx, xr.grad, 1e-5, "bce_posw gradient, 5000 rows")
+    lg = torch.randn(6, 11, generator=g)
+    lab = torch.tensor([0, 10, 3, 11, 2, -1])
+    dl = LS.cross_entropy(dev(lg), dev(lab), 1.0, slot)
+    assert torch.isnan(slot).all() and torch.isnan(dl[3]).all() and torch.isnan(dl[5]).all() and torch.isfinite(dl[0]).all()
+    a, b = torch.randn(7, 3, 64, 64, generator=g), torch.randn(7, 3, 64, 64, generator=g)
+    keep = torch.tensor([0., 0., 1., 1., 1., 1., 1.])
+    ar = a.clone().requires_grad_(True)
+    ref = (keep.view(-1, 1, 1, 1) * (ar - b).abs()).sum() / (3 * 64 * 64 * 5.0)
+    ref.backward()
+    da = LS.l1_rows(dev(a), dev(b), dev(keep), 1.0, 5.0, slot)
+    assert abs(float(slot) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    close(da, ar.grad, 1e-6, "l1_rows gradient")
+
+
+def test_modules_vs_reference_op_fixtures(golden_dir):
+    """The ConditionalBatchNorm2d / SPADE / spectrally-normalised discriminator-block vectors of tests/golden/ops_small.npz
+    (outputs, input and parameter gradients, running statistics after 1 and 3 calls, spectral-norm u/v after k forwards —
+    all produced by the imported REFERENCE modules) on the HIP path, with the closed-form weights of oracle/fill.py."""
+    from oracle.fill import fill_state
+    from models.generator_obj_att import ConditionalBatchNorm2d
+    from models.spade.networks.normalization import SPADE
+    from models.discriminator import OptimizedBlock, ResidualBlock, add_sn
+    o = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    t = lambda k: torch.from_numpy(o[k])
+
+    def filled(m):
+        m.load_state_dict(fill_state(m.state_dict()))
+        return m.to(DEV)
+
+    def sn_w(m):      # what the owning discriminator does once per forward call (agl.discriminator._Discriminator._weights)
+        from agl import functional as F
+        mods = [q for q in m.modules() if getattr(q, "has_sn", False)]
+        ws = F.spectral_norm_weights([q.weight_orig for q in mods], [q.weight_u for q in mods], [q.weight_v for q in mods], m.training)
+        return {id(q): w for q, w in zip(mods, ws)}
+
+    cbn = filled(ConditionalBatchNorm2d(6, 5))
+    x = dev(t("cbn_x")).requires_grad_(True)
+    y = cbn(x, dev(t("cbn_labels")))
+    y.backward(dev(t("cbn_gy")))
+    close(y, t("cbn_y"), 2e-5, "condbn y")
+    close(x.grad, t("cbn_dx"), 2e-4, "condbn dx")
+    close(cbn.embed.weight.grad, t("cbn_dembed"), 2e-4, "condbn dembed")
+    close(cbn.bn.running_mean, t("cbn_rm1"), 1e-5, "condbn running_mean after 1")
+    close(cbn.bn.running_var, t("cbn_rv1"), 1e-5, "condbn running_var after 1")
+    for _ in range(2):
+        cbn(dev(t("cbn_x") * 1.5 + 0.3), dev(t("cbn_labels")))
+    close(cbn.bn.running_mean, t("cbn_rm3"), 1e-5, "condbn running_mean after 3")
+    close(cbn.bn.running_var, t("cbn_rv3"), 1e-5, "condbn running_var after 3")
+
+    for S in (8, 16):
+        sp = filled(SPADE(16, 64))
+        k = f"spade{S}_"
+        x, seg = dev(t(k + "x")).requires_grad_(True), dev(t(k + "seg")).requires_grad_(True)
+        y = sp(x, seg)
+        y.backward(dev(t(k + "gy")))
+        close(y, t(k + "y"), 2e-5, k + "y")
+        close(x.grad, t(k + "dx"), 2e-4, k + "dx")
+        close(seg.grad, t(k + "dseg"), 2e-4, k + "dseg")
+        close(sp.mlp_shared[0].weight.grad, t(k + "dWshared"), 2e-4, k + "dWshared")
+        close(sp.mlp_gamma.weight.grad, t(k + "dWgamma"), 2e-4, k + "dWgamma")
+        close(sp.mlp_beta.bias.grad, t(k + "dbbeta"), 2e-4, k + "dbbeta")
+        close(sp.param_free_norm.running_var, t(k + "rv1"), 1e-5, k + "running_var")
+
+    for tag, down in (("opt_down", True), ("opt_flat", False)):
+        m = filled(add_sn(OptimizedBlock(3, 8, downsample=down)))
+        x = dev(t(f"d{tag}_x")).requires_grad_(True)
+        y = m(x, sn_w(m))
+        y.backward(dev(t(f"d{tag}_gy")))
+        close(y, t(f"d{tag}_y"), 5e-5, tag + " y")
+        close(x.grad, t(f"d{tag}_dx"), 5e-4, tag + " dx")
+        close(m.resi[2].weight_orig.grad, t(f"d{tag}_dW2"), 5e-4, tag + " dW2")
+        close(m.sc.weight_orig.grad, t(f"d{tag}_dWsc"), 5e-4, tag + " dWsc")
+        close(m.resi[0].weight_u, t(f"d{tag}_u0"), 1e-5, tag + " u after 1 forward")
+    m = filled(add_sn(ResidualBlock(8, 16, downsample=True)))
+    x = dev(t("dres_x")).requires_grad_(True)
+    y = m(x * 1.0, sn_w(m))
+    y.backward(dev(t("dres_gy")))
+    close(y, t("dres_y"), 5e-5, "D res y (aliased shortcut)")
+    close(x.grad, t("dres_dx"), 5e-4, "D res dx")
+    close(m.resi[3].weight_orig.grad, t("dres_dW3"), 5e-4, "D res dW3")
+    close(m.sc.weight_orig.grad, t("dres_dWsc"), 5e-4, "D res dWsc")
+    for k in range(2, 8):
+        with torch.no_grad():
+            m(dev(t("dres_x")).clone(), sn_w(m))
+        if k in (3, 7):
+            close(m.resi[3].weight_u, t(f"dres_u3_after{k}"), 2e-5, f"SN u after {k} forwards")
+            close(m.resi[3].weight_v, t(f"dres_v3_after{k}"), 2e-5, f"SN v after {k} forwards")

@@ -160,6 +160,56 @@ def test_oracle_step_reproduces_fixture_losses(golden_dir):
     same(outs[4], g["s0_out_img_rec"], 1e-5)
 
 
+def _eval_states(g, res128):
+    """Closed-form weights + the advanced spectral-norm u/v the fixture recorded (oracle/make_golden.py::eval_mode)."""
+    if res128:
+        from models.generator_obj_att128 import Generator
+        from models.discriminator import AttributeDiscriminator128 as AttD
+    else:
+        from models.generator_obj_att import Generator
+        from models.discriminator import AttributeDiscriminator as AttD
+    from models.discriminator import ImageDiscriminator, ObjectDiscriminator, add_sn
+    nets = {"G": Generator(num_embeddings=179, obj_att_dim=64, z_dim=64, clstm_layers=3, obj_size=64 if res128 else 32, attribute_dim=106),
+            "D_img": add_sn(ImageDiscriminator(conv_dim=64)), "D_obj": add_sn(ObjectDiscriminator(n_class=179)),
+            "D_att": add_sn(AttD(n_attribute=106))}
+    states = {}
+    for k, m in nets.items():
+        st = fill_state(m.state_dict())
+        for name in st:
+            key = f"sn_{k}_{name}"
+            if key in g.files:
+                st[name] = T(g[key])
+        states[k] = st
+    return nets, states
+
+
+@pytest.mark.parametrize("tag", ["64", "128"])
+def test_oracle_eval_mode_reproduces_reference_fixture(tag, golden_dir):
+    """The oracle's train=False branches (BatchNorm running statistics, spectral norm without a power iteration) against
+    the reference's netG.eval() / netD.eval() outputs (tests/golden/eval{64,128}.npz, test64.py:96-101,132-141)."""
+    g = np.load(os.path.join(golden_dir, f"eval{tag}.npz"))
+    res128 = tag == "128"
+    _, st = _eval_states(g, res128)
+    P = {k: OS.as_params(v) for k, v in st.items()}
+    b = {k[len("batch_"):]: T(g[k]) for k in g.files if k.startswith("batch_")}
+    eps = [T(e) for e in g["eps"]]
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = OG.generator(P["G"], b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
+                           b["masks_shift"], b["boxes_shift"], b["attribute_est"], obj_size=64 if res128 else 32, res128=res128,
+                           train=False, eps=eps)
+        names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift", "mu", "logvar",
+                 "z_rand_rec", "z_rand_shift"]
+        for n, a in zip(names, out):
+            same(a, g["out_" + n], 1e-5)
+        img, crops = T(g["out_img_rand"]), T(g["out_crops_rand"])
+        same(OG.image_discriminator(P["D_img"], img, False), g["d_img"], 1e-5)
+        s_, c_ = OG.object_discriminator(P["D_obj"], crops, False)
+        same(s_, g["d_obj_src"], 1e-5)
+        same(c_, g["d_obj_cls"], 1e-5)
+        same(OG.attribute_discriminator(P["D_att"], crops, False, res128), g["d_att"], 1e-5)
+
+
 def test_synthetic_batch_schema_and_shift_rule():
     from agl import synth
     b = synth.make_batch(6, 64, seed=1)

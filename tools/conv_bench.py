@@ -7,15 +7,13 @@ from agl import lib as L
 
 dev = "cuda:0"
 if os.environ.get("AGL_NOPATCH"):
-    L.call("agl_set_conv_patch", 0)
+    L.CONV_FLAGS |= L.CONV_NO_PATCH
 if os.environ.get("AGL_NOPATCH_S2"):
-    L.call("agl_set_conv_patch", 2)
-if os.environ.get("AGL_POS_MIN_N"):
-    L.call("agl_set_conv_pos", int(os.environ["AGL_POS_MIN_N"]))
+    L.CONV_FLAGS |= L.CONV_NO_PATCH_S2
 if os.environ.get("AGL_POS_ALL"):
-    L.call("agl_set_conv_pos", -1)
+    L.CONV_FLAGS |= L.CONV_POS_ALL_KS
 if os.environ.get("AGL_NOPOS"):
-    L.call("agl_set_conv_pos", 0)
+    L.CONV_FLAGS |= L.CONV_NO_POS
 if os.environ.get("AGL_PREC"):
     L.set_conv_precision(os.environ["AGL_PREC"])
 O, N = 393, 64
