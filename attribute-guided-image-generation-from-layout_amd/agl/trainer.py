@@ -78,7 +78,9 @@ class Trainer:
         self.reuse_generator_pass = reuse_generator_pass
         # arithmetic of the MFMA convolutions inside step(): "f32" exact fp32 (BASELINE config 2) or "bf16" operands with
         # fp32 accumulation (configs 3/5); passed per call through the C ABI (AGL_CONV_BF16), never a process-wide switch
-        self.conv_flags = {"f32": 0, "fp32": 0, "bf16": L.CONV_BF16}[conv_dtype]
+        # "f32x3": fp32 tensors with fp32-accurate products on the bf16 matrix cores (three bf16 terms per operand, six
+        # products, AGL_CONV_SPLIT3) in the kernels that support it, exact fp32 MFMA elsewhere
+        self.conv_flags = {"f32": 0, "fp32": 0, "f32x3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[conv_dtype]
         self._in_step = False
         # With data parallelism step() returns while the G all-reduce + Adam still run on the side stream.  Readers of
         # the weights outside step() (state_dict / checkpoint.save_model, eval or user forwards) join it first.

@@ -15,6 +15,7 @@
 // LDS images are [k][row] (row-fast gathers) or [row][k] padded to 17 (k-fast gathers) so both
 // the staging writes and the 32-lane fragment reads stay (nearly) bank-conflict free.
 #include "agl_internal.h"
+#include "pconv.h"
 #include <math.h>
 #include <algorithm>
 
@@ -893,6 +894,7 @@ struct ConvOpts {
   bool patch_s2;     // ... also its stride-2 forward form
   bool pos;          // position-major path on small maps allowed
   bool pos_all_ks;   // experiments: position-major also for 3x3 / 4x4 kernels
+  bool split3;       // fp32 operands as three bf16 terms, six bf16-MFMA products (pconv.hip) where that kernel applies
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -902,9 +904,10 @@ static ConvOpts conv_opts(int flags) {
   o.patch_s2 = o.patch && !(flags & 4);
   o.pos = !(flags & 8);
   o.pos_all_ks = (flags & 16) != 0;
+  o.split3 = (flags & 32) != 0 && o.prec == 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1386,6 +1389,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
     const long pn = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad).total();
     if (pn > need) need = pn;
   }
+  if (stride == 1) need = std::max(need, pconv_ws_bytes(Cin, Cout, ks, 3));
   return need;
 }
 
@@ -1409,6 +1413,14 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
     if (ws && ws_bytes >= pl.total())
       return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st, co.prec);
+  }
+  if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
+    PConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
+    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3;
+    const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
+    if (prc >= 0) return prc;
   }
   if (co.patch) {
     PatchArgs a;
@@ -1474,6 +1486,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
     const long pn = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad).total();
     if (pn > need) need = pn;
   }
+  if (stride == 1) need = std::max(need, pconv_ws_bytes(Cout, Cin, ks, 3));
   return need;
 }
 
@@ -1499,6 +1512,14 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
     if (ws && ws_bytes >= pl.total())
       return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, co.prec, 2, pos_mask);
+  }
+  if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
+    PConvArgs a;    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+    a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
+    a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
+    a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3;
+    const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
+    if (prc >= 0) return prc;
   }
   if (stride == 1 && co.patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
     PatchArgs a;

@@ -1,0 +1,16 @@
+// Internal interface of the bf16-MFMA LDS-patch convolution (pconv.hip), used by the dispatch in conv.hip.
+#pragma once
+#include "agl_internal.h"
+
+struct PConvArgs {
+  const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
+  int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up); OH, OW: output map
+  int ks, stride, pad, up, in_relu, relu, accumulate;
+  int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
+  int nsplit;                       // 1: bf16 operands (AGL_CONV_BF16); 3: fp32 operands as three bf16 terms, six products
+};
+
+// Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
+long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
+// Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.
+int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);

@@ -1,0 +1,402 @@
+// LDS-patch convolution on the bf16 matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulation).
+//
+// Replaces, for stride-1 3x3 / 5x5 convolutions on power-of-two maps, the im2col kernel of conv.hip in the two
+// configurations where that kernel is bound by its 4-byte gathers rather than by the matrix pipe:
+//   nsplit 1  (AGL_CONV_BF16, BASELINE configs 3/5): operands rounded to bf16 (RNE) once, when they are staged;
+//   nsplit 3  (AGL_CONV_SPLIT3): fp32 operands carried as THREE bf16 terms each (a = a1 + a2 + a3 exactly, to 2^-27
+//             relative) and multiplied as the six products a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 (the dropped ones are
+//             <= 2^-27 |ab|), accumulated in fp32 — fp32-accurate products at 6/16 of the fp32-MFMA cycle cost.
+//
+// Structure (one 256-thread workgroup = 2x2 waves, output tile BM channels x 128 pixels):
+//   * the weights are re-packed once per call (pack_weights_k) into bf16 [plane][channel chunk][half][tap][m][8], so
+//     a workgroup's slice for one chunk of 16 input channels is a set of contiguous 16-byte pieces that go to LDS
+//     unchanged ([plane][half][tap][row]: the 32x32x16 A fragment of a lane is ONE conflict-free ds_read_b128);
+//   * the input patch TI x (TH+ks-1) x (TW+ks-1) of the chunk is fetched ONCE from the fp32 NCHW tensor (each element
+//     is used ks^2 times from LDS instead of being re-gathered ks^2 times), converted, and stored channel-fastest as
+//     [plane][half][pixel] 16-byte pieces: the B fragment of a lane for tap (kh,kw) is ONE ds_read_b128 at
+//     pixel(lane) + kh*pitch + kw.  Row pitches are padded so that every 16-lane read group hits 16 distinct
+//     16-byte LDS slots (checked offline for each geometry);
+//   * K order = (tap, channel): one MFMA K-step = 16 channels of one tap, matching the lane map
+//     A[row][k = 8*(lane>>5) + j], B[k][col] of v_mfma_f32_32x32x16_bf16.
+// The input-gradient of a "same" convolution runs on the same kernel through the packed weights (flipped taps,
+// channel roles swapped).  Epilogues as in conv.hip (bias, ReLU-mask of the consumer, accumulate, ReLU).
+#include "pconv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+struct PArgs {
+  const float* x; const u32x4* wp; const float* bias; const float* pos_mask; float* y;
+  int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu, relu, accumulate;
+  int nch, mpad;
+  unsigned x_bytes;
+};
+
+// a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
+__device__ __forceinline__ void split3(float a, __bf16& t0, __bf16& t1, __bf16& t2) {
+  t0 = (__bf16)a;
+  const float r1 = a - (float)t0;
+  t1 = (__bf16)r1;
+  const float r2 = r1 - (float)t1;
+  t2 = (__bf16)r2;
+}
+
+// Weight re-pack: wp[plane][cc][h][tap][m][j] = term_plane( w[m*w_sm + (16cc + 8h + j)*w_sc + tap'] ), zero for m >= M
+__global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                               int flip, int mpad, int nch, int nsplit) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  if (i >= per_plane) return;
+  const int m = (int)(i % mpad);
+  long r = i / mpad;
+  const int tap = (int)(r % KK); r /= KK;
+  const int h = (int)(r & 1);
+  const int cc = (int)(r >> 1);
+  const int st = flip ? KK - 1 - tap : tap;
+  bf16x8 t0, t1, t2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 16 * cc + 8 * h + j;
+    const float v = (m < M && c < Cin) ? w[(long)m * w_sm + (long)c * w_sc + st] : 0.f;
+    if (nsplit == 1) { t0[j] = (__bf16)v; }
+    else { __bf16 a, b, d; split3(v, a, b, d); t0[j] = a; t1[j] = b; t2[j] = d; }
+  }
+  wp[i] = __builtin_bit_cast(u32x4, t0);
+  if (nsplit == 3) {
+    wp[per_plane + i] = __builtin_bit_cast(u32x4, t1);
+    wp[2 * per_plane + i] = __builtin_bit_cast(u32x4, t2);
+  }
+}
+
+// LDS pixel pitches that make every ds_read_b128 lane group of the B fragments hit 16 distinct 16-byte slots
+// (enumerated offline over the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} of every 32-pixel sub-tile).
+// The three-plane (split) mode trades the padding for LDS space — natural pitches, 2-way conflicts on the B reads of the
+// 16- and 8-wide tiles — so that two workgroups fit a CU (<= 80 KB each) and their waves cover each other's stalls.
+template <int TW, int KS, int NSPL> struct Pitch;
+template <int KS, int NSPL> struct Pitch<32, KS, NSPL> { static constexpr int PWP = 32 + KS - 1; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch<16, KS, 1> { static constexpr int PWP = 32; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch<16, KS, 3> { static constexpr int PWP = 16 + KS - 1; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch<8, KS, 1> { static constexpr int PWP = 24; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch<8, KS, 3> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
+template <int NSPL> struct Pitch<4, 3, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
+
+constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element: past every tensor (< 2 GB), and adding the
+                                          // (< 2 GB) scalar chunk offset cannot wrap back into range
+
+// TG: taps per weight stage (KS*KS: the whole window; KS: one kernel row at a time — keeps the 5x5 weight slice in LDS small)
+// Output tile: BM channels x (TI*TH*TW = 128 or 256) pixels; 2x2 waves, each BM/2 x BN/2.
+template <int KS, int TW, int TH, int TI, int BM, int NSPL, int TG>
+__global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
+  constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = KK / TG;
+  static_assert((BN == 128 || BN == 256) && (TG == KK || TG == KS), "pconv geometry");
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PWP = Pitch<TW, KS, NSPL>::PWP;
+  static_assert(PWP >= PW, "pitch");
+  constexpr int IMGP = PH * PWP + Pitch<TW, KS, NSPL>::IMG_EXTRA, NQ = TI * IMGP;
+  constexpr int P_PLANE = 2 * NQ;              // 16-byte pieces per plane: [h][q]
+  constexpr int A_PLANE = 2 * TG * BM;         //                           [h][t][row]
+  constexpr int NB = 2 * TI * PH * PW, BR = (NB + NT - 1) / NT;
+  constexpr int NA = NSPL * A_PLANE, AR = (NA + NT - 1) / NT;
+  constexpr int WTM = BM / 64, WTN = BN / 64;
+  constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
+  constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
+  static_assert((NSPL * (P_PLANE + A_PLANE)) * 4 >= 4 * 32 * EP_PITCH, "epilogue scratch must fit in the staging buffers");
+  __shared__ u32x4 lds[NSPL * (P_PLANE + A_PLANE)];
+  u32x4* const Pl = lds;
+  u32x4* const Al = lds + NSPL * P_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Hl = p.H << p.up, Wl = p.W << p.up;
+  int img0, ty0, tx0;
+  if constexpr (TI == 1) {
+    const int tpr = p.OW / TW, tpi = (p.OH / TH) * tpr;
+    img0 = blockIdx.x / tpi;
+    const int t = blockIdx.x - img0 * tpi;
+    ty0 = (t / tpr) * TH; tx0 = (t % tpr) * TW;
+  } else {
+    img0 = blockIdx.x * TI; ty0 = 0; tx0 = 0;
+  }
+  const int bm0 = blockIdx.y * BM;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+  // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
+  // the stage term is wave-uniform and travels in the scalar offset of the loads: no per-load vector arithmetic)
+  unsigned bsrc[BR];   // patch item e = (half h, image ti, row yy, column xx): byte offset of channel 8h, or OOB31
+  int bdst[BR];        // LDS piece index h*NQ + q, or -1
+#pragma unroll
+  for (int r = 0; r < BR; ++r) {
+    const int e = tid + NT * r;
+    const int h = e / (TI * PH * PW), rem = e - h * (TI * PH * PW);
+    const int ti = rem / (PH * PW), r2 = rem - ti * (PH * PW), yy = r2 / PW, xx = r2 - yy * PW;
+    const int img = img0 + ti, ly = ty0 - p.pad + yy, lx = tx0 - p.pad + xx;
+    const bool in = e < NB;
+    const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+    bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
+    bdst[r] = in ? h * NQ + ti * IMGP + yy * PWP + xx : -1;
+  }
+  const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
+  unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int e = min(tid + NT * r, NA - 1);
+    const int plane = e / A_PLANE, r1 = e - plane * A_PLANE;
+    const int h = r1 / (TG * BM), r2 = r1 - h * (TG * BM), t = r2 / BM, row = r2 - t * BM;
+    asrc[r] = (unsigned)((((plane * p.nch) * 2 + h) * KK + t) * p.mpad + bm0 + row);
+  }
+
+  float pb[BR][8];
+  u32x4 pa[AR];
+  auto gload_b = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pb[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, bsrc[r], (unsigned)(c0 + j) * cstride, 0));
+  };
+  auto gload_a = [&](int cc, int tg) {                     // cc is clamped by the caller (the last prefetch is never used)
+    const u32x4* base = p.wp + (long)(cc * 2 * KK + tg * TG) * p.mpad;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
+  };
+  auto sstore_b = [&]() {
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      if (bdst[r] < 0) continue;
+      bf16x8 t0, t1, t2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = p.in_relu ? fmaxf(pb[r][j], 0.f) : pb[r][j];
+        if constexpr (NSPL == 1) { t0[j] = (__bf16)v; }
+        else { __bf16 a, b, d; split3(v, a, b, d); t0[j] = a; t1[j] = b; t2[j] = d; }
+      }
+      Pl[bdst[r]] = __builtin_bit_cast(u32x4, t0);
+      if constexpr (NSPL == 3) {
+        Pl[P_PLANE + bdst[r]] = __builtin_bit_cast(u32x4, t1);
+        Pl[2 * P_PLANE + bdst[r]] = __builtin_bit_cast(u32x4, t2);
+      }
+    }
+  };
+  auto sstore_a = [&]() {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const int e = tid + NT * r;
+      if (NA % NT == 0 || e < NA) Al[e] = pa[r];
+    }
+  };
+
+  // ---- fragment addressing
+  int qlane[WTN];
+#pragma unroll
+  for (int jt = 0; jt < WTN; ++jt) {
+    const int j = wn * (BN / 2) + 32 * jt + l31;
+    const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
+    qlane[jt] = lh * NQ + ti * IMGP + py * PWP + px;
+  }
+  const int arow = lh * (TG * BM) + wm * (BM / 2) + l31;
+
+  f32x16 acc[NACC][WTM][WTN];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+
+  const int nstage = p.nch * NTG;      // stage s = (channel chunk s / NTG, tap group s % NTG)
+  gload_b(0);
+  gload_a(0, 0);
+  sstore_b();
+  sstore_a();
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const int cc = s / NTG, tg = s - cc * NTG;
+    const int s1 = min(s + 1, nstage - 1), cc1 = s1 / NTG, tg1 = s1 - cc1 * NTG;   // past the end: reload the last stage (unused)
+    const bool new_patch = (NTG == 1) || (s + 1) % NTG == 0;
+    if (new_patch) gload_b(16 * cc1);
+    gload_a(cc1, tg1);
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      int toff;
+      if constexpr (TG == KK) toff = (t / KS) * PWP + (t % KS);
+      else toff = tg * PWP + t;
+      bf16x8 fa[NSPL][WTM], fb[NSPL][WTN];
+#pragma unroll
+      for (int pl = 0; pl < NSPL; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[pl][i] = __builtin_bit_cast(bf16x8, Al[pl * A_PLANE + arow + t * BM + 32 * i]);
+#pragma unroll
+        for (int jt = 0; jt < WTN; ++jt) fb[pl][jt] = __builtin_bit_cast(bf16x8, Pl[pl * P_PLANE + qlane[jt] + toff]);
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int jt = 0; jt < WTN; ++jt) {
+          acc[0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][jt], acc[0][i][jt], 0, 0, 0);
+          if constexpr (NSPL == 3) {      // the small terms (<= 2^-8 of the leading one) accumulate apart: their rounding errors
+            f32x16& lo = acc[NACC - 1][i][jt];   // are 2^-8 smaller and the leading chain sees one rounding per K-step
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][jt], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][jt], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][jt], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][jt], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][jt], lo, 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+    if (new_patch) sstore_b();
+    sstore_a();
+    __syncthreads();
+  }
+  if constexpr (NSPL == 3) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][i][j][r] += acc[1][i][j][r];
+  }
+
+  // ---- epilogue.  D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel) — a lane holds 16
+  // channels of ONE pixel, so storing straight from the accumulators costs 16 four-byte store instructions per 32x32 tile.
+  // Each wave transposes its tiles through its own LDS scratch (the staging buffers are free after the loop's last barrier):
+  // afterwards a lane holds 4 consecutive pixels of one channel and every tile takes 4 sixteen-byte stores (and 16-byte
+  // loads for the optional mask / accumulate operands, issued together — no per-element load-then-wait chains).
+  float* const ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_PITCH);
+  const long OHW = (long)p.OH * p.OW;
+  const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8*pass, columns ec..ec+3
+#pragma unroll
+  for (int jt = 0; jt < WTN; ++jt) {
+    const int j = wn * (BN / 2) + 32 * jt + ec;
+    const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
+    const int img = img0 + ti;
+    const long pbase = (long)img * p.Cout * OHW + (long)(ty0 + py) * p.OW + tx0 + px;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) ep[((r2 & 3) + 8 * (r2 >> 2) + 4 * lh) * EP_PITCH + l31] = acc[0][i][jt][r2];
+      // (one wave writes and reads its own scratch: the LDS accesses of a wave are ordered, no barrier needed)
+      float4 v[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+      const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
+      float4 old[4], msk[4];
+      if (p.accumulate) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          old[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(p.y + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      if (p.pos_mask) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          msk[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(p.pos_mask + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int m = mb + 8 * ps;
+        if (m < p.Cout && img < p.N) {
+          float4 o = v[ps];
+          if (p.bias) { const float bb = p.bias[m]; o.x += bb; o.y += bb; o.z += bb; o.w += bb; }
+          if (p.pos_mask) {
+            if (!(msk[ps].x > 0.f)) o.x = 0.f;
+            if (!(msk[ps].y > 0.f)) o.y = 0.f;
+            if (!(msk[ps].z > 0.f)) o.z = 0.f;
+            if (!(msk[ps].w > 0.f)) o.w = 0.f;
+          }
+          if (p.accumulate) { o.x += old[ps].x; o.y += old[ps].y; o.z += old[ps].z; o.w += old[ps].w; }
+          if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          *reinterpret_cast<float4*>(p.y + pbase + (long)m * OHW) = o;
+        }
+      }
+    }
+  }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
+  if (!(ks == 3 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
+  return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
+}
+
+int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  if (a.stride != 1 || !(a.ks == 3 || a.ks == 5) || a.Cin % 16 != 0 || a.Cout < 48) return -1;
+  if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
+  int geo;
+  if (a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
+  else if (a.OW == 8 && a.OH == 8) geo = 1;
+  else if (a.OW == 4 && a.OH == 4 && a.ks == 3) geo = 2;
+  else return -1;
+  if ((a.H << a.up) + 2 * a.pad - a.ks + 1 != a.OH || (a.W << a.up) + 2 * a.pad - a.ks + 1 != a.OW) return -1;
+  const long need = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
+  if (!ws || ws_bytes < need) return -1;
+  if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
+  const int KK = a.ks * a.ks, nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
+  u32x4* wp = (u32x4*)ws;
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, KK, a.w_sm,
+                     a.w_sc, a.flip, mpad, nch, a.nsplit);
+  AGL_CHECK_LAUNCH(name);
+  PArgs p;
+  p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
+  p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
+  p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
+  // nsplit 1: 128 channels (64 when Cout <= 64) x 256 pixels per workgroup, 128 pixels when the wider tile would leave CUs
+  // without work; nsplit 3: 64 x 128 (three LDS planes)
+  const int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
+  const long px128 = geo == 0 ? (long)a.N * (a.OH / 8) * (a.OW / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  const bool w32 = a.OW % 32 == 0;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
+  bool wide = a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  if (geo == 0 && wide && !w32 && a.OH % 16 != 0) wide = false;
+  long ptiles;
+  if (geo == 0) ptiles = px128 / (wide ? 2 : 1);
+  else if (geo == 1) ptiles = agl_cdiv(a.N, wide ? 4 : 2);
+  else ptiles = agl_cdiv(a.N, wide ? 16 : 8);
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
+#define PC_LAUNCH(KS_, TW_, TH_, TI_, BM_, NS_, TG_) \
+  hipLaunchKernelGGL((pconv_k<KS_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
+#define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
+  do {                                                                                                   \
+    if (geo == 0 && !wide) PC_LAUNCH(KS_, 16, 8, 1, BM_, 1, TG_);                                        \
+    else if (geo == 0 && w32) PC_LAUNCH(KS_, 32, 8, 1, BM_, 1, TG_);                                     \
+    else if (geo == 0) PC_LAUNCH(KS_, 16, 16, 1, BM_, 1, TG_);                                           \
+    else if (geo == 1 && !wide) PC_LAUNCH(KS_, 8, 8, 2, BM_, 1, TG_);                                    \
+    else if (geo == 1) PC_LAUNCH(KS_, 8, 8, 4, BM_, 1, TG_);                                             \
+  } while (0)
+#define PC_SHAPES3(KS_, TG_)                                                                             \
+  do {                                                                                                   \
+    if (geo == 0 && w32) PC_LAUNCH(KS_, 32, 4, 1, 64, 3, TG_);                                           \
+    else if (geo == 0) PC_LAUNCH(KS_, 16, 8, 1, 64, 3, TG_);                                             \
+    else if (geo == 1) PC_LAUNCH(KS_, 8, 8, 2, 64, 3, TG_);                                              \
+  } while (0)
+  if (a.ks == 3) {
+    if (geo == 2) {
+      if (a.nsplit == 3) PC_LAUNCH(3, 4, 4, 8, 64, 3, 9);
+      else if (wide) { if (bm == 128) PC_LAUNCH(3, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 4, 4, 16, 64, 1, 9); }
+      else { if (bm == 128) PC_LAUNCH(3, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 4, 4, 8, 64, 1, 9); }
+    } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
+    else PC_SHAPES3(3, 9);
+  } else {
+    if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
+    else PC_SHAPES3(5, 5);
+  }
+#undef PC_SHAPES1
+#undef PC_SHAPES3
+#undef PC_LAUNCH
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}

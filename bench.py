@@ -47,7 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 128 px / bf16 secondary result")
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "f32x3", "bf16"],
                     help="MFMA arithmetic of the convolutions: exact fp32 (BASELINE config 2, default) or bf16 operands "
                          "with fp32 accumulation (configs 3/5); statistics, SN, losses and Adam are fp32 either way")
     ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
@@ -207,12 +207,13 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             for name, e0, e1, f, dims in conv:
                 k = (name.replace('agl_conv2d_', ''), dims)
                 agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
-            rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2] / 157.3e9))
+            by_ms = os.environ.get("AGL_DUMP_SORT") == "ms"
+            rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] if by_ms else kv[1][1] - kv[1][2] / 157.3e9))
             for (nm, dims), (cnt, ms, fl) in rows[:int(os.environ.get("AGL_DUMP_CONV_ROWS", "40"))]:
                 print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/157.3e9:6.2f} ms  dims {dims}', file=sys.stderr)
         c0, c1 = FLOPS_PER_IMAGE[res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic (reference graph), per GPU per step
-        peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         ex_tf = executed / (conv_ms * 1e-3) / 1e12
         # achieved / frac: FLOPs the timed launches actually execute (C-ABI agl_conv2d_*_flops: dense count minus the
         # padded taps the position-major path skips) / their measured duration.  The reference graph's FLOPs over the

@@ -37,12 +37,17 @@ const char* agl_last_error(void);
  *                        fp32 MFMA (config 2).  Statistics, SN, losses and Adam are fp32 either way.
  *   AGL_CONV_NO_PATCH    never use the LDS-patch kernel (A/B tests);  AGL_CONV_NO_PATCH_S2: not its stride-2 form
  *   AGL_CONV_NO_POS      never use the position-major path on <= 8x8 maps (A/B tests)
- *   AGL_CONV_POS_ALL_KS  experiments: position-major path also for 3x3 / 4x4 kernels                                  */
+ *   AGL_CONV_POS_ALL_KS  experiments: position-major path also for 3x3 / 4x4 kernels
+ *   AGL_CONV_SPLIT3      fp32 tensors, fp32-accurate products on the bf16 matrix cores: every operand is carried as three
+ *                        bf16 terms (a = a1+a2+a3 to 2^-27) and six of the nine partial products are accumulated in fp32
+ *                        (the dropped ones are <= 2^-27 |ab|); used by the LDS-patch kernel of csrc/pconv.hip where it
+ *                        applies (stride-1 3x3 / 5x5 on power-of-two maps), exact fp32 MFMA elsewhere               */
 #define AGL_CONV_BF16 1
 #define AGL_CONV_NO_PATCH 2
 #define AGL_CONV_NO_PATCH_S2 4
 #define AGL_CONV_NO_POS 8
 #define AGL_CONV_POS_ALL_KS 16
+#define AGL_CONV_SPLIT3 32
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);

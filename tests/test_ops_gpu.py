@@ -652,3 +652,67 @@ def test_modules_vs_reference_op_fixtures(golden_dir):
         if k in (3, 7):
             close(m.resi[3].weight_u, t(f"dres_u3_after{k}"), 2e-5, f"SN u after {k} forwards")
             close(m.resi[3].weight_v, t(f"dres_v3_after{k}"), 2e-5, f"SN v after {k} forwards")
+
+
+PCONV_CASES = [  # N, Cin, H, Cout, ks  (stride 1, "same" padding): the three tile geometries of csrc/pconv.hip, 3x3 and 5x5
+    (4, 64, 32, 128, 3), (3, 32, 16, 64, 3), (2, 48, 64, 80, 3), (5, 64, 8, 128, 3), (7, 32, 8, 200, 3), (9, 64, 4, 128, 3),
+    (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5)]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", PCONV_CASES)
+def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
+    """The LDS-patch kernel on the bf16 matrix cores (csrc/pconv.hip), forward and input-gradient forms with every fused
+    epilogue.  'bf16' (AGL_CONV_BF16): equal to an fp32 convolution of the bf16-rounded operands to fp32 accuracy (2e-5).
+    'split3' (AGL_CONV_SPLIT3): fp32 operands as three bf16 terms, six products — must meet the SAME tolerance as the exact
+    fp32 MFMA path against torch fp32 (2e-5 forward, 1e-4 input gradient), and against an fp64 convolution its error must not
+    exceed 2x the error of the exact fp32 MFMA kernel on the same problem (+2e-7): an fp32-accurate path, not a reduced-precision one."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks = case
+    p = ks // 2
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    if mode == "bf16":
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        flags, tol = L.CONV_BF16, 2e-5
+    else:
+        r = lambda t: t
+        flags, tol = L.CONV_SPLIT3, 2e-5
+    xr, wr = r(x), r(w)
+    y_ref = TF.conv2d(torch.relu(xr) if mode == "split3" else r(torch.relu(x)), wr, b, padding=p)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    with L.conv_flags(flags):
+        y = L.conv2d_fwd(xd, wd, bd, 1, p, in_relu=True)
+        close(y, y_ref, tol, "forward (input ReLU, bias)")
+        base = rn(*y_ref.shape, seed=5)
+        y2 = L.conv2d_fwd(xd, wd, None, 1, p, out=dev(base).clone(), accumulate=True)
+        close(y2, base + TF.conv2d(xr, wr, None, padding=p), tol, "accumulate")
+        y3 = L.conv2d_fwd(xd, wd, bd, 1, p, relu=True)
+        close(y3, torch.relu(TF.conv2d(xr, wr, b, padding=p)), tol, "output ReLU")
+        # input gradient = same kernel with flipped taps / swapped channel roles, masked by the consumer's ReLU
+        gy = rn(*y_ref.shape, seed=7)
+        gyr = r(gy)
+        xg = xr.clone().requires_grad_(True)
+        TF.conv2d(xg, wr, None, padding=p).backward(gyr)
+        mask = rn(N, Cin, H, H, seed=9)
+        dx = L.conv2d_bwd_data(dev(gy), wd, (H, H), 1, p, pos_mask=dev(mask))
+        close(dx, xg.grad * (mask > 0), 1e-4 if mode == "split3" else 5e-5, "input gradient with ReLU mask")
+    if mode == "split3":
+        # accuracy class: against an fp64 convolution the split path must be as accurate as the exact fp32 MFMA chain
+        # (v_mfma_f32_32x32x2_f32, flags 0) on the same problem — it is not a reduced-precision mode
+        y64 = TF.conv2d(torch.relu(x).double(), w.double(), b.double(), padding=p)
+        y_exact = L.conv2d_fwd(xd, wd, bd, 1, p, in_relu=True)
+        e_split = float((y.cpu().double() - y64).abs().max())
+        e_exact = float((y_exact.cpu().double() - y64).abs().max())
+        assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
+
+
+def test_pconv_upsampled_input():
+    """Nearest up-sampling folded into the patch staging (SPADE mlp_shared reads the 8x8 map up-sampled, normalization.py:100)."""
+    from agl import lib as L
+    x, w = rn(3, 64, 8, 8), rn(128, 64, 3, 3, seed=1) * 0.05
+    for flags, r in ((L.CONV_BF16, lambda t: t.to(torch.bfloat16).to(torch.float32)), (L.CONV_SPLIT3, lambda t: t)):
+        for up in (1, 2):
+            ref = TF.conv2d(TF.interpolate(r(x), scale_factor=2 ** up, mode="nearest"), r(w), None, padding=1)
+            with L.conv_flags(flags):
+                y = L.conv2d_fwd(dev(x), dev(w), None, 1, 1, up=up)
+            close(y, ref, 2e-5, f"up={up} flags={flags}")

@@ -14,6 +14,8 @@ if os.environ.get("AGL_POS_ALL"):
     L.CONV_FLAGS |= L.CONV_POS_ALL_KS
 if os.environ.get("AGL_NOPOS"):
     L.CONV_FLAGS |= L.CONV_NO_POS
+if os.environ.get("AGL_SPLIT3"):
+    L.CONV_FLAGS |= L.CONV_SPLIT3
 if os.environ.get("AGL_PREC"):
     L.set_conv_precision(os.environ["AGL_PREC"])
 O, N = 393, 64
@@ -51,6 +53,10 @@ SHAPES = [
     ("Dobj.3b 256>512 k3 @8", O, 256, 8, 512, 3, 1, 1),
     ("Dobj.4a 512>512 k3 @4", O, 512, 4, 512, 3, 1, 1),
     ("Dobj.4b 512>1024 k3 @4", O, 512, 4, 1024, 3, 1, 1),
+    ("128px SPADE5.gb 128>256 k3 @128", 32, 128, 128, 256, 3, 1, 1),
+    ("128px DEC.c6 128>128 k5 @128", 32, 128, 128, 128, 5, 1, 2),
+    ("128px Dobj.0b 64>64 k3 @64 (B=210)", 210, 64, 64, 64, 3, 1, 1),
+    ("128px Dobj.1b 64>128 k3 @64 (B=210)", 210, 64, 64, 128, 3, 1, 1),
 ]
 
 

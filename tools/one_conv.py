@@ -6,6 +6,8 @@ import torch
 from agl import lib as L
 B, Cin, H, Cout, ks, s, p = (int(v) for v in sys.argv[1:8])
 which = sys.argv[8] if len(sys.argv) > 8 else "fwd"
+if os.environ.get("AGL_PREC"): L.set_conv_precision(os.environ["AGL_PREC"])
+if os.environ.get("AGL_SPLIT3"): L.CONV_FLAGS |= L.CONV_SPLIT3
 x = torch.randn(B, Cin, H, H, device="cuda:0"); w = torch.randn(Cout, Cin, ks, ks, device="cuda:0") * 0.05
 y = L.conv2d_fwd(x, w, None, s, p); dy = torch.randn_like(y)
 for _ in range(5):
