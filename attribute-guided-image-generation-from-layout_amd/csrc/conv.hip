@@ -1661,7 +1661,16 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
   return Cout <= 4 && Cin >= 32 && stride == 1 && up == 0 && !in_relu;
 }
 
+static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
+  long need = bww_ws_core(N, Cin, Cout, ks, OH, OW);
+  PBwwArgs a;      // bf16 / split kernels: stride-1 "same" convolutions only, so the input extent follows from the output's
+  a.dy = nullptr; a.x = nullptr; a.dw = nullptr; a.N = N; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
+  a.stride = 1; a.pad = ks / 2; a.up = 0; a.H = OH; a.W = OW; a.in_relu = 0; a.accumulate = 0;
+  for (int ns = 1; ns <= 3; ns += 2) { a.nsplit = ns; need = std::max(need, pbww_ws_bytes(a)); }
+  return need;
+}
+static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW) {
   long pos_need = 0;
   if (OH <= 8 && OW <= 8 && ks == 5 && pos_ok(kDefaultOpts, N, 64, OH, OW, Cout, ks, 0) && Cin >= 64)   // stride-1 "same" 5x5 on a small map
     pos_need = pos_bww_plan(N, Cin, OH, OW, Cout, OH, OW, ks, 1, ks / 2).total();
@@ -1676,7 +1685,7 @@ long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, in
     for (int pad = 0; pad < ks; ++pad) {
       const int H = OH + ks - 1 - 2 * pad, W = OW + ks - 1 - 2 * pad;
       if (H <= 0 || W <= 0) break;
-      const long need = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
+      const long need = bww_ws_core(N, Cout, Cin, ks, H, W);
       if (need > inner) inner = need;
     }
     long Nc0 = (long)Cin * ks * ks, R0 = (long)N * OH * OW;
@@ -1699,6 +1708,13 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (co.patch && (co.prec == 1 || co.split3)) {
+    PBwwArgs a;
+    a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
+    a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = co.prec == 1 ? 1 : 3;
+    const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww)");
+    if (prc >= 0) return prc;
+  }
   if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
       pos_ok(co, N, 64, H, W, Cout, ks, 0)) {
     const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, 1, pad);
@@ -1706,7 +1722,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
       return pos_conv_bww(dy, x, dw, ws, N, Cin, H, W, Cout, OH, OW, ks, 1, pad, accumulate, (hipStream_t)stream, co.prec);
   }
   if (bww_swapped(Cin, Cout, stride, up_log2, in_relu)) {
-    const long inner = agl_conv2d_bwd_weight_ws_bytes(N, Cout, Cin, ks, H, W);
+    const long inner = bww_ws_core(N, Cout, Cin, ks, H, W);
     const long tmp_bytes = (long)Cin * Cout * ks * ks * 4;
     if (!ws || ws_bytes < inner + tmp_bytes) {
       agl_set_error("agl_conv2d_bwd_weight: workspace too small (%ld < %ld)", ws_bytes, inner + tmp_bytes);

@@ -14,3 +14,11 @@ struct PConvArgs {
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
 // Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
+
+struct PBwwArgs {
+  const float* dy; const float* x; float* dw;
+  int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up)
+  int ks, stride, pad, up, in_relu, accumulate, nsplit;
+};
+long pbww_ws_bytes(const PBwwArgs& a);
+int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);

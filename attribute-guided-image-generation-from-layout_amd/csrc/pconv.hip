@@ -325,6 +325,212 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+
+// =====================================================================================================================
+// Weight gradient on the bf16 matrix cores:  dw[co][c][kh][kw] = sum over (image, oy, ox) of dy[co][pix] * x[c][pix*S + tap].
+// GEMM view: rows = output channels, columns = (input channel, tap), reduction = pixels.  v_mfma_f32_16x16x32_bf16 takes 32
+// pixels per step; lane l holds A[row l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col l&15].
+//   * A (dy): the tile's rows are staged pixel-contiguous, [plane][co][pixel] bf16 with a 288-byte row pitch (conflict-free
+//     ds_read_b128 of 8 consecutive pixels per lane);
+//   * B (x):  the patch is staged ONCE per tile, pixel-major / channel-fastest [plane][q][BC channels].  A lane needs 8 pixels
+//     of ONE channel — a column of that image — which ds_read_b64_tr_b16 delivers: per 16-lane group it reads a 4-pixel x
+//     16-channel block (each lane supplies the address of one 8-byte row quarter, so the tap shift and the convolution
+//     stride are just address arithmetic, with no alignment constraint) and hands lane i column i.
+// A workgroup owns 64*RT output channels x 16*CT input channels x all taps (accumulators in registers), walks its share of
+// the 128-pixel tiles, and writes one slab; slab_sum_k adds the slabs in fixed order (deterministic).
+struct WArgs {
+  const float* dy; const float* x; float* slabs;
+  int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
+  int tiles, tiles_per_split;
+  unsigned x_bytes, dy_bytes;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL>
+__global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
+  constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
+  static_assert(NPX == 128 && TW >= 8, "pbww geometry");
+  constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, IMGP = PH * PW, NQ = TI * IMGP;
+  constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 sixteen-byte slots -> conflict-free b128 reads
+  constexpr int XROW = 2 * BC;                          // bytes per patch pixel
+  constexpr int D_PLANE = BMCO * DPITCH, X_PLANE = NQ * XROW;
+  constexpr int NACC = NSPL == 3 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSPL * (D_PLANE + X_PLANE)];
+  unsigned char* const Dl = lds;
+  unsigned char* const Xl = lds + NSPL * D_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int c0 = blockIdx.y * BC, co0 = blockIdx.z * BMCO;
+  const int t_beg = blockIdx.x * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
+  const int Hl = p.H << p.up, Wl = p.W << p.up;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
+  const int tpr = p.OW / TW, tpi = TI == 1 ? (p.OH / TH) * tpr : 1;
+
+  f32x4 acc[NACC][RT][CT][KK];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[a][i][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane patch positions of the tr reads: K-step ks, read rd (rows 4*rd .. 4*rd+3 of the group's 8 pixels)
+  int xq[KSTEPS][2];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int j = 32 * ks + 8 * lg + 4 * rd + (l15 >> 2);
+      const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
+      xq[ks][rd] = (ti * IMGP + S * (py * PW + px)) * XROW + (l15 & 3) * 8;
+    }
+  const int arow = (wave * 16 * RT + l15) * DPITCH + lg * 16;
+
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    int img0, ty0, tx0;
+    if constexpr (TI == 1) {
+      img0 = tile / tpi;
+      const int t = tile - img0 * tpi;
+      ty0 = (t / tpr) * TH; tx0 = (t % tpr) * TW;
+    } else {
+      img0 = tile * TI; ty0 = 0; tx0 = 0;
+    }
+    __syncthreads();                                   // everyone is done reading the previous tile
+    // ---- dy tile: item = (output channel, 8 consecutive pixels)
+    constexpr int ND = BMCO * (NPX / 8);
+#pragma unroll
+    for (int r = 0; r < (ND + NT - 1) / NT; ++r) {
+      const int e = tid + NT * r;
+      if (ND % NT != 0 && e >= ND) break;
+      const int co = e / (NPX / 8), oc = e - co * (NPX / 8);
+      const int j = 8 * oc, ti = j / (TH * TW), rr = j - ti * (TH * TW), py = rr / TW, px = rr - py * TW;
+      const int img = img0 + ti;
+      const bool ok = co0 + co < p.Cout && img < p.N;
+      // (16-byte buffer loads are not usable here: this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to ONE dword
+      //  load; plain 16-byte global loads from a clamped, always-valid address + a select instead)
+      const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px) : 0;
+      const float4 lo = *reinterpret_cast<const float4*>(p.dy + idx);
+      const float4 hi = *reinterpret_cast<const float4*>(p.dy + idx + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (!ok) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+      }
+      bf16x8 t0, t1, t2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if constexpr (NSPL == 1) { t0[q] = (__bf16)v[q]; }
+        else { __bf16 a, b, d; split3(v[q], a, b, d); t0[q] = a; t1[q] = b; t2[q] = d; }
+      }
+      unsigned char* dst = Dl + co * DPITCH + oc * 16;
+      *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, t0);
+      if constexpr (NSPL == 3) {
+        *reinterpret_cast<u32x4*>(dst + D_PLANE) = __builtin_bit_cast(u32x4, t1);
+        *reinterpret_cast<u32x4*>(dst + 2 * D_PLANE) = __builtin_bit_cast(u32x4, t2);
+      }
+    }
+    // ---- x patch: item = (channel octet, patch pixel)
+    constexpr int NXI = NQ * (BC / 8);
+#pragma unroll
+    for (int r = 0; r < (NXI + NT - 1) / NT; ++r) {
+      const int e = tid + NT * r;
+      if (NXI % NT != 0 && e >= NXI) break;
+      const int oc = e / NQ, q = e - oc * NQ;
+      const int ti = q / IMGP, r2 = q - ti * IMGP, yy = r2 / PW, xx = r2 - yy * PW;
+      const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
+      const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+      const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
+      bf16x8 t0, t1, t2;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, (unsigned)jj * cstride, 0));
+        if (p.in_relu) v = fmaxf(v, 0.f);
+        if constexpr (NSPL == 1) { t0[jj] = (__bf16)v; }
+        else { __bf16 a, b, d; split3(v, a, b, d); t0[jj] = a; t1[jj] = b; t2[jj] = d; }
+      }
+      unsigned char* dst = Xl + q * XROW + oc * 16;
+      *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, t0);
+      if constexpr (NSPL == 3) {
+        *reinterpret_cast<u32x4*>(dst + X_PLANE) = __builtin_bit_cast(u32x4, t1);
+        *reinterpret_cast<u32x4*>(dst + 2 * X_PLANE) = __builtin_bit_cast(u32x4, t2);
+      }
+    }
+    __syncthreads();
+    // ---- 32 pixels per step
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      bf16x8 fa[NSPL][RT];
+#pragma unroll
+      for (int pl = 0; pl < NSPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+          fa[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Dl + pl * D_PLANE + arow + i * 16 * DPITCH + ks * 64));
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int toff = ((t / KS) * PW + (t % KS)) * XROW;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          bf16x8 fb[NSPL];
+#pragma unroll
+          for (int pl = 0; pl < NSPL; ++pl) {
+            typedef s16x4 __attribute__((address_space(3))) * lptr;
+            const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(Xl + pl * X_PLANE + xq[ks][0] + toff + j * 32));
+            const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(Xl + pl * X_PLANE + xq[ks][1] + toff + j * 32));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 both = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+            fb[pl] = __builtin_bit_cast(bf16x8, both);
+          }
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            acc[0][i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0], acc[0][i][j][t], 0, 0, 0);
+            if constexpr (NSPL == 3) {
+              f32x4& lo = acc[NACC - 1][i][j][t];
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0], lo, 0, 0, 0);
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2], lo, 0, 0, 0);
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1], lo, 0, 0, 0);
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0], lo, 0, 0, 0);
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1], lo, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- slab: C tile col = lane&15 (input channel), row = 4*(lane>>4) + reg (output channel)
+  float* out = p.slabs + (long)blockIdx.x * p.Cout * p.Cin * KK;
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wave * 16 * RT + 16 * i + 4 * lg + r, c = c0 + 16 * j + l15;
+        if (co < p.Cout) {
+          float* o = out + ((long)co * p.Cin + c) * KK;
+#pragma unroll
+          for (int t = 0; t < KK; ++t) {
+            float v = acc[0][i][j][t][r];
+            if constexpr (NSPL == 3) v += acc[1][i][j][t][r];
+            o[t] = v;
+          }
+        }
+      }
+}
+
+__global__ void slab_sum_k(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
 }  // namespace
 
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
@@ -397,6 +603,63 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_SHAPES1
 #undef PC_SHAPES3
 #undef PC_LAUNCH
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------
+static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, int* rt, int* ct) {
+  if (a.stride != 1 || !(a.ks == 3 || a.ks == 5) || a.Cin % 16 != 0 || a.Cout < 32) return -1;
+  if (!(a.nsplit == 1 || a.nsplit == 3) || (a.nsplit == 3 && a.ks == 5)) return -1;
+  if ((a.H << a.up) + 2 * a.pad - a.ks + 1 != a.OH || (a.W << a.up) + 2 * a.pad - a.ks + 1 != a.OW) return -1;
+  long tiles;
+  if (a.OW % 16 == 0 && a.OH % 8 == 0) tiles = (long)a.N * (a.OH / 8) * (a.OW / 16);
+  else if (a.OW == 8 && a.OH == 8) tiles = agl_cdiv(a.N, 2);
+  else return -1;
+  if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
+  // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
+  *rt = (a.nsplit == 1 && a.ks == 3 && a.Cout > 64) ? 2 : 1;
+  *ct = (a.nsplit == 1 && a.ks == 3 && a.Cin % 32 == 0) ? 2 : 1;
+  const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct));
+  long z = (768 + blocks - 1) / blocks;       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
+  if (z > tiles) z = tiles;
+  if (z < 1) z = 1;
+  const long per = (tiles + z - 1) / z;
+  z = (tiles + per - 1) / per;
+  *splits = (int)z; *tps = (int)per; *tiles_out = tiles;
+  return 0;
+}
+
+long pbww_ws_bytes(const PBwwArgs& a) {
+  int s, t, rt, ct; long tiles;
+  if (pbww_plan(a, &s, &t, &tiles, &rt, &ct) != 0) return 0;
+  return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4;
+}
+
+int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  int splits, tps, rt, ct; long tiles;
+  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct) != 0) return -1;
+  const long n = (long)a.Cout * a.Cin * a.ks * a.ks;
+  if (!ws || ws_bytes < (long)splits * n * 4) return -1;
+  WArgs p;
+  p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
+  p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
+  dim3 g((unsigned)splits, a.Cin / (16 * ct), agl_cdiv(a.Cout, 64 * rt));
+  const bool g8 = a.OW == 8 && a.OH == 8;
+#define PW_LAUNCH(KS_, RT_, CT_, NS_)                                                                               \
+  do {                                                                                                              \
+    if (g8) hipLaunchKernelGGL((pbww_k<KS_, 1, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                   \
+    else hipLaunchKernelGGL((pbww_k<KS_, 1, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                     \
+  } while (0)
+  if (a.ks == 3 && a.nsplit == 1) {
+    if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 1, 1);
+    else if (ct == 2) PW_LAUNCH(3, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1);
+  } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 3);
+  else PW_LAUNCH(5, 1, 1, 1);
+#undef PW_LAUNCH
+  AGL_CHECK_LAUNCH(name);
+  hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.dw, n, splits, a.accumulate);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }

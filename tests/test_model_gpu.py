@@ -130,13 +130,13 @@ def test_discriminator_vs_oracle(which):
                 close(v, P[k], 1e-4, k)
 
 
-def _run_step_fixture(tag, res128, n_steps, golden_dir):
+def _run_step_fixture(tag, res128, n_steps, golden_dir, conv_dtype="f32"):
     from agl.trainer import Trainer, batch_to_device
     g = np.load(os.path.join(golden_dir, f"step{tag}.npz"), allow_pickle=False)
     G, Di, Do, Da = build_nets(res128)
     for net, key in ((G, "G"), (Di, "D_img"), (Do, "D_obj"), (Da, "D_att")):   # state_dict layout == reference's
         assert list(net.state_dict().keys()) == [str(s) for s in g[f"s0_statenames_{key}"]], key
-    tr = Trainer(G, Di, Do, Da, torch.from_numpy(g["pos_weight"]))
+    tr = Trainer(G, Di, Do, Da, torch.from_numpy(g["pos_weight"]), conv_dtype=conv_dtype)
     batch = {k[len("batch_"):]: g[k] for k in g.files if k.startswith("batch_")}
     b = batch_to_device(batch, DEV)
     nets = {"G": G, "D_img": Di, "D_obj": Do, "D_att": Da}
@@ -210,6 +210,16 @@ def _run_step_fixture(tag, res128, n_steps, golden_dir):
 
 def test_full_step_64_vs_reference_fixture(golden_dir):
     _run_step_fixture("64", False, 2, golden_dir)
+
+
+def test_full_step_64_split_products_vs_reference_fixture(golden_dir):
+    """The same fixture, same (fp32) tolerances, with conv_dtype="f32x3": fp32 tensors whose products are formed on the bf16
+    matrix cores from three bf16 terms per operand (AGL_CONV_SPLIT3, csrc/pconv.hip) wherever that kernel applies."""
+    _run_step_fixture("64", False, 1, golden_dir, conv_dtype="f32x3")
+
+
+def test_full_step_128_split_products_vs_reference_fixture(golden_dir):
+    _run_step_fixture("128", True, 1, golden_dir, conv_dtype="f32x3")
 
 
 def test_full_step_128_vs_reference_fixture(golden_dir):

@@ -696,6 +696,16 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
         mask = rn(N, Cin, H, H, seed=9)
         dx = L.conv2d_bwd_data(dev(gy), wd, (H, H), 1, p, pos_mask=dev(mask))
         close(dx, xg.grad * (mask > 0), 1e-4 if mode == "split3" else 5e-5, "input gradient with ReLU mask")
+        # weight gradient (16x16x32 MFMA, transposed LDS reads; csrc/pconv.hip pbww_k), plain / with input ReLU / accumulating
+        wg = wr.clone().requires_grad_(True)
+        TF.conv2d(xr, wg, None, padding=p).backward(gyr)
+        dw = L.conv2d_bwd_weight(dev(gy), xd, ks, 1, p)
+        close(dw, wg.grad, 1e-4, "weight gradient")
+        wg2 = wr.clone().requires_grad_(True)
+        TF.conv2d(torch.relu(xr) if mode == "split3" else r(torch.relu(x)), wg2, None, padding=p).backward(gyr)
+        base_w = rn(Cout, Cin, ks, ks, seed=11)
+        dw2 = L.conv2d_bwd_weight(dev(gy), xd, ks, 1, p, in_relu=True, out=dev(base_w).clone(), accumulate=True)
+        close(dw2, base_w + wg2.grad, 1e-4, "weight gradient (input ReLU, accumulate)")
     if mode == "split3":
         # accuracy class: against an fp64 convolution the split path must be as accurate as the exact fp32 MFMA chain
         # (v_mfma_f32_32x32x2_f32, flags 0) on the same problem — it is not a reduced-precision mode
