@@ -1389,7 +1389,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
     const long pn = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad).total();
     if (pn > need) need = pn;
   }
-  if (stride == 1) need = std::max(need, pconv_ws_bytes(Cin, Cout, ks, 3));
+  need = std::max(need, pconv_ws_bytes(Cin, Cout, ks, 3));
   return need;
 }
 
@@ -1664,10 +1664,16 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
 static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
   long need = bww_ws_core(N, Cin, Cout, ks, OH, OW);
-  PBwwArgs a;      // bf16 / split kernels: stride-1 "same" convolutions only, so the input extent follows from the output's
+  PBwwArgs a;      // bf16 / split kernels: the input extent is not an argument here, so cover the convolution forms the path has
   a.dy = nullptr; a.x = nullptr; a.dw = nullptr; a.N = N; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
-  a.stride = 1; a.pad = ks / 2; a.up = 0; a.H = OH; a.W = OW; a.in_relu = 0; a.accumulate = 0;
-  for (int ns = 1; ns <= 3; ns += 2) { a.nsplit = ns; need = std::max(need, pbww_ws_bytes(a)); }
+  a.up = 0; a.in_relu = 0; a.accumulate = 0;
+  for (int form = 0; form < 2; ++form) {       // stride 1 "same"; stride 2 (4x4 pad 1: H = 2*OH; 3x3 pad 0: H = 2*OH + 1)
+    if (form == 0) { a.stride = 1; a.pad = ks / 2; a.H = OH; a.W = OW; }
+    else if (ks == 4) { a.stride = 2; a.pad = 1; a.H = 2 * OH; a.W = 2 * OW; }
+    else if (ks == 3) { a.stride = 2; a.pad = 0; a.H = 2 * OH + 1; a.W = 2 * OW + 1; }
+    else continue;
+    for (int ns = 1; ns <= 3; ns += 2) { a.nsplit = ns; need = std::max(need, pbww_ws_bytes(a)); }
+  }
   return need;
 }
 static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW) {

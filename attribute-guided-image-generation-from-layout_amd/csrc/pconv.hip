@@ -86,23 +86,38 @@ template <int KS> struct Pitch<8, KS, 1> { static constexpr int PWP = 24; static
 template <int KS> struct Pitch<8, KS, 3> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
 template <int NSPL> struct Pitch<4, 3, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
 
+// Stride 2: the patch is split by column parity ([half][parity][row][column/2]) so that a lane group again reads 16 distinct slots;
+// PWH = pitch of a parity plane row.
+template <int TW, int KS> struct Pitch2;
+template <int KS> struct Pitch2<32, KS> { static constexpr int PWP = 33; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch2<16, KS> { static constexpr int PWP = 24; static constexpr int IMG_EXTRA = 0; };
+template <int KS> struct Pitch2<8, KS> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
+template <> struct Pitch2<4, 4> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 4; };
+template <> struct Pitch2<4, 3> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 10; };
+template <int S, int TW, int KS, int NSPL> struct PitchSel { using type = Pitch<TW, KS, NSPL>; };
+template <int TW, int KS, int NSPL> struct PitchSel<2, TW, KS, NSPL> { using type = Pitch2<TW, KS>; };
+
 constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element: past every tensor (< 2 GB), and adding the
                                           // (< 2 GB) scalar chunk offset cannot wrap back into range
 
 // TG: taps per weight stage (KS*KS: the whole window; KS: one kernel row at a time — keeps the 5x5 weight slice in LDS small)
 // Output tile: BM channels x (TI*TH*TW = 128 or 256) pixels; 2x2 waves, each BM/2 x BN/2.
-template <int KS, int TW, int TH, int TI, int BM, int NSPL, int TG>
+template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG>
 __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = KK / TG;
-  static_assert((BN == 128 || BN == 256) && (TG == KK || TG == KS), "pconv geometry");
-  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PWP = Pitch<TW, KS, NSPL>::PWP;
-  static_assert(PWP >= PW, "pitch");
-  constexpr int IMGP = PH * PWP + Pitch<TW, KS, NSPL>::IMG_EXTRA, NQ = TI * IMGP;
+  static_assert((BN == 64 || BN == 128 || BN == 256) && (TG == KK || TG == KS) && (S == 1 || S == 2), "pconv geometry");
+  constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;
+  using PitchT = typename PitchSel<S, TW, KS, NSPL>::type;
+  constexpr int PWP = PitchT::PWP;             // row pitch (of a parity plane when S == 2)
+  static_assert(S * PWP >= PW, "pitch");
+  constexpr int IMGP = PH * PWP + PitchT::IMG_EXTRA;
+  constexpr int PAR = TI * IMGP;               // pieces per parity plane
+  constexpr int NQ = S * PAR;
   constexpr int P_PLANE = 2 * NQ;              // 16-byte pieces per plane: [h][q]
   constexpr int A_PLANE = 2 * TG * BM;         //                           [h][t][row]
   constexpr int NB = 2 * TI * PH * PW, BR = (NB + NT - 1) / NT;
   constexpr int NA = NSPL * A_PLANE, AR = (NA + NT - 1) / NT;
-  constexpr int WTM = BM / 64, WTN = BN / 64;
+  constexpr int WTM = BM / 64, WTN = BN / 64;   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/2 pixels)
   constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
   constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
   static_assert((NSPL * (P_PLANE + A_PLANE)) * 4 >= 4 * 32 * EP_PITCH, "epilogue scratch must fit in the staging buffers");
@@ -134,11 +149,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const int e = tid + NT * r;
     const int h = e / (TI * PH * PW), rem = e - h * (TI * PH * PW);
     const int ti = rem / (PH * PW), r2 = rem - ti * (PH * PW), yy = r2 / PW, xx = r2 - yy * PW;
-    const int img = img0 + ti, ly = ty0 - p.pad + yy, lx = tx0 - p.pad + xx;
+    const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
     const bool in = e < NB;
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
     bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
-    bdst[r] = in ? h * NQ + ti * IMGP + yy * PWP + xx : -1;
+    bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
   }
   const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
   unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   for (int jt = 0; jt < WTN; ++jt) {
     const int j = wn * (BN / 2) + 32 * jt + l31;
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
-    qlane[jt] = lh * NQ + ti * IMGP + py * PWP + px;
+    qlane[jt] = lh * NQ + ti * IMGP + S * py * PWP + px;
   }
   const int arow = lh * (TG * BM) + wm * (BM / 2) + l31;
 
@@ -224,9 +239,9 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     gload_a(cc1, tg1);
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-      int toff;
-      if constexpr (TG == KK) toff = (t / KS) * PWP + (t % KS);
-      else toff = tg * PWP + t;
+      int toff;                                  // LDS piece offset of tap (kh, kw)
+      if constexpr (TG == KK) toff = (t / KS) * PWP + (S == 2 ? ((t % KS) & 1) * PAR + ((t % KS) >> 1) : (t % KS));
+      else toff = tg * PWP + (S == 2 ? (t & 1) * PAR + (t >> 1) : t);
       bf16x8 fa[NSPL][WTM], fb[NSPL][WTN];
 #pragma unroll
       for (int pl = 0; pl < NSPL; ++pl) {
@@ -351,9 +366,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL>
 __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
-  static_assert(NPX == 128 && TW >= 8, "pbww geometry");
+  static_assert((NPX == 128 || NPX == 64) && TW >= 8, "pbww geometry");
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, IMGP = PH * PW, NQ = TI * IMGP;
-  constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 sixteen-byte slots -> conflict-free b128 reads
+  constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
   constexpr int XROW = 2 * BC;                          // bytes per patch pixel
   constexpr int D_PLANE = BMCO * DPITCH, X_PLANE = NQ * XROW;
   constexpr int NACC = NSPL == 3 ? 2 : 1;
@@ -534,19 +549,21 @@ __global__ void slab_sum_k(const float* __restrict__ slabs, float* __restrict__ 
 }  // namespace
 
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
-  if (!(ks == 3 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
+  if (!(ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
   return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
 }
 
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
-  if (a.stride != 1 || !(a.ks == 3 || a.ks == 5) || a.Cin % 16 != 0 || a.Cout < 48) return -1;
+  const bool s2 = a.stride == 2;
+  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
+  if (a.Cin % 16 != 0 || a.Cout < 48) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
   int geo;
   if (a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
   else if (a.OW == 8 && a.OH == 8) geo = 1;
-  else if (a.OW == 4 && a.OH == 4 && a.ks == 3) geo = 2;
+  else if (a.OW == 4 && a.OH == 4 && (a.ks == 3 || a.ks == 4)) geo = 2;
   else return -1;
-  if ((a.H << a.up) + 2 * a.pad - a.ks + 1 != a.OH || (a.W << a.up) + 2 * a.pad - a.ks + 1 != a.OW) return -1;
+  if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
   const long need = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
   if (!ws || ws_bytes < need) return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
@@ -562,44 +579,64 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   // nsplit 1: 128 channels (64 when Cout <= 64) x 256 pixels per workgroup, 128 pixels when the wider tile would leave CUs
-  // without work; nsplit 3: 64 x 128 (three LDS planes)
+  // without work; nsplit 3: 64 x 128 (three LDS planes).  Stride 2 (patch = 4x the tile): 128 pixels, 64 in split mode.
   const int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   const long px128 = geo == 0 ? (long)a.N * (a.OH / 8) * (a.OW / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
   const bool w32 = a.OW % 32 == 0;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
-  bool wide = a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  bool wide = !s2 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
   if (geo == 0 && wide && !w32 && a.OH % 16 != 0) wide = false;
+  const bool half = s2 && a.nsplit == 3;           // 64-pixel tiles
   long ptiles;
-  if (geo == 0) ptiles = px128 / (wide ? 2 : 1);
-  else if (geo == 1) ptiles = agl_cdiv(a.N, wide ? 4 : 2);
-  else ptiles = agl_cdiv(a.N, wide ? 16 : 8);
+  if (geo == 0) ptiles = half ? px128 * 2 : px128 / (wide ? 2 : 1);
+  else if (geo == 1) ptiles = half ? a.N : agl_cdiv(a.N, wide ? 4 : 2);
+  else ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
-#define PC_LAUNCH(KS_, TW_, TH_, TI_, BM_, NS_, TG_) \
-  hipLaunchKernelGGL((pconv_k<KS_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
+#define PC_LAUNCH(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
+  hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
 #define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
   do {                                                                                                   \
-    if (geo == 0 && !wide) PC_LAUNCH(KS_, 16, 8, 1, BM_, 1, TG_);                                        \
-    else if (geo == 0 && w32) PC_LAUNCH(KS_, 32, 8, 1, BM_, 1, TG_);                                     \
-    else if (geo == 0) PC_LAUNCH(KS_, 16, 16, 1, BM_, 1, TG_);                                           \
-    else if (geo == 1 && !wide) PC_LAUNCH(KS_, 8, 8, 2, BM_, 1, TG_);                                    \
-    else if (geo == 1) PC_LAUNCH(KS_, 8, 8, 4, BM_, 1, TG_);                                             \
+    if (geo == 0 && !wide) PC_LAUNCH(KS_, 1, 16, 8, 1, BM_, 1, TG_);                                     \
+    else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 8, 1, BM_, 1, TG_);                                  \
+    else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 16, 1, BM_, 1, TG_);                                        \
+    else if (geo == 1 && !wide) PC_LAUNCH(KS_, 1, 8, 8, 2, BM_, 1, TG_);                                 \
+    else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 4, BM_, 1, TG_);                                          \
   } while (0)
 #define PC_SHAPES3(KS_, TG_)                                                                             \
   do {                                                                                                   \
-    if (geo == 0 && w32) PC_LAUNCH(KS_, 32, 4, 1, 64, 3, TG_);                                           \
-    else if (geo == 0) PC_LAUNCH(KS_, 16, 8, 1, 64, 3, TG_);                                             \
-    else if (geo == 1) PC_LAUNCH(KS_, 8, 8, 2, 64, 3, TG_);                                              \
+    if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 4, 1, 64, 3, TG_);                                        \
+    else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 8, 1, 64, 3, TG_);                                          \
+    else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 2, 64, 3, TG_);                                           \
   } while (0)
-  if (a.ks == 3) {
+#define PC_STRIDE2(KS_, TG_)                                                                             \
+  do {                                                                                                   \
+    if (a.nsplit == 3) {                                                                                 \
+      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 4, 1, 64, 3, TG_);                                             \
+      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 1, 64, 3, TG_);                                         \
+      else PC_LAUNCH(KS_, 2, 4, 4, 4, 64, 3, TG_);                                                       \
+    } else if (bm == 128) {                                                                              \
+      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 128, 1, TG_);                                            \
+      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 128, 1, TG_);                                        \
+      else PC_LAUNCH(KS_, 2, 4, 4, 8, 128, 1, TG_);                                                      \
+    } else {                                                                                             \
+      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 64, 1, TG_);                                             \
+      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 64, 1, TG_);                                         \
+      else PC_LAUNCH(KS_, 2, 4, 4, 8, 64, 1, TG_);                                                       \
+    }                                                                                                    \
+  } while (0)
+  if (s2) {
+    if (a.ks == 4) PC_STRIDE2(4, 4); else PC_STRIDE2(3, 3);
+  } else if (a.ks == 3) {
     if (geo == 2) {
-      if (a.nsplit == 3) PC_LAUNCH(3, 4, 4, 8, 64, 3, 9);
-      else if (wide) { if (bm == 128) PC_LAUNCH(3, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 4, 4, 16, 64, 1, 9); }
-      else { if (bm == 128) PC_LAUNCH(3, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 4, 4, 8, 64, 1, 9); }
+      if (a.nsplit == 3) PC_LAUNCH(3, 1, 4, 4, 8, 64, 3, 9);
+      else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
+      else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
     } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
     else PC_SHAPES3(3, 9);
   } else {
     if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
     else PC_SHAPES3(5, 5);
   }
+#undef PC_STRIDE2
 #undef PC_SHAPES1
 #undef PC_SHAPES3
 #undef PC_LAUNCH
@@ -608,17 +645,20 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
-static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, int* rt, int* ct) {
-  if (a.stride != 1 || !(a.ks == 3 || a.ks == 5) || a.Cin % 16 != 0 || a.Cout < 32) return -1;
+static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, int* rt, int* ct, int* half_out) {
+  const bool s2 = a.stride == 2;
+  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
+  if (a.Cin % 16 != 0 || a.Cout < 32) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3) || (a.nsplit == 3 && a.ks == 5)) return -1;
-  if ((a.H << a.up) + 2 * a.pad - a.ks + 1 != a.OH || (a.W << a.up) + 2 * a.pad - a.ks + 1 != a.OW) return -1;
+  if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
+  const bool half = s2 && a.nsplit == 3;       // 64-pixel tiles: the stride-2 patch of a 128-pixel tile does not fit three planes
   long tiles;
-  if (a.OW % 16 == 0 && a.OH % 8 == 0) tiles = (long)a.N * (a.OH / 8) * (a.OW / 16);
-  else if (a.OW == 8 && a.OH == 8) tiles = agl_cdiv(a.N, 2);
+  if (a.OW % 16 == 0 && a.OH % 8 == 0) tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1);
+  else if (a.OW == 8 && a.OH == 8) tiles = half ? a.N : agl_cdiv(a.N, 2);
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
-  *rt = (a.nsplit == 1 && a.ks == 3 && a.Cout > 64) ? 2 : 1;
+  *rt = (a.nsplit == 1 && a.ks != 5 && a.Cout > 64) ? 2 : 1;
   *ct = (a.nsplit == 1 && a.ks == 3 && a.Cin % 32 == 0) ? 2 : 1;
   const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct));
   long z = (768 + blocks - 1) / blocks;       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
@@ -626,19 +666,19 @@ static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, 
   if (z < 1) z = 1;
   const long per = (tiles + z - 1) / z;
   z = (tiles + per - 1) / per;
-  *splits = (int)z; *tps = (int)per; *tiles_out = tiles;
+  *splits = (int)z; *tps = (int)per; *tiles_out = tiles; *half_out = half;
   return 0;
 }
 
 long pbww_ws_bytes(const PBwwArgs& a) {
-  int s, t, rt, ct; long tiles;
-  if (pbww_plan(a, &s, &t, &tiles, &rt, &ct) != 0) return 0;
+  int s, t, rt, ct, half; long tiles;
+  if (pbww_plan(a, &s, &t, &tiles, &rt, &ct, &half) != 0) return 0;
   return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4;
 }
 
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
-  int splits, tps, rt, ct; long tiles;
-  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct) != 0) return -1;
+  int splits, tps, rt, ct, half; long tiles;
+  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half) != 0) return -1;
   const long n = (long)a.Cout * a.Cin * a.ks * a.ks;
   if (!ws || ws_bytes < (long)splits * n * 4) return -1;
   WArgs p;
@@ -647,16 +687,22 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   dim3 g((unsigned)splits, a.Cin / (16 * ct), agl_cdiv(a.Cout, 64 * rt));
   const bool g8 = a.OW == 8 && a.OH == 8;
-#define PW_LAUNCH(KS_, RT_, CT_, NS_)                                                                               \
+#define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
-    if (g8) hipLaunchKernelGGL((pbww_k<KS_, 1, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                   \
-    else hipLaunchKernelGGL((pbww_k<KS_, 1, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                     \
+    if (g8 && half) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);          \
+    else if (g8) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);             \
+    else if (half) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);          \
+    else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                    \
   } while (0)
-  if (a.ks == 3 && a.nsplit == 1) {
-    if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 1, 1);
-    else if (ct == 2) PW_LAUNCH(3, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1);
-  } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 3);
-  else PW_LAUNCH(5, 1, 1, 1);
+  if (a.stride == 2) {
+    if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
+    else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 2, 1, 1);
+           else if (ct == 2) PW_LAUNCH(3, 2, 1, 2, 1); else PW_LAUNCH(3, 2, 1, 1, 1); }
+  } else if (a.ks == 3 && a.nsplit == 1) {
+    if (rt == 2 && ct == 2) PW_LAUNCH(3, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 1, 2, 1, 1);
+    else if (ct == 2) PW_LAUNCH(3, 1, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1, 1);
+  } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
+  else PW_LAUNCH(5, 1, 1, 1, 1);
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
   hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.dw, n, splits, a.accumulate);

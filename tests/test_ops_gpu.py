@@ -726,3 +726,25 @@ def test_pconv_upsampled_input():
             with L.conv_flags(flags):
                 y = L.conv2d_fwd(dev(x), dev(w), None, 1, 1, up=up)
             close(y, ref, 2e-5, f"up={up} flags={flags}")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(4, 64, 32, 128, 4, 1), (5, 32, 16, 64, 4, 1), (9, 16, 8, 96, 4, 1), (4, 64, 33, 128, 3, 0), (6, 32, 17, 64, 3, 0),
+                                  (10, 32, 9, 96, 3, 0), (2, 128, 64, 64, 4, 1), (3, 48, 66, 64, 4, 1)])
+def test_pconv_stride2_forward(case, mode):
+    """Stride-2 forward forms of the bf16-matrix-core patch kernel (4x4/pad 1: layout- and crop-encoder layers; 3x3/pad 0: the
+    box form of the down-sampling discriminator blocks): the patch is split by column parity in LDS.  Same tolerances as the
+    stride-1 cases, with bias / input ReLU / output ReLU."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, p = case
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    yr = TF.relu(TF.conv2d(r(TF.relu(x)), r(w), b, stride=2, padding=p))
+    with L.conv_flags(L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3):
+        y = L.conv2d_fwd(dev(x), dev(w), dev(b), 2, p, in_relu=True, relu=True)
+        gy = rn(*yr.shape, seed=7)
+        dw = L.conv2d_bwd_weight(dev(gy), dev(x), ks, 2, p)
+    close(y, yr, 2e-5, "stride-2 forward")
+    wg = r(w).clone().requires_grad_(True)
+    TF.conv2d(r(x), wg, None, stride=2, padding=p).backward(r(gy))
+    close(dw, wg.grad, 1e-4, "stride-2 weight gradient")
