@@ -1409,11 +1409,6 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64)   // (linear layers, HW = 1, stay on the GEMM)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
-  if (pos_ok(co, N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
-    const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
-    if (ws && ws_bytes >= pl.total())
-      return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st, co.prec);
-  }
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -1421,6 +1416,11 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
     if (prc >= 0) return prc;
+  }
+  if (pos_ok(co, N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
+    const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
+    if (ws && ws_bytes >= pl.total())
+      return pos_conv_fwd(x, w, bias, y, ws, N, Cin, H, W, Cout, ks, stride, pad, in_relu, relu, accumulate, st, co.prec);
   }
   if (co.patch) {
     PatchArgs a;
@@ -1507,12 +1507,6 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   if (Cin <= 4 && stride == 1 && IH * IW >= 64)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
-  if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0)) {
-    // "same" convolution: dx = forward convolution of dy with flipped taps, channel roles swapped, pad ks-1-pad
-    const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
-    if (ws && ws_bytes >= pl.total())
-      return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, co.prec, 2, pos_mask);
-  }
   if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a;    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
@@ -1520,6 +1514,12 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
     if (prc >= 0) return prc;
+  }
+  if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0)) {
+    // "same" convolution: dx = forward convolution of dy with flipped taps, channel roles swapped, pad ks-1-pad
+    const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
+    if (ws && ws_bytes >= pl.total())
+      return pos_conv_fwd(dy, w, nullptr, dx, ws, N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad, 0, 0, accumulate, st, co.prec, 2, pos_mask);
   }
   if (stride == 1 && co.patch && IH == OH && IW == OW) {   // "same" convolution: dx = conv(dy, flipped taps, roles swapped)
     PatchArgs a;
@@ -1786,21 +1786,24 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
   const int Hl = H << up_log2, Wl = W << up_log2;
   const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
   const bool small = Cout <= 4 && stride == 1 && up_log2 == 0 && OH * OW >= 64;
-  if (!small && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
+  const bool mc = co.patch && (co.prec == 1 || co.split3) && pconv_ws_bytes(Cin, Cout, ks, 1) > 0 && stride == 1 && OH == 8 && OW == 8;
+  if (!small && !mc && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, stride, pad);
   return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
 }
 double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
   const bool small = Cin <= 4 && stride == 1 && IH * IW >= 64;
-  if (!small && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))
+  const bool mc = co.patch && (co.prec == 1 || co.split3) && pconv_ws_bytes(Cout, Cin, ks, 1) > 0 && stride == 1 && IH == 8 && IW == 8;
+  if (!small && !mc && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(OH, OW, IH, IW, ks, 1, ks - 1 - pad);
   return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
 }
 double agl_conv2d_bwd_weight_flops(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad,
                                    int up_log2, int in_relu, int flags) {
   const ConvOpts co = conv_opts(flags);
-  if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
+  const bool mc = co.patch && co.prec == 1 && Cin % 16 == 0 && Cout >= 32;     // pbww takes 5x5 in bf16 mode only
+  if (!mc && stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
       pos_ok(co, N, 64, H, W, Cout, ks, 0))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, 1, pad);
   return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
