@@ -433,7 +433,10 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         x, xb, w3 = ctx.saved_tensors
         dy = _c(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0] and (BOX_BWD or xshape[2] >= BOX_BWD_MIN):
+        # bf16-matrix-core modes: the 4x4 / stride-2 form always (its four even phases run on csrc/pconv.hip; the 3x3 / stride-2
+        # phases of the box form are unequal and stay on the im2col kernel)
+        mc = bool(L.CONV_FLAGS & (L.CONV_BF16 | L.CONV_SPLIT3))
+        if ctx.needs_input_grad[0] and not mc and (BOX_BWD or xshape[2] >= BOX_BWD_MIN):
             dxb = L.conv2d_bwd_data(dy, w3, (xshape[2] + 1, xshape[3] + 1), 2, 0)
             dx = L.box2_bwd(dxb, x if x_relu else None)
         elif ctx.needs_input_grad[0]:

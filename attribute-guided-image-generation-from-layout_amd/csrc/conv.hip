@@ -1487,6 +1487,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
     if (pn > need) need = pn;
   }
   if (stride == 1) need = std::max(need, pconv_ws_bytes(Cout, Cin, ks, 3));
+  if (stride == 2 && ks == 4) need = std::max(need, pconvT_ws_bytes(Cout, Cin, 3));
   return need;
 }
 
@@ -1529,6 +1530,14 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1;
     a.x_bytes = (unsigned)((long)N * Cout * OH * OW * 4); a.w_bytes = (unsigned)((long)Cout * Cin * ks * ks * 4);
     const int prc = try_patch_conv(a, ks, ws, ws_bytes, st, "agl_conv2d_bwd_data(patch)", co);
+    if (prc >= 0) return prc;
+  }
+  if (stride == 2 && ks == 4 && co.patch && (co.prec == 1 || co.split3) && !bias) {
+    PConvArgs a{};
+    a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
+    a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
+    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3;
+    const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases)");
     if (prc >= 0) return prc;
   }
   const long out_numel = (long)N * Cin * IH * IW;
@@ -1786,7 +1795,13 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
   const int Hl = H << up_log2, Wl = W << up_log2;
   const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
   const bool small = Cout <= 4 && stride == 1 && up_log2 == 0 && OH * OW >= 64;
-  const bool mc = co.patch && (co.prec == 1 || co.split3) && pconv_ws_bytes(Cin, Cout, ks, 1) > 0 && stride == 1 && OH == 8 && OW == 8;
+  bool mc = false;
+  if (co.patch && (co.prec == 1 || co.split3)) {
+    PConvArgs a{};
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
+    a.nsplit = co.prec == 1 ? 1 : 3;
+    mc = pconv_eligible(a);
+  }
   if (!small && !mc && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, stride, pad);
   return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;
@@ -1794,7 +1809,13 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
 double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
   const bool small = Cin <= 4 && stride == 1 && IH * IW >= 64;
-  const bool mc = co.patch && (co.prec == 1 || co.split3) && pconv_ws_bytes(Cout, Cin, ks, 1) > 0 && stride == 1 && IH == 8 && IW == 8;
+  bool mc = false;
+  if (co.patch && (co.prec == 1 || co.split3) && stride == 1 && IH == OH && IW == OW) {
+    PConvArgs a{};
+    a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0;
+    a.nsplit = co.prec == 1 ? 1 : 3;
+    mc = pconv_eligible(a);
+  }
   if (!small && !mc && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(OH, OW, IH, IW, ks, 1, ks - 1 - pad);
   return 2.0 * N * OH * OW * (double)Cout * Cin * ks * ks;

@@ -12,8 +12,16 @@ struct PConvArgs {
 
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
+// True when pconv_try would launch for these extents (given enough workspace).
+bool pconv_eligible(const PConvArgs& a);
 // Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
+
+// 4x4 / stride-2 / pad-1 input gradient on the same kernel (four 2x2-tap phases): a.x = dy (a.Cin reduction channels, a.H x a.W),
+// a.y = dx (a.Cout channels, a.OH = 2H, a.OW = 2W), a.w_sm / a.w_sc = element strides of w for (dx channel, dy channel).
+bool pconvT_eligible(const PConvArgs& a);
+long pconvT_ws_bytes(int Cred, int Crow, int nsplit);
+int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
 
 struct PBwwArgs {
   const float* dy; const float* x; float* dw;

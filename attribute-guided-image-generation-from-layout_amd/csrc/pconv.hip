@@ -49,7 +49,7 @@ __device__ __forceinline__ void split3(float a, __bf16& t0, __bf16& t1, __bf16& 
 
 // Weight re-pack: wp[plane][cc][h][tap][m][j] = term_plane( w[m*w_sm + (16cc + 8h + j)*w_sc + tap'] ), zero for m >= M
 __global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
-                               int flip, int mpad, int nch, int nsplit) {
+                               int flip, int mpad, int nch, int nsplit, int phase4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per_plane = (long)nch * 2 * KK * mpad;
   if (i >= per_plane) return;
@@ -58,7 +58,12 @@ __global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ 
   const int tap = (int)(r % KK); r /= KK;
   const int h = (int)(r & 1);
   const int cc = (int)(r >> 1);
-  const int st = flip ? KK - 1 - tap : tap;
+  int st = flip ? KK - 1 - tap : tap;
+  if (phase4) {      // tap = phase*4 + th'*2 + tw' of the 4x4 / stride-2 / pad-1 input gradient: phase (ph,pw) of the output uses the
+    const int phase = tap >> 2, thp = (tap >> 1) & 1, twp = tap & 1;   // window rows kh = kh0 + 2*th, kh0 = (ph+1)&1, th = 1 - th'
+    const int kh = (((phase >> 1) + 1) & 1) + 2 * (1 - thp), kw = (((phase & 1) + 1) & 1) + 2 * (1 - twp);
+    st = kh * 4 + kw;
+  }
   bf16x8 t0, t1, t2;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -85,6 +90,7 @@ template <int KS> struct Pitch<16, KS, 3> { static constexpr int PWP = 16 + KS -
 template <int KS> struct Pitch<8, KS, 1> { static constexpr int PWP = 24; static constexpr int IMG_EXTRA = 0; };
 template <int KS> struct Pitch<8, KS, 3> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
 template <int NSPL> struct Pitch<4, 3, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
+template <int NSPL> struct Pitch<4, 2, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
 
 // Stride 2: the patch is split by column parity ([half][parity][row][column/2]) so that a lane group again reads 16 distinct slots;
 // PWH = pitch of a parity plane row.
@@ -102,9 +108,13 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 
 // TG: taps per weight stage (KS*KS: the whole window; KS: one kernel row at a time — keeps the 5x5 weight slice in LDS small)
 // Output tile: BM channels x (TI*TH*TW = 128 or 256) pixels; 2x2 waves, each BM/2 x BN/2.
-template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG>
+// PHS: the four stride phases of a 4x4 / stride-2 / pad-1 input gradient (= ConvTranspose2d(4,2,1) forward).  Output phase
+// (ph,pw) = blockIdx.z is a 2x2-tap stride-1 correlation of dy with pads (1-ph, 1-pw) and its own quarter of the packed weights;
+// its pixels (a,b) land at (2a+ph, 2b+pw) of the twice-as-large output map.
+template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false>
 __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
-  constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = KK / TG;
+  static_assert(!PHS || (KS == 2 && S == 1 && TG == 4), "phase mode");
+  constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = PHS ? 1 : KK / TG, KKW = PHS ? 16 : KK;
   static_assert((BN == 64 || BN == 128 || BN == 256) && (TG == KK || TG == KS) && (S == 1 || S == 2), "pconv geometry");
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;
   using PitchT = typename PitchSel<S, TW, KS, NSPL>::type;
@@ -120,8 +130,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   constexpr int WTM = BM / 64, WTN = BN / 64;   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/2 pixels)
   constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
   constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
-  static_assert((NSPL * (P_PLANE + A_PLANE)) * 4 >= 4 * 32 * EP_PITCH, "epilogue scratch must fit in the staging buffers");
-  __shared__ u32x4 lds[NSPL * (P_PLANE + A_PLANE)];
+  constexpr int STAGE_PIECES = NSPL * (P_PLANE + A_PLANE), EP_PIECES = 4 * 32 * EP_PITCH / 4;   // 16-byte pieces
+  __shared__ u32x4 lds[STAGE_PIECES > EP_PIECES ? STAGE_PIECES : EP_PIECES];
   u32x4* const Pl = lds;
   u32x4* const Al = lds + NSPL * P_PLANE;
 
@@ -139,6 +149,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
   const int bm0 = blockIdx.y * BM;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const int phase = PHS ? (int)blockIdx.z : 0, ph_y = phase >> 1, ph_x = phase & 1;
+  const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? 1 - ph_x : p.pad;
 
   // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
   // the stage term is wave-uniform and travels in the scalar offset of the loads: no per-load vector arithmetic)
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const int e = tid + NT * r;
     const int h = e / (TI * PH * PW), rem = e - h * (TI * PH * PW);
     const int ti = rem / (PH * PW), r2 = rem - ti * (PH * PW), yy = r2 / PW, xx = r2 - yy * PW;
-    const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
+    const int img = img0 + ti, ly = S * ty0 - pad_y + yy, lx = S * tx0 - pad_x + xx;
     const bool in = e < NB;
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
     bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const int e = min(tid + NT * r, NA - 1);
     const int plane = e / A_PLANE, r1 = e - plane * A_PLANE;
     const int h = r1 / (TG * BM), r2 = r1 - h * (TG * BM), t = r2 / BM, row = r2 - t * BM;
-    asrc[r] = (unsigned)((((plane * p.nch) * 2 + h) * KK + t) * p.mpad + bm0 + row);
+    asrc[r] = (unsigned)((((plane * p.nch) * 2 + h) * KKW + t) * p.mpad + bm0 + row);
   }
 
   float pb[BR][8];
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
         pb[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, bsrc[r], (unsigned)(c0 + j) * cstride, 0));
   };
   auto gload_a = [&](int cc, int tg) {                     // cc is clamped by the caller (the last prefetch is never used)
-    const u32x4* base = p.wp + (long)(cc * 2 * KK + tg * TG) * p.mpad;
+    const u32x4* base = p.wp + (long)(cc * 2 * KKW + tg * TG) * p.mpad;
 #pragma unroll
     for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
   };
@@ -227,13 +239,13 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 
   const int nstage = p.nch * NTG;      // stage s = (channel chunk s / NTG, tap group s % NTG)
   gload_b(0);
-  gload_a(0, 0);
+  gload_a(0, PHS ? phase : 0);
   sstore_b();
   sstore_a();
   __syncthreads();
   for (int s = 0; s < nstage; ++s) {
-    const int cc = s / NTG, tg = s - cc * NTG;
-    const int s1 = min(s + 1, nstage - 1), cc1 = s1 / NTG, tg1 = s1 - cc1 * NTG;   // past the end: reload the last stage (unused)
+    const int cc = s / NTG, tg = PHS ? phase : s - cc * NTG;
+    const int s1 = min(s + 1, nstage - 1), cc1 = s1 / NTG, tg1 = PHS ? phase : s1 - cc1 * NTG;   // past the end: reload the last stage (unused)
     const bool new_patch = (NTG == 1) || (s + 1) % NTG == 0;
     if (new_patch) gload_b(16 * cc1);
     gload_a(cc1, tg1);
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
       int toff;                                  // LDS piece offset of tap (kh, kw)
       if constexpr (TG == KK) toff = (t / KS) * PWP + (S == 2 ? ((t % KS) & 1) * PAR + ((t % KS) >> 1) : (t % KS));
       else toff = tg * PWP + (S == 2 ? (t & 1) * PAR + (t >> 1) : t);
+      (void)tg;
       bf16x8 fa[NSPL][WTM], fb[NSPL][WTN];
 #pragma unroll
       for (int pl = 0; pl < NSPL; ++pl) {
@@ -302,6 +315,28 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
       const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
+      if constexpr (PHS) {        // pixels (a, b..b+3) of this phase -> (2a+ph, 2(b+q)+pw) of the 2*OH x 2*OW map: scalar accesses
+        const long OHW2 = 4 * OHW;
+        const long pb2 = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * (2 * p.OW) + 2 * (tx0 + px) + ph_x;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          if (m < p.Cout && img < p.N) {
+            const float vv[4] = {v[ps].x, v[ps].y, v[ps].z, v[ps].w};
+            const float bb = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const long o = pb2 + (long)m * OHW2 + 2 * q;
+              float val = vv[q] + bb;
+              if (p.pos_mask && !(p.pos_mask[o] > 0.f)) val = 0.f;
+              if (p.accumulate) val += p.y[o];
+              if (p.relu) val = fmaxf(val, 0.f);
+              p.y[o] = val;
+            }
+          }
+        }
+        continue;
+      }
       float4 old[4], msk[4];
       if (p.accumulate) {
 #pragma unroll
@@ -553,7 +588,9 @@ long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
   return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
 }
 
-int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+struct PConvPlan { int geo, bm; bool s2, w32, wide, half; long ptiles; };
+// Pure eligibility / tiling decision (no launches): 0 when pconv takes the call.
+static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   const bool s2 = a.stride == 2;
   if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
   if (a.Cin % 16 != 0 || a.Cout < 48) return -1;
@@ -564,20 +601,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   else if (a.OW == 4 && a.OH == 4 && (a.ks == 3 || a.ks == 4)) geo = 2;
   else return -1;
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
-  const long need = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
-  if (!ws || ws_bytes < need) return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
-  const int KK = a.ks * a.ks, nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
-  u32x4* wp = (u32x4*)ws;
-  const long per_plane = (long)nch * 2 * KK * mpad;
-  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, KK, a.w_sm,
-                     a.w_sc, a.flip, mpad, nch, a.nsplit);
-  AGL_CHECK_LAUNCH(name);
-  PArgs p;
-  p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
-  p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
-  p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
-  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   // nsplit 1: 128 channels (64 when Cout <= 64) x 256 pixels per workgroup, 128 pixels when the wider tile would leave CUs
   // without work; nsplit 3: 64 x 128 (three LDS planes).  Stride 2 (patch = 4x the tile): 128 pixels, 64 in split mode.
   const int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
@@ -590,7 +614,36 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   if (geo == 0) ptiles = half ? px128 * 2 : px128 / (wide ? 2 : 1);
   else if (geo == 1) ptiles = half ? a.N : agl_cdiv(a.N, wide ? 4 : 2);
   else ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
+  // no reduction split in this kernel: a grid that cannot occupy most CUs runs one long serial K loop per workgroup and is
+  // slower than the split-K im2col / position-major kernels (ConvLSTM recurrence steps over the few images still active)
+  if (ptiles * agl_cdiv(a.Cout, bm) < 200) return -1;
+  pl.geo = geo; pl.bm = bm; pl.s2 = s2; pl.w32 = w32; pl.wide = wide; pl.half = half; pl.ptiles = ptiles;
+  return 0;
+}
+
+bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
+
+int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  PConvPlan pl;
+  if (pconv_plan(a, pl) != 0) return -1;
+  const long need = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
+  if (!ws || ws_bytes < need) return -1;
+  const int geo = pl.geo, bm = pl.bm;
+  const bool s2 = pl.s2, w32 = pl.w32, wide = pl.wide, half = pl.half;
+  const long ptiles = pl.ptiles;
+  (void)half;
+  const int KK = a.ks * a.ks, nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
+  u32x4* wp = (u32x4*)ws;
+  PArgs p;
+  p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
+  p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
+  p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, KK, a.w_sm,
+                     a.w_sc, a.flip, mpad, nch, a.nsplit, 0);
+  AGL_CHECK_LAUNCH(name);
 #define PC_LAUNCH(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
 #define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
@@ -640,6 +693,60 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_SHAPES1
 #undef PC_SHAPES3
 #undef PC_LAUNCH
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+
+// ---- 4x4 / stride-2 / pad-1 input gradient (and ConvTranspose2d(4,2,1) forward): four 2x2-tap phases, blockIdx.z = phase ----
+// a.x = dy (N, a.Cin = reduction channels, a.H x a.W), a.y = dx (N, a.Cout, 2H x 2W); w[co][ci][4][4] addressed through
+// w_sm (stride of the output row m = ci: 16) and w_sc (stride of the reduction channel c = co: Cin*16).
+static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles) {
+  if (a.ks != 4 || a.stride != 2 || a.pad != 1 || a.up != 0 || a.Cin % 16 != 0 || a.Cout < 48) return -1;
+  if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
+  if (a.OH != 2 * a.H || a.OW != 2 * a.W) return -1;
+  if (a.W % 16 == 0 && a.H % 8 == 0) *geo = 0;
+  else if (a.W == 8 && a.H == 8) *geo = 1;
+  else if (a.W == 4 && a.H == 4) *geo = 2;
+  else return -1;
+  if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;
+  *bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
+  *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  if (*ptiles * agl_cdiv(a.Cout, *bm) * 4 < 200) return -1;
+  return 0;
+}
+bool pconvT_eligible(const PConvArgs& a) { int g, b; long t; return pconvT_plan(a, &g, &b, &t) == 0; }
+long pconvT_ws_bytes(int Cred, int Crow, int nsplit) {
+  if (Cred % 16 != 0 || Crow < 48) return 0;
+  return (long)nsplit * (Cred / 16) * 2 * 16 * round_up(Crow, 128) * 16;
+}
+int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  int geo, bm; long ptiles;
+  if (pconvT_plan(a, &geo, &bm, &ptiles) != 0) return -1;
+  if (!ws || ws_bytes < pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit)) return -1;
+  const int nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
+  u32x4* wp = (u32x4*)ws;
+  const long per_plane = (long)nch * 2 * 16 * mpad;
+  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, 16, a.w_sm,
+                     a.w_sc, 0, mpad, nch, a.nsplit, 1);
+  AGL_CHECK_LAUNCH(name);
+  PArgs p;
+  p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
+  p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
+  p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), 4);
+#define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
+#define PT_GEO(BM_, NS_)                                          \
+  do {                                                            \
+    if (geo == 0) PT_LAUNCH(16, 8, 1, BM_, NS_);                  \
+    else if (geo == 1) PT_LAUNCH(8, 8, 2, BM_, NS_);              \
+    else PT_LAUNCH(4, 4, 8, BM_, NS_);                            \
+  } while (0)
+  if (a.nsplit == 3) PT_GEO(64, 3);
+  else if (bm == 128) PT_GEO(128, 1);
+  else PT_GEO(64, 1);
+#undef PT_GEO
+#undef PT_LAUNCH
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }

@@ -748,3 +748,22 @@ def test_pconv_stride2_forward(case, mode):
     wg = r(w).clone().requires_grad_(True)
     TF.conv2d(r(x), wg, None, stride=2, padding=p).backward(r(gy))
     close(dw, wg.grad, 1e-4, "stride-2 weight gradient")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(4, 64, 32, 128), (5, 96, 16, 64), (9, 128, 8, 80), (17, 64, 4, 256), (3, 48, 64, 64)])
+def test_pconv_stride2_input_gradient_phases(case, mode):
+    """4x4 / stride-2 / pad-1 input gradient (and ConvTranspose2d(4,2,1) forward) as four 2x2-tap phases on the bf16-matrix-core
+    patch kernel, against torch: plain, and with the consumer's ReLU mask + accumulation."""
+    from agl import lib as L
+    N, Cout, OH, Cin = case            # dy: (N, Cout, OH, OH); dx: (N, Cin, 2*OH, 2*OH)
+    w = rn(Cout, Cin, 4, 4, seed=1) * (1.0 / (Cout * 4) ** 0.5)
+    gy = rn(N, Cout, OH, OH, seed=3)
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    ref = TF.conv_transpose2d(r(gy), r(w), None, stride=2, padding=1)
+    mask, base = rn(N, Cin, 2 * OH, 2 * OH, seed=5), rn(N, Cin, 2 * OH, 2 * OH, seed=6)
+    with L.conv_flags(L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3):
+        dx = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1)
+        dx2 = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1, pos_mask=dev(mask), out=dev(base).clone(), accumulate=True)
+    close(dx, ref, 5e-5 if mode == "bf16" else 2e-5, "stride-2 input gradient")
+    close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
