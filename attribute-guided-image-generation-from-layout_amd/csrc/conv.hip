@@ -1823,7 +1823,7 @@ double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int O
 double agl_conv2d_bwd_weight_flops(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad,
                                    int up_log2, int in_relu, int flags) {
   const ConvOpts co = conv_opts(flags);
-  const bool mc = co.patch && co.prec == 1 && Cin % 16 == 0 && Cout >= 32;     // pbww takes 5x5 in bf16 mode only
+  const bool mc = co.patch && (co.prec == 1 || co.split3) && Cin % 16 == 0 && Cout >= 32;     // pbww takes the call (dense taps)
   if (!mc && stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
       pos_ok(co, N, 64, H, W, Cout, ks, 0))
     return 2.0 * N * Cout * Cin * (double)pos_valid_taps(H, W, OH, OW, ks, 1, pad);

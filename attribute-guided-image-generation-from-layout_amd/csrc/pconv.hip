@@ -91,6 +91,8 @@ template <int KS> struct Pitch<8, KS, 1> { static constexpr int PWP = 24; static
 template <int KS> struct Pitch<8, KS, 3> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
 template <int NSPL> struct Pitch<4, 3, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
 template <int NSPL> struct Pitch<4, 2, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
+template <> struct Pitch<2, 2, 1> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 2; };
+template <> struct Pitch<2, 2, 3> { static constexpr int PWP = 3; static constexpr int IMG_EXTRA = 0; };   // 2-way, fits two workgroups
 
 // Stride 2: the patch is split by column parity ([half][parity][row][column/2]) so that a lane group again reads 16 distinct slots;
 // PWH = pitch of a parity plane row.
@@ -315,18 +317,26 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
       const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
-      if constexpr (PHS) {        // pixels (a, b..b+3) of this phase -> (2a+ph, 2(b+q)+pw) of the 2*OH x 2*OW map: scalar accesses
+      if constexpr (PHS) {        // pixel (a, b) of this phase -> (2a+ph, 2b+pw) of the 2*OH x 2*OW map: scalar accesses
         const long OHW2 = 4 * OHW;
-        const long pb2 = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * (2 * p.OW) + 2 * (tx0 + px) + ph_x;
+        long pb2[4];
+        bool iok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // (with 2-wide tiles the four pixels of a lane are not in one row)
+          const int jq = j + q, tq = jq / (TH * TW), rq = jq - tq * (TH * TW), pyq = rq / TW, pxq = rq - pyq * TW;
+          iok[q] = img0 + tq < p.N;
+          pb2[q] = (long)(img0 + tq) * p.Cout * OHW2 + (long)(2 * (ty0 + pyq) + ph_y) * (2 * p.OW) + 2 * (tx0 + pxq) + ph_x;
+        }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
-          if (m < p.Cout && img < p.N) {
+          if (m < p.Cout) {
             const float vv[4] = {v[ps].x, v[ps].y, v[ps].z, v[ps].w};
             const float bb = p.bias ? p.bias[m] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const long o = pb2 + (long)m * OHW2 + 2 * q;
+              if (!iok[q]) continue;
+              const long o = pb2[q] + (long)m * OHW2;
               float val = vv[q] + bb;
               if (p.pos_mask && !(p.pos_mask[o] > 0.f)) val = 0.f;
               if (p.accumulate) val += p.y[o];
@@ -398,9 +408,12 @@ struct WArgs {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL>
+// TSUB: taps per pass.  When 4*RT*CT*KS^2 accumulator registers (x2 in split mode) do not fit, the taps are processed in
+// ceil(KS^2/TSUB) passes by different workgroups (blockIdx.y = channel block * passes + pass), each staging the same tiles.
+template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS>
 __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
+  constexpr int NPASS = (KK + TSUB - 1) / TSUB;
   static_assert((NPX == 128 || NPX == 64) && TW >= 8, "pbww geometry");
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, IMGP = PH * PW, NQ = TI * IMGP;
   constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
@@ -412,14 +425,15 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
   unsigned char* const Xl = lds + NSPL * D_PLANE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int c0 = blockIdx.y * BC, co0 = blockIdx.z * BMCO;
+  const int pass = NPASS == 1 ? 0 : (int)blockIdx.y % NPASS, tap0 = pass * TSUB;
+  const int c0 = ((int)blockIdx.y / NPASS) * BC, co0 = blockIdx.z * BMCO;
   const int t_beg = blockIdx.x * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
   const int Hl = p.H << p.up, Wl = p.W << p.up;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
   const int tpr = p.OW / TW, tpi = TI == 1 ? (p.OH / TH) * tpr : 1;
 
-  f32x4 acc[NACC][RT][CT][KK];
+  f32x4 acc[NACC][RT][CT][TSUB];
 #pragma unroll
   for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
 #pragma unroll
       for (int j = 0; j < CT; ++j)
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc[a][i][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TSUB; ++t) acc[a][i][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane patch positions of the tr reads: K-step ks, read rd (rows 4*rd .. 4*rd+3 of the group's 8 pixels)
   int xq[KSTEPS][2];
@@ -521,8 +535,10 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
         for (int i = 0; i < RT; ++i)
           fa[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Dl + pl * D_PLANE + arow + i * 16 * DPITCH + ks * 64));
 #pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const int toff = ((t / KS) * PW + (t % KS)) * XROW;
+      for (int t = 0; t < TSUB; ++t) {
+        const int tap = tap0 + t;
+        if (NPASS > 1 && tap >= KK) break;                      // (uniform) last pass of an uneven split
+        const int toff = ((tap / KS) * PW + (tap % KS)) * XROW;
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
           bf16x8 fb[NSPL];
@@ -564,10 +580,11 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
         if (co < p.Cout) {
           float* o = out + ((long)co * p.Cin + c) * KK;
 #pragma unroll
-          for (int t = 0; t < KK; ++t) {
+          for (int t = 0; t < TSUB; ++t) {
+            if (tap0 + t >= KK) break;
             float v = acc[0][i][j][t][r];
             if constexpr (NSPL == 3) v += acc[1][i][j][t][r];
-            o[t] = v;
+            o[tap0 + t] = v;
           }
         }
       }
@@ -599,6 +616,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   if (a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
   else if (a.OW == 8 && a.OH == 8) geo = 1;
   else if (a.OW == 4 && a.OH == 4 && (a.ks == 3 || a.ks == 4)) geo = 2;
+  else if (!s2 && a.OW % 8 == 0 && a.OH % 8 == 0) geo = 3;      // 8 x 8 tiles of one image (64 pixels)
   else return -1;
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
@@ -607,13 +625,14 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   const int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   const long px128 = geo == 0 ? (long)a.N * (a.OH / 8) * (a.OW / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
   const bool w32 = a.OW % 32 == 0;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
-  bool wide = !s2 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  bool wide = !s2 && geo != 3 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
   if (geo == 0 && wide && !w32 && a.OH % 16 != 0) wide = false;
   const bool half = s2 && a.nsplit == 3;           // 64-pixel tiles
   long ptiles;
   if (geo == 0) ptiles = half ? px128 * 2 : px128 / (wide ? 2 : 1);
   else if (geo == 1) ptiles = half ? a.N : agl_cdiv(a.N, wide ? 4 : 2);
-  else ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
+  else if (geo == 2) ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
+  else ptiles = (long)a.N * (a.OH / 8) * (a.OW / 8);
   // no reduction split in this kernel: a grid that cannot occupy most CUs runs one long serial K loop per workgroup and is
   // slower than the split-K im2col / position-major kernels (ConvLSTM recurrence steps over the few images still active)
   if (ptiles * agl_cdiv(a.Cout, bm) < 200) return -1;
@@ -648,7 +667,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
 #define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
   do {                                                                                                   \
-    if (geo == 0 && !wide) PC_LAUNCH(KS_, 1, 16, 8, 1, BM_, 1, TG_);                                     \
+    if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, BM_, 1, TG_);                                               \
+    else if (geo == 0 && !wide) PC_LAUNCH(KS_, 1, 16, 8, 1, BM_, 1, TG_);                                \
     else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 8, 1, BM_, 1, TG_);                                  \
     else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 16, 1, BM_, 1, TG_);                                        \
     else if (geo == 1 && !wide) PC_LAUNCH(KS_, 1, 8, 8, 2, BM_, 1, TG_);                                 \
@@ -656,7 +676,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   } while (0)
 #define PC_SHAPES3(KS_, TG_)                                                                             \
   do {                                                                                                   \
-    if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 4, 1, 64, 3, TG_);                                        \
+    if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, 64, 3, TG_);                                                \
+    else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 4, 1, 64, 3, TG_);                                   \
     else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 8, 1, 64, 3, TG_);                                          \
     else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 2, 64, 3, TG_);                                           \
   } while (0)
@@ -707,10 +728,11 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles) {
   if (a.W % 16 == 0 && a.H % 8 == 0) *geo = 0;
   else if (a.W == 8 && a.H == 8) *geo = 1;
   else if (a.W == 4 && a.H == 4) *geo = 2;
+  else if (a.W == 2 && a.H == 2) *geo = 3;
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;
   *bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
-  *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : (*geo == 2 ? agl_cdiv(a.N, 8) : agl_cdiv(a.N, 32)));
   if (*ptiles * agl_cdiv(a.Cout, *bm) * 4 < 200) return -1;
   return 0;
 }
@@ -740,7 +762,8 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   do {                                                            \
     if (geo == 0) PT_LAUNCH(16, 8, 1, BM_, NS_);                  \
     else if (geo == 1) PT_LAUNCH(8, 8, 2, BM_, NS_);              \
-    else PT_LAUNCH(4, 4, 8, BM_, NS_);                            \
+    else if (geo == 2) PT_LAUNCH(4, 4, 8, BM_, NS_);              \
+    else PT_LAUNCH(2, 2, 32, BM_, NS_);                           \
   } while (0)
   if (a.nsplit == 3) PT_GEO(64, 3);
   else if (bm == 128) PT_GEO(128, 1);
@@ -756,24 +779,27 @@ static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, 
   const bool s2 = a.stride == 2;
   if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
   if (a.Cin % 16 != 0 || a.Cout < 32) return -1;
-  if (!(a.nsplit == 1 || a.nsplit == 3) || (a.nsplit == 3 && a.ks == 5)) return -1;
+  if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
   const bool half = s2 && a.nsplit == 3;       // 64-pixel tiles: the stride-2 patch of a 128-pixel tile does not fit three planes
   long tiles;
-  if (a.OW % 16 == 0 && a.OH % 8 == 0) tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1);
-  else if (a.OW == 8 && a.OH == 8) tiles = half ? a.N : agl_cdiv(a.N, 2);
+  int shape;           // pixel tile: 0 = 8 x 16, 1 = two 8 x 8 images, 2 = 4 x 16 (64 pixels), 3 = 8 x 8 of one image (64 pixels)
+  if (a.OW % 16 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1); shape = half ? 2 : 0; }
+  else if (a.OW == 8 && a.OH == 8) { tiles = half ? a.N : agl_cdiv(a.N, 2); shape = half ? 3 : 1; }
+  else if (a.OW % 8 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 8); shape = 3; }
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
   *rt = (a.nsplit == 1 && a.ks != 5 && a.Cout > 64) ? 2 : 1;
   *ct = (a.nsplit == 1 && a.ks == 3 && a.Cin % 32 == 0) ? 2 : 1;
-  const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct));
+  const int npass = (a.nsplit == 3 && a.ks == 5) ? 2 : 1;      // 25 taps in split mode: 13 + 12
+  const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
   long z = (768 + blocks - 1) / blocks;       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
   if (z > tiles) z = tiles;
   if (z < 1) z = 1;
   const long per = (tiles + z - 1) / z;
   z = (tiles + per - 1) / per;
-  *splits = (int)z; *tps = (int)per; *tiles_out = tiles; *half_out = half;
+  *splits = (int)z; *tps = (int)per; *tiles_out = tiles; *half_out = shape;
   return 0;
 }
 
@@ -792,13 +818,13 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
-  dim3 g((unsigned)splits, a.Cin / (16 * ct), agl_cdiv(a.Cout, 64 * rt));
-  const bool g8 = a.OW == 8 && a.OH == 8;
+  const int npass = (a.nsplit == 3 && a.ks == 5) ? 2 : 1;
+  dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
 #define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
-    if (g8 && half) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);          \
-    else if (g8) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);             \
-    else if (half) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);          \
+    if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);           \
+    else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
+    else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);     \
     else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                    \
   } while (0)
   if (a.stride == 2) {
@@ -809,7 +835,12 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     if (rt == 2 && ct == 2) PW_LAUNCH(3, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 1, 2, 1, 1);
     else if (ct == 2) PW_LAUNCH(3, 1, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1, 1);
   } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
-  else PW_LAUNCH(5, 1, 1, 1, 1);
+  else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
+  else {
+    if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
+  }
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
   hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.dw, n, splits, a.accumulate);

@@ -656,7 +656,7 @@ def test_modules_vs_reference_op_fixtures(golden_dir):
 
 PCONV_CASES = [  # N, Cin, H, Cout, ks  (stride 1, "same" padding): the three tile geometries of csrc/pconv.hip, 3x3 and 5x5
     (4, 64, 32, 128, 3), (3, 32, 16, 64, 3), (2, 48, 64, 80, 3), (5, 64, 8, 128, 3), (7, 32, 8, 200, 3), (9, 64, 4, 128, 3),
-    (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5)]
+    (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5), (9, 64, 24, 128, 3), (7, 32, 40, 64, 3)]
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
@@ -751,7 +751,7 @@ def test_pconv_stride2_forward(case, mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
-@pytest.mark.parametrize("case", [(4, 64, 32, 128), (5, 96, 16, 64), (9, 128, 8, 80), (17, 64, 4, 256), (3, 48, 64, 64)])
+@pytest.mark.parametrize("case", [(4, 64, 32, 128), (5, 96, 16, 64), (9, 128, 8, 80), (17, 64, 4, 256), (3, 48, 64, 64), (70, 128, 2, 256)])
 def test_pconv_stride2_input_gradient_phases(case, mode):
     """4x4 / stride-2 / pad-1 input gradient (and ConvTranspose2d(4,2,1) forward) as four 2x2-tap phases on the bf16-matrix-core
     patch kernel, against torch: plain, and with the consumer's ReLU mask + accumulation."""
