@@ -104,15 +104,20 @@ struct FwdProb {
     int img = nn / OHW, pix = nn - img * OHW;
     c.off = (long)img * Cout * OHW + pix; return c;
   }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) {
-      long o = c.off + (long)m * OHW;
-      if (splits > 1) { part[o] = v; return; }
-      if (bias) v += bias[m];
-      if (accumulate) v += y[o];
-      if (relu) v = fmaxf(v, 0.f);
-      y[o] = v;
-    }
+  // epilogue API (see igemm_f32): the operands an epilogue needs from memory are fetched for a whole accumulator tile before any
+  // of them is consumed — a per-element `if (accumulate) v += y[o]` makes the compiler wait for each load in turn
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return c.off + (long)m * OHW; }
+  __device__ bool reads_old() const { return splits <= 1 && accumulate; }
+  __device__ bool reads_mask() const { return false; }
+  __device__ float old_at(long o) const { return y[o]; }
+  __device__ float mask_at(long) const { return 1.f; }
+  __device__ void finish(int m, long o, float v, float old, float) const {
+    if (splits > 1) { part[o] = v; return; }
+    if (bias) v += bias[m];
+    if (accumulate) v += old;
+    if (relu) v = fmaxf(v, 0.f);
+    y[o] = v;
   }
 };
 
@@ -186,16 +191,19 @@ struct BwdDataProb {
     int a = q / IWp, b = q - a * IWp;
     c.off = (long)img * Cin * IHW + (long)(a * S + ph) * IW + (b * S + pw); return c;
   }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) {
-      long o = c.off + (long)m * IHW;
-      if (splits > 1) { part[o] = v; return; }
-      if (bias) v += bias[m];
-      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
-      if (accumulate) v += dx[o];
-      if (relu) v = fmaxf(v, 0.f);
-      dx[o] = v;
-    }
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return c.off + (long)m * IHW; }
+  __device__ bool reads_old() const { return splits <= 1 && accumulate; }
+  __device__ bool reads_mask() const { return splits <= 1 && pos_mask != nullptr; }
+  __device__ float old_at(long o) const { return dx[o]; }
+  __device__ float mask_at(long o) const { return pos_mask[o]; }
+  __device__ void finish(int m, long o, float v, float old, float mk) const {
+    if (splits > 1) { part[o] = v; return; }
+    if (bias) v += bias[m];
+    if (pos_mask && !(mk > 0.f)) v = 0.f;
+    if (accumulate) v += old;
+    if (relu) v = fmaxf(v, 0.f);
+    dx[o] = v;
   }
 };
 
@@ -290,16 +298,19 @@ struct BwdDataGenProb {
     int a = q / IWp, b = q - a * IWp;
     c.off = (long)img * Cin * IHW + (long)(a * S + ph) * IW + (b * S + pw); return c;
   }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) {
-      long o = c.off + (long)m * IHW;
-      if (splits > 1) { part[o] = v; return; }
-      if (bias) v += bias[m];
-      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
-      if (accumulate) v += dx[o];
-      if (relu) v = fmaxf(v, 0.f);
-      dx[o] = v;
-    }
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return c.off + (long)m * IHW; }
+  __device__ bool reads_old() const { return splits <= 1 && accumulate; }
+  __device__ bool reads_mask() const { return splits <= 1 && pos_mask != nullptr; }
+  __device__ float old_at(long o) const { return dx[o]; }
+  __device__ float mask_at(long o) const { return pos_mask[o]; }
+  __device__ void finish(int m, long o, float v, float old, float mk) const {
+    if (splits > 1) { part[o] = v; return; }
+    if (bias) v += bias[m];
+    if (pos_mask && !(mk > 0.f)) v = 0.f;
+    if (accumulate) v += old;
+    if (relu) v = fmaxf(v, 0.f);
+    dx[o] = v;
   }
 };
 
@@ -356,9 +367,13 @@ struct BwdWeightProb {
   }
   struct Col { int n; bool ok; };
   __device__ Col col(int n) const { return {n, n < Nc}; }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) out[(long)m * Nc + c.n] = v;
-  }
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return (long)m * Nc + c.n; }
+  __device__ bool reads_old() const { return false; }
+  __device__ bool reads_mask() const { return false; }
+  __device__ float old_at(long) const { return 0.f; }
+  __device__ float mask_at(long) const { return 1.f; }
+  __device__ void finish(int, long o, float v, float, float) const { out[o] = v; }
 };
 
 // ------------------------------------------------------------------ position-major forward (small maps)
@@ -460,14 +475,17 @@ struct PosFwdProb {
     col_of(c.ok ? n : 0, q, img);
     c.off = (long)q * Cout * N + img; return c;
   }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) {
-      const long o = c.off + (long)m * N;
-      if (splits > 1) { part[o] = v; return; }
-      if (bias) v += bias[m];
-      if (relu) v = fmaxf(v, 0.f);
-      yt[o] = v;
-    }
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return c.off + (long)m * N; }
+  __device__ bool reads_old() const { return false; }
+  __device__ bool reads_mask() const { return false; }
+  __device__ float old_at(long) const { return 0.f; }
+  __device__ float mask_at(long) const { return 1.f; }
+  __device__ void finish(int m, long o, float v, float, float) const {
+    if (splits > 1) { part[o] = v; return; }
+    if (bias) v += bias[m];
+    if (relu) v = fmaxf(v, 0.f);
+    yt[o] = v;
   }
 };
 
@@ -534,9 +552,13 @@ struct PosBwwProb {
   __device__ unsigned off_b(const RowB& r, const KB& k) const { return (r.ok & k.ok) ? (unsigned)(k.base + r.base) * 4u : OOB; }
   struct Col { int n; bool ok; };
   __device__ Col col(int n) const { return {n, n < Nc}; }
-  __device__ void store(int m, const Col& c, float v) const {
-    if (m < M && c.ok) out[(long)m * Nc + c.n] = v;
-  }
+  __device__ bool out_ok(int m, const Col& c) const { return m < M && c.ok; }
+  __device__ long out_off(int m, const Col& c) const { return (long)m * Nc + c.n; }
+  __device__ bool reads_old() const { return false; }
+  __device__ bool reads_mask() const { return false; }
+  __device__ float old_at(long) const { return 0.f; }
+  __device__ float mask_at(long) const { return 1.f; }
+  __device__ void finish(int, long o, float v, float, float) const { out[o] = v; }
 };
 
 // dw[(a*B + b)*KK + t] (+)= dwt[(t*A + a)*B + b]
@@ -820,8 +842,26 @@ __global__ __launch_bounds__(NT, (BM * BN > 128 * 128) ? 2 : 4) void igemm_f32(P
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int mb = bm0 + wm * 32 * WTM + 32 * i + 4 * lh;
+      long o[16];
+      bool ok[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p.store(mb + (r & 3) + 8 * (r >> 2), c, acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        ok[r] = p.out_ok(m, c);
+        o[r] = p.out_off(m, c);
+      }
+      float old[16], mk[16];
+      if (p.reads_old()) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = ok[r] ? p.old_at(o[r]) : 0.f;
+      }
+      if (p.reads_mask()) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = ok[r] ? p.mask_at(o[r]) : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok[r]) p.finish(mb + (r & 3) + 8 * (r >> 2), o[r], acc[i][j][r], old[r], mk[r]);
     }
   }
 }
@@ -1215,6 +1255,22 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int mb = bm0 + wm * 32 * WTM + 32 * i + 4 * lh;
+      float old[16], mk[16];
+      const bool rd_old = p.splits <= 1 && p.accumulate, rd_mask = p.splits <= 1 && p.pos_mask != nullptr;
+      if (rd_old) {          // operands of the epilogue are fetched for the whole tile first (no load-wait chain per element)
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const int m = mb + (r2 & 3) + 8 * (r2 >> 2);
+          old[r2] = (m < p.Cout && img < p.N) ? outp[pbase + (long)m * OHW] : 0.f;
+        }
+      }
+      if (rd_mask) {
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const int m = mb + (r2 & 3) + 8 * (r2 >> 2);
+          mk[r2] = (m < p.Cout && img < p.N) ? p.pos_mask[pbase + (long)m * OHW] : 1.f;
+        }
+      }
 #pragma unroll
       for (int r2 = 0; r2 < 16; ++r2) {
         const int m = mb + (r2 & 3) + 8 * (r2 >> 2);
@@ -1223,8 +1279,8 @@ __global__ __launch_bounds__(NT, 3) void patch_conv(PatchArgs p) {
           float v = acc[i][jt][r2];
           if (p.splits > 1) { outp[o] = v; continue; }
           if (p.bias) v += p.bias[m];
-          if (p.pos_mask && !(p.pos_mask[o] > 0.f)) v = 0.f;
-          if (p.accumulate) v += outp[o];
+          if (rd_mask && !(mk[r2] > 0.f)) v = 0.f;
+          if (rd_old) v += old[r2];
           if (p.relu) v = fmaxf(v, 0.f);
           outp[o] = v;
         }

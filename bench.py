@@ -249,7 +249,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             tr_ = hbm_traffic(tag)
             roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4),
-                        "traffic": tr_["bytes_per_launch"] if tr_ else None,
+                        "traffic": round(tr_["bytes_per_iteration"] / max(1, len(nrm))) if tr_ else None,
                         "traffic_source": tr_["source"] if tr_ else None,
                         "algorithmic_bytes_per_launch": round(nbytes / max(1, len(nrm))),
                         "kernel": "normalisation family: bn_stats_partial/final + norm_apply_fwd + norm_bwd_rows/channels/apply "
