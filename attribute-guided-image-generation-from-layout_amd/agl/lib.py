@@ -85,6 +85,10 @@ SIGNATURES = {
     "agl_kl_sum": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "agl_rasterize_boxes": (_I, [_P, _P, _I, _I, _P]),
     "agl_attr_estimate": (_I, [_P, _P, _P, _I, _I, _P]),
+    "agl_layout_from_boxes": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "agl_attr_edit": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "agl_topk_contains": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "agl_sigmoid_threshold": (_I, [_P, _P, _L, _F, _P]),
     "agl_deprocess_u8": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "agl_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
 }
@@ -468,6 +472,37 @@ def rasterize_boxes(boxes, R):
     masks = torch.empty((O, 1, R, R), dtype=torch.float32, device=boxes.device)
     call("agl_rasterize_boxes", ptr(boxes.contiguous()), ptr(masks), O, R, stream())
     return masks
+
+
+def layout_from_boxes(boxes, R):
+    """(O,4) boxes -> (boxes_shift (O,4), masks (O,1,R,R), masks_shift (O,1,R,R)) on device (data/vg_custom_mask.py:136-158)."""
+    O = boxes.shape[0]
+    boxes = boxes.contiguous()
+    bs = torch.empty_like(boxes)
+    masks = torch.empty((O, 1, R, R), dtype=torch.float32, device=boxes.device)
+    ms = torch.empty_like(masks)
+    call("agl_layout_from_boxes", ptr(boxes), ptr(bs), ptr(masks), ptr(ms), O, R, stream())
+    return bs, masks, ms
+
+
+def attr_edit_(attribute, cols_dev, tgt):
+    """In place: attribute[:, cols] = 0; attribute[:, tgt] = 1 (test64.py:160-167).  cols_dev: int32 device tensor."""
+    O, A = attribute.shape
+    call("agl_attr_edit", ptr(attribute), ptr(cols_dev, torch.int32), cols_dev.numel(), int(tgt), O, A, stream())
+    return attribute
+
+
+def topk_contains(logits, k, tgt):
+    O, A = logits.shape
+    out = torch.empty(O, dtype=torch.uint8, device=logits.device)
+    call("agl_topk_contains", ptr(logits.contiguous()), ptr(out, torch.uint8), O, A, int(k), int(tgt), stream())
+    return out
+
+
+def sigmoid_threshold(logits, thr):
+    pred = torch.empty(logits.shape, dtype=torch.uint8, device=logits.device)
+    call("agl_sigmoid_threshold", ptr(logits.contiguous()), ptr(pred, torch.uint8), logits.numel(), float(thr), stream())
+    return pred
 
 
 def deprocess_u8(imgs, inv_std, mean, rescale=True):

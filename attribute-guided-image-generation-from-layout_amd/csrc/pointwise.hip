@@ -472,6 +472,63 @@ __global__ void rasterize_boxes_k(const float* __restrict__ boxes, float* __rest
   masks[i] = (x >= cx0 && x < cx1 && y >= cy0 && y < cy1) ? 1.f : 0.f;
 }
 
+// Per-object layout tensors of the VG batch builder from the boxes alone (data/vg_custom_mask.py:136-158), N3: the box mask,
+// the shifted box (moved by 0.8 x the larger horizontal border distance when the box is narrower than half the image) and the
+// shifted mask.  The reference computes with python floats (doubles) and python round (half to even): same here.  One workgroup
+// column per object plane; thread -> pixel.
+__global__ void layout_from_boxes_k(const float* __restrict__ boxes, float* __restrict__ boxes_shift, float* __restrict__ masks,
+                                    float* __restrict__ masks_shift, int O, int R) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= (long)O * R * R) return;
+  const int x = (int)(i % R);
+  long t = i / R;
+  const int y = (int)(t % R);
+  const int o = (int)(t / R);
+  const float* b = boxes + 4 * o;
+  const double x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3];
+  double sx0 = x0, sx1 = x1;
+  if (x1 - x0 < 0.5) {                                   // :144
+    const double left = x0, right = 1.0 - x1;
+    if (left > right) { const double sh = left * 0.8; sx0 = x0 - sh; sx1 = x1 - sh; }          // :147-151
+    else if (right > left) { const double sh = right * 0.8; sx0 = x0 + sh; sx1 = x1 + sh; }    // :152-156
+  }
+  auto clip = [R](long v) { if (v < 0) v += R; return v < 0 ? 0L : (v > R ? (long)R : v); };    // python slice semantics
+  const long cy0 = clip((long)rint(y0 * R)), cy1 = clip((long)rint(y1 * R));
+  const bool iny = y >= cy0 && y < cy1;
+  masks[i] = (iny && x >= clip((long)rint(x0 * R)) && x < clip((long)rint(x1 * R))) ? 1.f : 0.f;                 // :136
+  masks_shift[i] = (iny && x >= clip((long)rint(sx0 * R)) && x < clip((long)rint(sx1 * R))) ? 1.f : 0.f;       // :157
+  if (x == 0 && y == 0) {                                                                                       // :158
+    boxes_shift[4 * o + 0] = (float)sx0; boxes_shift[4 * o + 1] = (float)y0;
+    boxes_shift[4 * o + 2] = (float)sx1; boxes_shift[4 * o + 3] = (float)y1;
+  }
+}
+
+// ---- inference-side attribute logic (test64.py:114-198), N2
+// rows of `attribute` (O, A): clear the listed columns and set column tgt (test64.py:160-167 attribute modification)
+__global__ void attr_edit_k(float* __restrict__ attribute, const int* __restrict__ cols, int ncols, int tgt, int O, int A) {
+  const int o = blockIdx.x * TPB + threadIdx.x;
+  if (o >= O) return;
+  for (int j = 0; j < ncols; ++j) attribute[(long)o * A + cols[j]] = 0.f;
+  attribute[(long)o * A + tgt] = 1.f;
+}
+// out[o] = 1 if column tgt is among the k largest logits of row o (torch.topk(k) membership, test64.py:180-184): true iff fewer than
+// k entries are strictly greater (ties resolved in favour of membership)
+__global__ void topk_contains_k(const float* __restrict__ logits, unsigned char* __restrict__ out, int O, int A, int k, int tgt) {
+  const int o = blockIdx.x * TPB + threadIdx.x;
+  if (o >= O) return;
+  const float* row = logits + (long)o * A;
+  const float v = row[tgt];
+  int greater = 0;
+  for (int j = 0; j < A; ++j) greater += row[j] > v;
+  out[o] = greater < k;
+}
+// pred[o][a] = sigmoid(logits[o][a]) > thr  (test64.py:143-150)
+__global__ void sigmoid_threshold_k(const float* __restrict__ logits, unsigned char* __restrict__ pred, long n, float thr) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  pred[i] = 1.f / (1.f + expf(-logits[i])) > thr;
+}
+
 // ImageNet de-normalisation to bytes (data/utils.py:47-66 imagenet_deprocess_batch): per channel
 // y = x / fp32(1/std_c) + fp32(mean_c) (two torchvision Normalize passes: sub 0, div 1/std; sub -mean, div 1),
 // then per IMAGE (all channels) r = (y - lo) / (hi - lo) when rescaling, then byte(clamp(255 r, 0, 255)).
@@ -793,6 +850,34 @@ int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* st
   AGL_REQUIRE(boxes && masks && O > 0 && R > 0, "agl_rasterize_boxes: bad argument");
   LAUNCH1D(rasterize_boxes_k, (long)O * R * R, boxes, masks, O, R);
   AGL_CHECK_LAUNCH("agl_rasterize_boxes");
+  return AGL_OK;
+}
+
+int agl_layout_from_boxes(const float* boxes, float* boxes_shift, float* masks, float* masks_shift, int O, int R, void* stream) {
+  AGL_REQUIRE(boxes && boxes_shift && masks && masks_shift && O > 0 && R > 0, "agl_layout_from_boxes: bad argument");
+  LAUNCH1D(layout_from_boxes_k, (long)O * R * R, boxes, boxes_shift, masks, masks_shift, O, R);
+  AGL_CHECK_LAUNCH("agl_layout_from_boxes");
+  return AGL_OK;
+}
+
+int agl_attr_edit(float* attribute, const int* cols_dev, int ncols, int tgt, int O, int A, void* stream) {
+  AGL_REQUIRE(attribute && (cols_dev || ncols == 0) && O > 0 && A > 0 && tgt >= 0 && tgt < A && ncols >= 0, "agl_attr_edit: bad argument");
+  LAUNCH1D(attr_edit_k, (long)O, attribute, cols_dev, ncols, tgt, O, A);
+  AGL_CHECK_LAUNCH("agl_attr_edit");
+  return AGL_OK;
+}
+
+int agl_topk_contains(const float* logits, unsigned char* out, int O, int A, int k, int tgt, void* stream) {
+  AGL_REQUIRE(logits && out && O > 0 && A > 0 && k > 0 && tgt >= 0 && tgt < A, "agl_topk_contains: bad argument");
+  LAUNCH1D(topk_contains_k, (long)O, logits, out, O, A, k, tgt);
+  AGL_CHECK_LAUNCH("agl_topk_contains");
+  return AGL_OK;
+}
+
+int agl_sigmoid_threshold(const float* logits, unsigned char* pred, long n, float thr, void* stream) {
+  AGL_REQUIRE(logits && pred && n > 0, "agl_sigmoid_threshold: bad argument");
+  LAUNCH1D(sigmoid_threshold_k, n, logits, pred, n, thr);
+  AGL_CHECK_LAUNCH("agl_sigmoid_threshold");
   return AGL_OK;
 }
 

@@ -206,6 +206,14 @@ int agl_hinge_loss(const float* x, long n, int mode, float coef, float* loss_out
 /* N3: object masks from boxes on device (data/vg_custom_mask.py:136,158: python round(), slice semantics) */
 int agl_rasterize_boxes(const float* boxes, float* masks, int O, int R, void* stream);
 int agl_attr_estimate(const float* logits, const float* attribute, float* attribute_est, int O, int A, void* stream);
+/* N3: everything the VG batch builder derives from the boxes (data/vg_custom_mask.py:136-158): masks, the shifted boxes
+ * (0.8 x the larger horizontal border distance when the box is narrower than half the image) and their masks. */
+int agl_layout_from_boxes(const float* boxes, float* boxes_shift, float* masks, float* masks_shift, int O, int R, void* stream);
+/* N2: the attribute logic of the inference / attribute-editing loop (test64.py:143-184): clear a set of columns and set one
+ * (cols_dev: device int array); membership of a column in a row's top-k logits; sigmoid(logit) > threshold. */
+int agl_attr_edit(float* attribute, const int* cols_dev, int ncols, int tgt, int O, int A, void* stream);
+int agl_topk_contains(const float* logits, unsigned char* out, int O, int A, int k, int tgt, void* stream);
+int agl_sigmoid_threshold(const float* logits, unsigned char* pred, long n, float thr, void* stream);
 /* N2: data/utils.py:47-66 imagenet_deprocess_batch — de-normalise, per-image min/max rescale, bytes. inv_std/mean are
  * HOST pointers to 3 floats (fp32(1/std_c), fp32(mean_c)). */
 int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, int rescale, const float* inv_std, const float* mean,

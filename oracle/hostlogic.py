@@ -67,3 +67,46 @@ def imagenet_deprocess_batch(imgs, rescale=True):
             x = x.sub(lo).div(hi - lo)
         out.append(x[None].mul(255).clamp(0, 255).byte())
     return torch.cat(out, dim=0)
+
+
+# ---- N3: per-object layout tensors from boxes (data/vg_custom_mask.py:136-158), python floats and python round like the reference
+def layout_from_boxes(boxes, R):
+    O = boxes.shape[0]
+    masks = torch.zeros(O, 1, R, R)
+    masks_shift = torch.zeros(O, 1, R, R)
+    boxes_shift = torch.FloatTensor([[0, 0, 1, 1]]).repeat(O, 1)
+    for i in range(O):
+        x0, y0, x1, y1 = (float(v) for v in boxes[i])
+        masks[i, :, round(y0 * R):round(y1 * R), round(x0 * R):round(x1 * R)] = 1          # :136
+        width = x1 - x0
+        x0_shift, x1_shift = x0, x1
+        if width < 0.5:                                                                    # :144
+            border_dist_left = x0
+            border_dist_right = 1 - x1
+            if border_dist_left > border_dist_right:
+                shift = border_dist_left * 0.8
+                x0_shift, x1_shift = x0 - shift, x1 - shift
+            elif border_dist_right > border_dist_left:
+                shift = border_dist_right * 0.8
+                x0_shift, x1_shift = x0 + shift, x1 + shift
+        masks_shift[i, :, round(y0 * R):round(y1 * R), round(x0_shift * R):round(x1_shift * R)] = 1   # :157
+        boxes_shift[i] = torch.FloatTensor([x0_shift, y0, x1_shift, y1])                              # :158
+    return boxes_shift, masks, masks_shift
+
+
+# ---- N2: the attribute logic of the inference loop (test64.py:143-150, 160-167, 179-184) on CPU tensors
+def edit_attribute_rows(attribute, attribute_est, tgt, remove=(2, 8, 0, 94, 90, 95, 96, 34, 25, 70, 58, 104)):
+    attribute, attribute_est = attribute.clone(), attribute_est.clone()
+    for idx in range(attribute.shape[0]):
+        attribute[idx, list(remove)] = 0
+        attribute[idx, tgt] = 1
+        attribute_est[idx, list(remove)] = 0
+        attribute_est[idx, tgt] = 1
+    return attribute, attribute_est
+
+
+def edit_success(logits_rand, logits_rand_edit, tgt):
+    max_idx = logits_rand.topk(5)[1]
+    changed = [i for i in range(logits_rand.shape[0]) if tgt not in max_idx[i]]
+    max_idx_y = logits_rand_edit.topk(3)[1]
+    return changed, [i for i in changed if tgt in max_idx_y[i]]

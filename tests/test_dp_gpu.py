@@ -59,6 +59,15 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tr, b, eps = _make(seed_offset=rank)
     assert tr.sync.enabled and tr.sync.world == 2
+    # with data parallelism step() returns while the G all-reduce + Adam still run on the side stream; a state_dict()
+    # taken right after step() (what checkpoint.save_model does) must already hold the post-update weights
+    tr.step(b, eps[:3], eps[3:])
+    sd = {k: v.detach().clone() for k, v in tr.netG.state_dict().items()}          # no finish(), no synchronize()
+    tr.finish()
+    torch.cuda.synchronize()
+    for k, v in tr.netG.state_dict().items():
+        assert torch.equal(sd[k], v), ("state_dict taken right after step() is stale", k)
+    tr, b, eps = _make(seed_offset=rank)
     losses, pg, pd = _run(tr, b, eps)
     same = []
     for t in (pg, pd):                         # replicas must hold bit-identical weights

@@ -150,3 +150,32 @@ def test_spade_block_class_index_maps():
             assert mm == sorted(mm) and lo[0] == 0 and lo[-1] == len(mm)
             for i in range(len(lo) - 1):
                 assert all(mm[j] == i for j in range(int(lo[i]), int(lo[i + 1])))
+
+
+def test_oracle_layout_from_boxes_agrees_with_batch_builder_and_hand_cases():
+    """oracle/hostlogic.py::layout_from_boxes (data/vg_custom_mask.py:136-158 restated) against hand-computed cases and against the
+    independent restatement inside the synthetic batch builder (agl/synth.py)."""
+    import oracle.hostlogic as OH
+    from agl import synth
+    boxes = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.25, 0.1, 0.75, 0.9], [0.5, 0.25, 0.75, 0.5], [0.1, 0.0, 0.3, 0.5]])
+    bs, m, ms = OH.layout_from_boxes(boxes, 8)
+    assert torch.equal(bs[0], boxes[0]) and torch.equal(bs[1], boxes[1])            # wide / equal border distances: no shift
+    assert torch.allclose(bs[2], torch.tensor([0.1, 0.25, 0.35, 0.5]))              # left 0.5 > right 0.25: shift left by 0.4
+    assert torch.allclose(bs[3], torch.tensor([0.66, 0.0, 0.86, 0.5]))              # right 0.7 > left 0.1: shift right by 0.56
+    assert m[2, 0].sum() == 2 * 2 and m[2, 0, 2:4, 4:6].all()                       # rows round(2)..round(4), cols 4..6
+    assert ms[2, 0, 2:4, 1:3].all() and ms[2, 0].sum() == 4                         # cols round(0.8)=1 .. round(2.8)=3
+    b = synth.make_batch(5, 64, seed=4)
+    bs, m, ms = OH.layout_from_boxes(torch.from_numpy(b["boxes"]), 64)
+    assert np.array_equal(bs.numpy(), b["boxes_shift"]) and np.array_equal(m.numpy(), b["masks"]) and np.array_equal(ms.numpy(), b["masks_shift"])
+
+
+def test_oracle_attribute_edit_logic():
+    import oracle.hostlogic as OH
+    a = torch.zeros(3, 106); a[0, 2] = 1; a[1, 50] = 1; a[2, 95] = 1
+    e = a.clone(); e[1, 8] = 1
+    a2, e2 = OH.edit_attribute_rows(a, e, 95)
+    assert a2[:, 95].all() and a2[0, 2] == 0 and a2[1, 50] == 1 and e2[1, 8] == 0 and e2[1, 50] == 1
+    lg = torch.zeros(2, 106); lg[0, :5] = torch.tensor([5., 4., 3., 2., 1.]); lg[1, 95] = 9.
+    lg2 = torch.zeros(2, 106); lg2[0, 95] = 7.
+    changed, success = OH.edit_success(lg, lg2, 95)
+    assert changed == [0] and success == [0]

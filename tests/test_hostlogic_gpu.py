@@ -117,3 +117,86 @@ def test_checkpoint_roundtrip_resumes_training(tmp_path):
                 assert float((a - r).abs().max()) <= 4.1e-4 + 1e-5 * float(r.abs().max()), k
             else:
                 assert torch.equal(v.cpu(), w[k]), k
+
+
+def test_layout_tensors_from_boxes_on_device():
+    """masks, shifted boxes and shifted masks built in HBM from the boxes alone (agl_layout_from_boxes) equal the
+    restatement of data/vg_custom_mask.py:136-158 in oracle/hostlogic.py (python floats, python round, slice clipping) bit for bit,
+    including boxes wider than half the image (no shift), equal border distances (no shift), boxes touching the borders and
+    shifted boxes that leave the image."""
+    import oracle.hostlogic as OH
+    from agl import lib as L
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.rand(200, generator=g) * 0.7
+    y0 = torch.rand(200, generator=g) * 0.7
+    boxes = torch.stack([x0, y0, (x0 + 0.05 + torch.rand(200, generator=g) * 0.6).clamp(max=1.0),
+                         (y0 + 0.05 + torch.rand(200, generator=g) * 0.5).clamp(max=1.0)], 1)
+    boxes[:6] = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.25, 0.1, 0.75, 0.9], [0.3, 0.2, 0.7, 0.4], [0.0, 0.5, 0.2, 1.0],
+                              [0.8, 0.0, 1.0, 0.3], [0.05, 0.05, 0.15, 0.15]])
+    for R in (64, 128):
+        bs_ref, m_ref, ms_ref = OH.layout_from_boxes(boxes, R)
+        bs, m, ms = L.layout_from_boxes(boxes.to(DEV), R)
+        assert torch.equal(bs.cpu(), bs_ref)
+        assert torch.equal(m.cpu(), m_ref)
+        assert torch.equal(ms.cpu(), ms_ref)
+
+
+def test_attribute_editing_loop_vs_oracle():
+    """one iteration of the attribute-editing inference loop (test64.py:114-198) on the eval-mode kernels against
+    the oracle graph + the loop's attribute logic restated in oracle/hostlogic.py: attribute estimate and edited attribute
+    rows exactly, generated images within 1e-3 relative-to-max, classifier predictions / top-k success lists equal wherever the
+    oracle's decision margin exceeds the numerical tolerance."""
+    import oracle.graph as OG, oracle.step as OS, oracle.hostlogic as OH
+    from oracle.fill import fill_state
+    from agl import synth
+    from agl.infer import edit_attributes_batch
+    from models.generator_obj_att import Generator
+    from models.discriminator import AttributeDiscriminator, add_sn
+    G = Generator(num_embeddings=179, obj_att_dim=64, z_dim=64, clstm_layers=3, obj_size=32, attribute_dim=106)
+    Da = add_sn(AttributeDiscriminator(n_attribute=106))
+    for m in (G, Da):
+        m.load_state_dict(fill_state(m.state_dict()))
+    Pg = OS.as_params({k: v.clone() for k, v in G.state_dict().items()})
+    Pa = OS.as_params({k: v.clone() for k, v in Da.state_dict().items()})
+    G.to(DEV), Da.to(DEV)
+    bn = synth.make_batch(3, 64, seed=23, objs_per_image=[4, 3, 5])
+    b = {k: torch.from_numpy(v) for k, v in bn.items()}
+    O = b["objs"].shape[0]
+    gen = torch.Generator().manual_seed(2)
+    z, z2 = torch.randn(O, 64, generator=gen), torch.randn(O, 64, generator=gen)
+    eps = [torch.randn(O, 64, generator=gen) for _ in range(6)]
+    d = {k: (v.to(DEV) if k != "obj_to_img" else v) for k, v in b.items()}
+    d["attribute"] = d["attribute_gt"].clone()
+    res = edit_attributes_batch(G, Da, d, tgt=95, z=z, z_edit=z2, eps=eps[:3], eps_edit=eps[3:])
+    torch.cuda.synchronize()
+    # ---- oracle
+    with torch.no_grad():
+        attr = b["attribute_gt"]
+        crops = OG.crop_boxes(b["imgs"], b["boxes"], b["obj_to_img"], 32)
+        est = OH.estimate_attributes(OG.attribute_discriminator(Pa, crops, False, False), attr)
+        gen_o = lambda a, ae, zz, ee: OG.generator(Pg, b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], zz, a,
+                                                  b["masks_shift"], b["boxes_shift"], ae, obj_size=32, res128=False, train=False, eps=ee)
+        out = gen_o(attr, est, z, eps[:3])
+        lg = OG.attribute_discriminator(Pa, out[2], False, False)
+        a2, e2 = OH.edit_attribute_rows(attr, est, 95)
+        out2 = gen_o(a2, e2, z2, eps[3:])
+        lg2 = OG.attribute_discriminator(Pa, out2[2], False, False)
+        changed, success = OH.edit_success(lg, lg2, 95)
+    assert torch.equal(res["attribute_est"].cpu(), est)
+    assert torch.equal(res["attribute_edit"].cpu(), a2) and torch.equal(res["attribute_est_edit"].cpu(), e2)
+    scale = float(out[5].abs().max())
+    assert float((res["img_rand"].cpu() - out[5]).abs().max()) <= 1e-3 * scale
+    assert float((res["img_rand_edit"].cpu() - out2[5]).abs().max()) <= 1e-3 * float(out2[5].abs().max())
+    # decisions: compare where the oracle's margin is clear of the logits' numerical tolerance
+    tol = 2e-3 * float(lg.abs().max())
+    sig = torch.sigmoid(lg)
+    clear = (lg - float(torch.logit(torch.tensor(0.9)))).abs() > tol
+    assert torch.equal(res["pred"].cpu().bool()[clear], (sig > 0.9)[clear])
+    ch = res["changed"].cpu().bool()
+    for i in range(O):
+        kth5 = lg[i].topk(6)[0]
+        margin5 = min(abs(float(lg[i, 95] - kth5[4])), abs(float(lg[i, 95] - kth5[5])))
+        if margin5 > tol:
+            assert bool(ch[i]) == (i in changed), i
+    img_ref = OH.imagenet_deprocess_batch(out[5])
+    assert int((res["images"]["rand"].cpu().int() - img_ref.int()).abs().max()) <= 1
