@@ -842,26 +842,14 @@ __global__ __launch_bounds__(NT, (BM * BN > 128 * 128) ? 2 : 4) void igemm_f32(P
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int mb = bm0 + wm * 32 * WTM + 32 * i + 4 * lh;
-      long o[16];
-      bool ok[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        ok[r] = p.out_ok(m, c);
-        o[r] = p.out_off(m, c);
+      for (int r = 0; r < 16; ++r) {      // (fetching the epilogue operands of a whole tile first was tried: it pushes these
+        const int m = mb + (r & 3) + 8 * (r >> 2);   //  128-VGPR kernels into spills and measured 2 % slower at step level)
+        if (p.out_ok(m, c)) {
+          const long o = p.out_off(m, c);
+          p.finish(m, o, acc[i][j][r], p.reads_old() ? p.old_at(o) : 0.f, p.reads_mask() ? p.mask_at(o) : 1.f);
+        }
       }
-      float old[16], mk[16];
-      if (p.reads_old()) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = ok[r] ? p.old_at(o[r]) : 0.f;
-      }
-      if (p.reads_mask()) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = ok[r] ? p.mask_at(o[r]) : 1.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (ok[r]) p.finish(mb + (r & 3) + 8 * (r >> 2), o[r], acc[i][j][r], old[r], mk[r]);
     }
   }
 }
