@@ -132,7 +132,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight",
 
 # Convolution flags passed with every agl_conv2d_* call (include/agl.h AGL_CONV_*).  This is host-side state of the
 # Python binding only — the C ABI has no process-wide switches.
-CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3 = 1, 2, 4, 8, 16, 32
+CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_FLAGS = 0
 
 

@@ -923,6 +923,7 @@ struct ConvOpts {
   bool pos;          // position-major path on small maps allowed
   bool pos_all_ks;   // experiments: position-major also for 3x3 / 4x4 kernels
   bool split3;       // fp32 operands as three bf16 terms, six bf16-MFMA products (pconv.hip) where that kernel applies
+  bool any_grid;     // matrix-core kernels also below their occupancy threshold (unit tests)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -933,9 +934,10 @@ static ConvOpts conv_opts(int flags) {
   o.pos = !(flags & 8);
   o.pos_all_ks = (flags & 16) != 0;
   o.split3 = (flags & 32) != 0 && o.prec == 0;
+  o.any_grid = (flags & 64) != 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1457,7 +1459,7 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     PConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
-    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3;
+    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
     if (prc >= 0) return prc;
   }
@@ -1556,7 +1558,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     PConvArgs a;    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
-    a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3;
+    a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
     if (prc >= 0) return prc;
   }
@@ -1580,7 +1582,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     PConvArgs a{};
     a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
-    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3;
+    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases)");
     if (prc >= 0) return prc;
   }
@@ -1843,7 +1845,7 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
   if (co.patch && (co.prec == 1 || co.split3)) {
     PConvArgs a{};
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
-    a.nsplit = co.prec == 1 ? 1 : 3;
+    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     mc = pconv_eligible(a);
   }
   if (!small && !mc && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
@@ -1857,7 +1859,7 @@ double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int O
   if (co.patch && (co.prec == 1 || co.split3) && stride == 1 && IH == OH && IW == OW) {
     PConvArgs a{};
     a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0;
-    a.nsplit = co.prec == 1 ? 1 : 3;
+    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     mc = pconv_eligible(a);
   }
   if (!small && !mc && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))

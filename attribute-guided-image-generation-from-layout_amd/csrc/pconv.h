@@ -8,6 +8,7 @@ struct PConvArgs {
   int ks, stride, pad, up, in_relu, relu, accumulate;
   int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
   int nsplit;                       // 1: bf16 operands (AGL_CONV_BF16); 3: fp32 operands as three bf16 terms, six products
+  int any_grid;                     // launch also below the occupancy threshold (AGL_CONV_ANY_GRID)
 };
 
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.

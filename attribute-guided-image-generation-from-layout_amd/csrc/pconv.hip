@@ -91,6 +91,7 @@ template <int KS> struct Pitch<8, KS, 1> { static constexpr int PWP = 24; static
 template <int KS> struct Pitch<8, KS, 3> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
 template <int NSPL> struct Pitch<4, 3, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
 template <int NSPL> struct Pitch<4, 2, NSPL> { static constexpr int PWP = 8; static constexpr int IMG_EXTRA = 4; };
+template <int NSPL> struct Pitch<4, 1, NSPL> { static constexpr int PWP = 4; static constexpr int IMG_EXTRA = 0; };   // 1x1: pixels are consecutive pieces
 template <> struct Pitch<2, 2, 1> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 2; };
 template <> struct Pitch<2, 2, 3> { static constexpr int PWP = 3; static constexpr int IMG_EXTRA = 0; };   // 2-way, fits two workgroups
 
@@ -113,7 +114,7 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // PHS: the four stride phases of a 4x4 / stride-2 / pad-1 input gradient (= ConvTranspose2d(4,2,1) forward).  Output phase
 // (ph,pw) = blockIdx.z is a 2x2-tap stride-1 correlation of dy with pads (1-ph, 1-pw) and its own quarter of the packed weights;
 // its pixels (a,b) land at (2a+ph, 2b+pw) of the twice-as-large output map.
-template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false>
+template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false>
 __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   static_assert(!PHS || (KS == 2 && S == 1 && TG == 4), "phase mode");
   constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = PHS ? 1 : KK / TG, KKW = PHS ? 16 : KK;
@@ -132,10 +133,18 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   constexpr int WTM = BM / 64, WTN = BN / 64;   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/2 pixels)
   constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
   constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
-  constexpr int STAGE_PIECES = NSPL * (P_PLANE + A_PLANE), EP_PIECES = 4 * 32 * EP_PITCH / 4;   // 16-byte pieces
+  // DB: double buffering (where it does not cost a workgroup per CU).  With a second weight buffer the stores of stage s+1 need
+  // no barrier of their own (one barrier per stage); a second patch buffer does the same for the once-per-chunk patch stores.
+  // Measured per geometry (tools/conv_bench.py): -16..18 % on the 4x4-map 3x3 layers and -2..3 % on the 5x5 ConvLSTM layers in
+  // split mode; +3..8 % (slower) on the larger 3x3 tiles, where it forces one kernel row per weight stage, and on the phase
+  // kernels — so it is a per-instantiation choice of the dispatch, not a default.
+  constexpr int PB = NSPL * P_PLANE, AB = NSPL * A_PLANE;          // 16-byte pieces per patch / weight buffer
+  constexpr int LDS_CAP = (PB + AB <= 5120) ? 5120 : 10240;       // keep two workgroups per CU (80 KB each) when one buffer pair fits that
+  constexpr bool DBA = DB && PB + 2 * AB <= LDS_CAP, DBB = DBA && 2 * PB + 2 * AB <= LDS_CAP;
+  constexpr int STAGE_PIECES = (DBB ? 2 : 1) * PB + (DBA ? 2 : 1) * AB, EP_PIECES = 4 * 32 * EP_PITCH / 4;   // 16-byte pieces
   __shared__ u32x4 lds[STAGE_PIECES > EP_PIECES ? STAGE_PIECES : EP_PIECES];
   u32x4* const Pl = lds;
-  u32x4* const Al = lds + NSPL * P_PLANE;
+  u32x4* const Al = lds + (DBB ? 2 : 1) * PB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -193,7 +202,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
   };
-  auto sstore_b = [&]() {
+  auto sstore_b = [&](int buf) {
+    u32x4* const Pl = lds + buf;
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       if (bdst[r] < 0) continue;
@@ -211,11 +221,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
       }
     }
   };
-  auto sstore_a = [&]() {
+  auto sstore_a = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       const int e = tid + NT * r;
-      if (NA % NT == 0 || e < NA) Al[e] = pa[r];
+      if (NA % NT == 0 || e < NA) Al[buf + e] = pa[r];
     }
   };
 
@@ -242,15 +252,19 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   const int nstage = p.nch * NTG;      // stage s = (channel chunk s / NTG, tap group s % NTG)
   gload_b(0);
   gload_a(0, PHS ? phase : 0);
-  sstore_b();
-  sstore_a();
+  sstore_b(0);
+  sstore_a(0);
   __syncthreads();
   for (int s = 0; s < nstage; ++s) {
     const int cc = s / NTG, tg = PHS ? phase : s - cc * NTG;
     const int s1 = min(s + 1, nstage - 1), cc1 = s1 / NTG, tg1 = PHS ? phase : s1 - cc1 * NTG;   // past the end: reload the last stage (unused)
-    const bool new_patch = (NTG == 1) || (s + 1) % NTG == 0;
-    if (new_patch) gload_b(16 * cc1);
+    const bool first_tg = (NTG == 1) || s == cc * NTG, last_tg = (NTG == 1) || (s + 1) % NTG == 0;
+    // the next chunk's patch: fetched at the chunk's first tap group when it has its own LDS buffer (the stores wait for the
+    // loads only NTG stages later), else at the last one (the registers are live for one stage only)
+    if (DBB ? first_tg : last_tg) gload_b(16 * min(cc + 1, p.nch - 1));
     gload_a(cc1, tg1);
+    const u32x4* const Pc = Pl + (DBB ? (cc & 1) * PB : 0);
+    const u32x4* const Ac = Al + (DBA ? (s & 1) * AB : 0);
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       int toff;                                  // LDS piece offset of tap (kh, kw)
@@ -261,9 +275,9 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
       for (int pl = 0; pl < NSPL; ++pl) {
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[pl][i] = __builtin_bit_cast(bf16x8, Al[pl * A_PLANE + arow + t * BM + 32 * i]);
+        for (int i = 0; i < WTM; ++i) fa[pl][i] = __builtin_bit_cast(bf16x8, Ac[pl * A_PLANE + arow + t * BM + 32 * i]);
 #pragma unroll
-        for (int jt = 0; jt < WTN; ++jt) fb[pl][jt] = __builtin_bit_cast(bf16x8, Pl[pl * P_PLANE + qlane[jt] + toff]);
+        for (int jt = 0; jt < WTN; ++jt) fb[pl][jt] = __builtin_bit_cast(bf16x8, Pc[pl * P_PLANE + qlane[jt] + toff]);
       }
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -280,9 +294,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           }
         }
     }
-    __syncthreads();
-    if (new_patch) sstore_b();
-    sstore_a();
+    // a buffer that is about to be overwritten may still be read by a slower wave unless it is the other one of a pair
+    if constexpr (!DBA) __syncthreads();
+    else if constexpr (!DBB) { if (last_tg) __syncthreads(); }
+    if (last_tg) sstore_b(DBB ? ((cc + 1) & 1) * PB : 0);
+    sstore_a(DBA ? ((s + 1) & 1) * AB : 0);
     __syncthreads();
   }
   if constexpr (NSPL == 3) {
@@ -601,42 +617,54 @@ __global__ void slab_sum_k(const float* __restrict__ slabs, float* __restrict__ 
 }  // namespace
 
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
-  if (!(ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
+  if (!(ks == 1 || ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
   return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
 }
 
-struct PConvPlan { int geo, bm; bool s2, w32, wide, half; long ptiles; };
+struct PConvPlan { int geo, bm; bool s2, w32, wide, half; long ptiles; int oh, ow; };
 // Pure eligibility / tiling decision (no launches): 0 when pconv takes the call.
 static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   const bool s2 = a.stride == 2;
-  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
+  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0
+         : !(a.stride == 1 && (a.ks == 3 || a.ks == 5 || (a.ks == 1 && a.pad == 0 && a.up == 0)))) return -1;
   if (a.Cin % 16 != 0 || a.Cout < 48) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
-  int geo;
-  if (a.OW % 16 == 0 && a.OH % 8 == 0) geo = 0;
-  else if (a.OW == 8 && a.OH == 8) geo = 1;
-  else if (a.OW == 4 && a.OH == 4 && (a.ks == 3 || a.ks == 4)) geo = 2;
-  else if (!s2 && a.OW % 8 == 0 && a.OH % 8 == 0) geo = 3;      // 8 x 8 tiles of one image (64 pixels)
-  else return -1;
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
+  // a 1x1 convolution has no spatial structure: its map is re-read as (HW/16) x 16 so that any HW % 128 == 0 tiles as geo 0
+  int oh = a.OH, ow = a.OW;
+  if (a.ks == 1) {
+    const int hw = a.OH * a.OW;
+    if (hw % 128 == 0) { ow = 16; oh = hw / 16; }
+    else if (hw == 64) { ow = 8; oh = 8; }
+    else if (hw == 16) { ow = 4; oh = 4; }
+    else return -1;
+  }
+  int geo;
+  if (ow % 16 == 0 && oh % 8 == 0) geo = 0;
+  else if (ow == 8 && oh == 8) geo = 1;
+  else if (ow == 4 && oh == 4 && (a.ks == 3 || a.ks == 4 || a.ks == 1)) geo = 2;
+  else if (!s2 && ow % 8 == 0 && oh % 8 == 0) geo = 3;      // 8 x 8 tiles of one image (64 pixels)
+  else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
   // nsplit 1: 128 channels (64 when Cout <= 64) x 256 pixels per workgroup, 128 pixels when the wider tile would leave CUs
   // without work; nsplit 3: 64 x 128 (three LDS planes).  Stride 2 (patch = 4x the tile): 128 pixels, 64 in split mode.
-  const int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
-  const long px128 = geo == 0 ? (long)a.N * (a.OH / 8) * (a.OW / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
-  const bool w32 = a.OW % 32 == 0;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
-  bool wide = !s2 && geo != 3 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
-  if (geo == 0 && wide && !w32 && a.OH % 16 != 0) wide = false;
+  const long px128 = geo == 0 ? (long)a.N * (oh / 8) * (ow / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
+  // 1x1: bandwidth-bound — read the input once per 128 output channels where that still leaves a workgroup per CU
+  if (a.ks == 1 && a.Cout > 64 && px128 * agl_cdiv(a.Cout, 128) >= 256) bm = 128;
+  const bool w32 = ow % 32 == 0 && a.ks != 1;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
+  bool wide = !s2 && geo != 3 && a.ks != 1 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  if (geo == 0 && wide && !w32 && oh % 16 != 0) wide = false;
   const bool half = s2 && a.nsplit == 3;           // 64-pixel tiles
   long ptiles;
   if (geo == 0) ptiles = half ? px128 * 2 : px128 / (wide ? 2 : 1);
   else if (geo == 1) ptiles = half ? a.N : agl_cdiv(a.N, wide ? 4 : 2);
   else if (geo == 2) ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
-  else ptiles = (long)a.N * (a.OH / 8) * (a.OW / 8);
+  else ptiles = (long)a.N * (oh / 8) * (ow / 8);
   // no reduction split in this kernel: a grid that cannot occupy most CUs runs one long serial K loop per workgroup and is
   // slower than the split-K im2col / position-major kernels (ConvLSTM recurrence steps over the few images still active)
-  if (ptiles * agl_cdiv(a.Cout, bm) < 200) return -1;
-  pl.geo = geo; pl.bm = bm; pl.s2 = s2; pl.w32 = w32; pl.wide = wide; pl.half = half; pl.ptiles = ptiles;
+  if (ptiles * agl_cdiv(a.Cout, bm) < 200 && !a.any_grid) return -1;
+  pl.geo = geo; pl.bm = bm; pl.s2 = s2; pl.w32 = w32; pl.wide = wide; pl.half = half; pl.ptiles = ptiles; pl.oh = oh; pl.ow = ow;
   return 0;
 }
 
@@ -657,6 +685,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
+  if (a.ks == 1) { p.H = p.OH = pl.oh; p.W = p.OW = pl.ow; }      // the re-read map of a 1x1 convolution
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
   const long per_plane = (long)nch * 2 * KK * mpad;
@@ -665,6 +694,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   AGL_CHECK_LAUNCH(name);
 #define PC_LAUNCH(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
+#define PC_LAUNCH_DB(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
+  hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, true>), g, dim3(NT), 0, st, p)
 #define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
   do {                                                                                                   \
     if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, BM_, 1, TG_);                                               \
@@ -697,23 +728,37 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       else PC_LAUNCH(KS_, 2, 4, 4, 8, 64, 1, TG_);                                                       \
     }                                                                                                    \
   } while (0)
+#define PC_1X1(BM_, NS_)                                                                                 \
+  do {                                                                                                   \
+    if (geo == 0) PC_LAUNCH(1, 1, 16, 8, 1, BM_, NS_, 1);                                                \
+    else if (geo == 1) PC_LAUNCH(1, 1, 8, 8, 2, BM_, NS_, 1);                                            \
+    else PC_LAUNCH(1, 1, 4, 4, 8, BM_, NS_, 1);                                                          \
+  } while (0)
   if (s2) {
     if (a.ks == 4) PC_STRIDE2(4, 4); else PC_STRIDE2(3, 3);
+  } else if (a.ks == 1) {
+    if (a.nsplit == 3) { if (bm == 128) PC_1X1(128, 3); else PC_1X1(64, 3); }
+    else { if (bm == 128) PC_1X1(128, 1); else PC_1X1(64, 1); }
   } else if (a.ks == 3) {
     if (geo == 2) {
-      if (a.nsplit == 3) PC_LAUNCH(3, 1, 4, 4, 8, 64, 3, 9);
+      if (a.nsplit == 3) PC_LAUNCH_DB(3, 1, 4, 4, 8, 64, 3, 3);    // one kernel row per stage, two weight + two patch buffers
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
     } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
     else PC_SHAPES3(3, 9);
   } else {
     if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
-    else PC_SHAPES3(5, 5);
+    else if (geo == 3) PC_LAUNCH_DB(5, 1, 8, 8, 1, 64, 3, 5);
+    else if (geo == 0 && w32) PC_LAUNCH_DB(5, 1, 32, 4, 1, 64, 3, 5);
+    else if (geo == 0) PC_LAUNCH_DB(5, 1, 16, 8, 1, 64, 3, 5);
+    else if (geo == 1) PC_LAUNCH_DB(5, 1, 8, 8, 2, 64, 3, 5);
   }
 #undef PC_STRIDE2
+#undef PC_1X1
 #undef PC_SHAPES1
 #undef PC_SHAPES3
 #undef PC_LAUNCH
+#undef PC_LAUNCH_DB
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
@@ -733,7 +778,7 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles) {
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;
   *bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : (*geo == 2 ? agl_cdiv(a.N, 8) : agl_cdiv(a.N, 32)));
-  if (*ptiles * agl_cdiv(a.Cout, *bm) * 4 < 200) return -1;
+  if (*ptiles * agl_cdiv(a.Cout, *bm) * 4 < 200 && !a.any_grid) return -1;
   return 0;
 }
 bool pconvT_eligible(const PConvArgs& a) { int g, b; long t; return pconvT_plan(a, &g, &b, &t) == 0; }

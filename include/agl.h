@@ -41,13 +41,18 @@ const char* agl_last_error(void);
  *   AGL_CONV_SPLIT3      fp32 tensors, fp32-accurate products on the bf16 matrix cores: every operand is carried as three
  *                        bf16 terms (a = a1+a2+a3 to 2^-27) and six of the nine partial products are accumulated in fp32
  *                        (the dropped ones are <= 2^-27 |ab|); used by the LDS-patch kernel of csrc/pconv.hip where it
- *                        applies (stride-1 3x3 / 5x5 on power-of-two maps), exact fp32 MFMA elsewhere               */
+ *                        applies (1x1 / 3x3 / 5x5 stride 1, 4x4 / 3x3 stride 2 and their gradients on 4/8/16n-wide
+ *                        maps), exact fp32 MFMA elsewhere
+ *   AGL_CONV_ANY_GRID    take the matrix-core kernels of csrc/pconv.hip also for grids below their occupancy threshold
+ *                        (by default a launch of < 200 workgroups falls back to the split-K fp32 kernels, which are
+ *                        faster there); lets unit tests exercise those kernels on small tensors                       */
 #define AGL_CONV_BF16 1
 #define AGL_CONV_NO_PATCH 2
 #define AGL_CONV_NO_PATCH_S2 4
 #define AGL_CONV_NO_POS 8
 #define AGL_CONV_POS_ALL_KS 16
 #define AGL_CONV_SPLIT3 32
+#define AGL_CONV_ANY_GRID 64
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);

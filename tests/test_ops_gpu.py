@@ -654,9 +654,10 @@ def test_modules_vs_reference_op_fixtures(golden_dir):
             close(m.resi[3].weight_v, t(f"dres_v3_after{k}"), 2e-5, f"SN v after {k} forwards")
 
 
-PCONV_CASES = [  # N, Cin, H, Cout, ks  (stride 1, "same" padding): the three tile geometries of csrc/pconv.hip, 3x3 and 5x5
+PCONV_CASES = [  # N, Cin, H, Cout, ks  (stride 1, "same" padding): the tile geometries of csrc/pconv.hip; 3x3, 5x5 and 1x1
     (4, 64, 32, 128, 3), (3, 32, 16, 64, 3), (2, 48, 64, 80, 3), (5, 64, 8, 128, 3), (7, 32, 8, 200, 3), (9, 64, 4, 128, 3),
-    (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5), (9, 64, 24, 128, 3), (7, 32, 40, 64, 3)]
+    (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5), (9, 64, 24, 128, 3), (7, 32, 40, 64, 3),
+    (3, 64, 32, 128, 1), (5, 32, 16, 64, 1), (7, 48, 8, 200, 1), (19, 64, 4, 256, 1), (2, 16, 24, 48, 1)]
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
@@ -673,10 +674,10 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
     x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
     if mode == "bf16":
         r = lambda t: t.to(torch.bfloat16).to(torch.float32)
-        flags, tol = L.CONV_BF16, 2e-5
+        flags, tol = L.CONV_BF16 | L.CONV_ANY_GRID, 2e-5
     else:
         r = lambda t: t
-        flags, tol = L.CONV_SPLIT3, 2e-5
+        flags, tol = L.CONV_SPLIT3 | L.CONV_ANY_GRID, 2e-5
     xr, wr = r(x), r(w)
     y_ref = TF.conv2d(torch.relu(xr) if mode == "split3" else r(torch.relu(x)), wr, b, padding=p)
     xd, wd, bd = dev(x), dev(w), dev(b)
@@ -720,7 +721,7 @@ def test_pconv_upsampled_input():
     """Nearest up-sampling folded into the patch staging (SPADE mlp_shared reads the 8x8 map up-sampled, normalization.py:100)."""
     from agl import lib as L
     x, w = rn(3, 64, 8, 8), rn(128, 64, 3, 3, seed=1) * 0.05
-    for flags, r in ((L.CONV_BF16, lambda t: t.to(torch.bfloat16).to(torch.float32)), (L.CONV_SPLIT3, lambda t: t)):
+    for flags, r in ((L.CONV_BF16 | L.CONV_ANY_GRID, lambda t: t.to(torch.bfloat16).to(torch.float32)), (L.CONV_SPLIT3 | L.CONV_ANY_GRID, lambda t: t)):
         for up in (1, 2):
             ref = TF.conv2d(TF.interpolate(r(x), scale_factor=2 ** up, mode="nearest"), r(w), None, padding=1)
             with L.conv_flags(flags):
@@ -740,7 +741,7 @@ def test_pconv_stride2_forward(case, mode):
     x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
     r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
     yr = TF.relu(TF.conv2d(r(TF.relu(x)), r(w), b, stride=2, padding=p))
-    with L.conv_flags(L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3):
+    with L.conv_flags((L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID):   # (small tensors: below the occupancy threshold)
         y = L.conv2d_fwd(dev(x), dev(w), dev(b), 2, p, in_relu=True, relu=True)
         gy = rn(*yr.shape, seed=7)
         dw = L.conv2d_bwd_weight(dev(gy), dev(x), ks, 2, p)
@@ -762,7 +763,7 @@ def test_pconv_stride2_input_gradient_phases(case, mode):
     r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
     ref = TF.conv_transpose2d(r(gy), r(w), None, stride=2, padding=1)
     mask, base = rn(N, Cin, 2 * OH, 2 * OH, seed=5), rn(N, Cin, 2 * OH, 2 * OH, seed=6)
-    with L.conv_flags(L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3):
+    with L.conv_flags((L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID):   # (small tensors: below the occupancy threshold)
         dx = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1)
         dx2 = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1, pos_mask=dev(mask), out=dev(base).clone(), accumulate=True)
     close(dx, ref, 5e-5 if mode == "bf16" else 2e-5, "stride-2 input gradient")

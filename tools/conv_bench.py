@@ -53,6 +53,11 @@ SHAPES = [
     ("Dobj.3b 256>512 k3 @8", O, 256, 8, 512, 3, 1, 1),
     ("Dobj.4a 512>512 k3 @4", O, 512, 4, 512, 3, 1, 1),
     ("Dobj.4b 512>1024 k3 @4", O, 512, 4, 1024, 3, 1, 1),
+    ("Dobj.1sc 64>128 k1 @16", O, 64, 16, 128, 1, 1, 0),
+    ("Dobj.2sc 128>256 k1 @8", O, 128, 8, 256, 1, 1, 0),
+    ("Dobj.3sc 256>512 k1 @4", O, 256, 4, 512, 1, 1, 0),
+    ("Dobj.4sc 512>1024 k1 @2", O, 512, 2, 1024, 1, 1, 0),
+    ("Dobj.0sc 3>64 k1 @32", O, 3, 32, 64, 1, 1, 0),
     ("128px SPADE5.gb 128>256 k3 @128", 32, 128, 128, 256, 3, 1, 1),
     ("128px DEC.c6 128>128 k5 @128", 32, 128, 128, 128, 5, 1, 2),
     ("128px Dobj.0b 64>64 k3 @64 (B=210)", 210, 64, 64, 64, 3, 1, 1),
