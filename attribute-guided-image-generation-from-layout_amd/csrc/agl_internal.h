@@ -30,6 +30,9 @@ void agl_set_error(const char* fmt, ...);
 
 static inline int agl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// out[i] (+)= sum over `splits` slabs of n floats (conv.hip); deterministic for a given slab count
+int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name);
+
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

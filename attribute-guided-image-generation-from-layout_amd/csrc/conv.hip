@@ -16,6 +16,7 @@
 // the staging writes and the 32-lane fragment reads stay (nearly) bank-conflict free.
 #include "agl_internal.h"
 #include "pconv.h"
+#include "few.h"
 #include <math.h>
 #include <algorithm>
 
@@ -862,6 +863,39 @@ __global__ void slab_reduce(const float* __restrict__ slabs, float* __restrict__
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// Many slabs of few elements (few.hip: 512 slabs of 64 x 27): one thread per element would walk all slabs serially on a handful
+// of workgroups.  Here a workgroup owns 16 consecutive elements and its 16 thread rows take every 16th slab each; the 16
+// partial sums are added in row order (deterministic for a given slab count).
+__global__ __launch_bounds__(256) void slab_reduce_wide(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits,
+                                                        int accumulate) {
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + o;
+  float s = 0.f;
+  if (i < n)
+    for (int z = zl; z < splits; z += 16) s += slabs[(long)z * n + i];
+  part[zl][o] = s;
+  __syncthreads();
+  if (zl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += part[r][o];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
+}  // namespace
+// out[i] (+)= sum over slabs, in slab order (row-interleaved order in the wide form): shared by the weight-gradient paths
+int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name) {
+  if (splits >= 8 && n < (1L << 18))
+    hipLaunchKernelGGL(slab_reduce_wide, dim3(agl_cdiv(n, 16)), dim3(256), 0, st, slabs, out, n, splits, accumulate);
+  else
+    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, accumulate);
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+namespace {
+
 // dw[co][ci][kh][kw] (+)= t[ci][co][ks-1-kh][ks-1-kw]
 __global__ void flip_transpose_w(const float* __restrict__ t, float* __restrict__ dw, int Cout, int Cin, int ks, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -969,67 +1003,118 @@ int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, 
 // than LDS-bound (one value per 3 FMAs with a pixel per thread: 9.6 TFLOP/s).  Filter taps are wave-uniform scalar
 // loads.  The weight tensor is addressed by strides so the same kernel evaluates the input-gradient form (flipped
 // taps, channel roles swapped).  Stride 1 only.
-template <int KS, int TXT>
+template <int KS, int TXT, int NO>
 __global__ __launch_bounds__(256) void small_cout_conv(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ pos_mask,
                                                        float* __restrict__ y, int Cin, int H, int W, int Cout, int OH, int OW,
                                                        int pad, int s_co, int s_ci, int flip, int relu, int accumulate) {
-  constexpr int PX = 4, TX = TXT * PX, TY = 256 / TXT, CB = 4;
+  // Two LDS buffers per operand and a register prefetch: the loads of chunk k+1 are in flight while chunk k is evaluated and are
+  // stored into the other buffer before the single barrier of the iteration (the grids of these layers are one or two
+  // workgroups per CU, so nothing else would cover the load latency).  NO = output channels actually evaluated (1..4).
+  // CB = 4 keeps two buffer pairs under 40 KB: the 393-workgroup grids of the object crops run as one wave of co-resident
+  // workgroups instead of two rounds (3x3: 101 -> 68 us)
+  constexpr int PX = 4, TX = TXT * PX, TY = 256 / TXT, CB = KS == 1 ? 8 : 4;
   constexpr int PH = TY + KS - 1, PWV = TX + KS - 1, PITCH = (PWV + 3) / 4 * 4, PS = PH * PITCH;
   constexpr int SEG = PX + KS - 1, SEGV = (SEG + 3) / 4;           // row segment a thread reads, in float4s
-  __shared__ __attribute__((aligned(16))) float patch[CB * PS + 4];
-  __shared__ __attribute__((aligned(16))) float wl[CB * KS * KS * 4];   // [c][tap][o padded to 4]: one 16-byte broadcast read per tap
+  constexpr int NE = CB * PH * PWV, ER = (NE + 255) / 256;         // patch elements per chunk, per thread
+  constexpr int NW = CB * KS * KS * 4, WR = (NW + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float patch[2][CB * PS + 4];      // (+4: dump slot of the table's padding entries)
+  __shared__ __attribute__((aligned(16))) float wl[2][NW];          // [c][tap][o padded to 4]: one 16-byte broadcast read per tap
   const int tiles_x = (OW + TX - 1) / TX;
   const int n = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * TY, tx0 = (blockIdx.x % tiles_x) * TX;
   const int tx = threadIdx.x % TXT, ty = threadIdx.x / TXT;
-  float acc[4][PX];
+  float acc[NO][PX];
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
+  for (int o = 0; o < NO; ++o)
 #pragma unroll
     for (int q = 0; q < PX; ++q) acc[o][q] = 0.f;
   const float* xn = x + (long)n * Cin * H * W;
-  for (int c0 = 0; c0 < Cin; c0 += CB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < CB * PH * PWV; e += 256) {
-      const int c = e / (PH * PWV), r = e - c * (PH * PWV), py = r / PWV, pxx = r - py * PWV;
-      const int iy = ty0 - pad + py, ix = tx0 - pad + pxx;
-      float v = 0.f;
-      if (c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[(long)(c0 + c) * H * W + (long)iy * W + ix];
-      patch[c * PS + py * PITCH + pxx] = v;
+  // per-thread element table of a chunk (the same for every chunk), one register per element: LDS slot in the upper 14 bits,
+  // source offset within the chunk (< 2^18: launch_small_cout checks CB*H*W) or all ones (zero padding) in the lower 18
+  unsigned etab[ER];
+#pragma unroll
+  for (int r = 0; r < ER; ++r) {
+    const int e = threadIdx.x + 256 * r;
+    const int c = e / (PH * PWV), rr = e - c * (PH * PWV), py = rr / PWV, pxx = rr - py * PWV;
+    const int iy = ty0 - pad + py, ix = tx0 - pad + pxx;
+    const bool in = e < NE;
+    const unsigned src = (in && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? (unsigned)((c * H + iy) * W + ix) : 0x3FFFFu;
+    etab[r] = ((unsigned)(in ? c * PS + py * PITCH + pxx : CB * PS) << 18) | src;     // slot CB*PS..: the 4 spare floats of the buffer
+  }
+  float pv[ER], pw[WR];
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < ER; ++r) {
+      const int c = (threadIdx.x + 256 * r) / (PH * PWV);
+      const unsigned src = etab[r] & 0x3FFFFu;
+      pv[r] = (src != 0x3FFFFu && c0 + c < Cin) ? xn[(long)c0 * H * W + src] : 0.f;
     }
-    for (int e = threadIdx.x; e < CB * KS * KS * 4; e += 256) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+      const int e = threadIdx.x + 256 * r;
       const int c = e / (KS * KS * 4), t = (e >> 2) % (KS * KS), o = e & 3;
       const int tap = flip ? KS * KS - 1 - t : t;
-      wl[e] = (c0 + c < Cin && o < Cout) ? w[(long)(c0 + c) * s_ci + (long)o * s_co + tap] : 0.f;
+      pw[r] = (e < NW && c0 + c < Cin && o < Cout) ? w[(long)(c0 + c) * s_ci + (long)o * s_co + tap] : 0.f;
     }
-    __syncthreads();
+  };
+  auto sstore = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < ER; ++r) patch[b][etab[r] >> 18] = pv[r];
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      if (threadIdx.x + 256 * r < NW) wl[b][threadIdx.x + 256 * r] = pw[r];
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int b = 0;
+  for (int c0 = 0; c0 < Cin; c0 += CB, b ^= 1) {
+    const bool more = c0 + CB < Cin;
+    if (more) gload(c0 + CB);
     const int cn = min(CB, Cin - c0);
-    for (int c = 0; c < cn; ++c) {
+    // one kernel row (segment + its KS filter taps) is fetched from LDS while the previous one is evaluated: with one or two
+    // waves per SIMD nothing else hides the LDS latency
+    float4 sg[2][SEGV], wq[2][KS];
+    auto lload = [&](int c, int kh, int s) {
+      const float4* row = reinterpret_cast<const float4*>(patch[b] + c * PS + (ty + kh) * PITCH + PX * tx);
 #pragma unroll
-      for (int kh = 0; kh < KS; ++kh) {
-        float seg[SEGV * 4];
-        const float4* row = reinterpret_cast<const float4*>(patch + c * PS + (ty + kh) * PITCH + PX * tx);
+      for (int v4 = 0; v4 < SEGV; ++v4) sg[s][v4] = row[v4];
 #pragma unroll
-        for (int v4 = 0; v4 < SEGV; ++v4) {
-          const float4 t = row[v4];
-          seg[4 * v4 + 0] = t.x; seg[4 * v4 + 1] = t.y; seg[4 * v4 + 2] = t.z; seg[4 * v4 + 3] = t.w;
-        }
+      for (int kw = 0; kw < KS; ++kw) wq[s][kw] = *reinterpret_cast<const float4*>(wl[b] + ((c * KS + kh) * KS + kw) * 4);
+    };
+    lload(0, 0, 0);
+    for (int c = 0; c < cn; c += 2) {      // two channels per trip: the register set of every row is a compile-time choice
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wl + ((c * KS + kh) * KS + kw) * 4);
-          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+      for (int cc = 0; cc < 2; ++cc) {
+        if (c + cc >= cn) break;
 #pragma unroll
-          for (int o = 0; o < 4; ++o)       // all four lanes of outputs: rows o >= Cout of wl are zero (no branch in the hot loop)
+        for (int kh = 0; kh < KS; ++kh) {
+          const int cur = (cc * KS + kh) & 1;
+          if (kh + 1 < KS) lload(c + cc, kh + 1, cur ^ 1);
+          else if (c + cc + 1 < cn) lload(c + cc + 1, 0, cur ^ 1);
+          float seg[SEGV * 4];
 #pragma unroll
-            for (int q = 0; q < PX; ++q) acc[o][q] = fmaf(seg[q + kw], wv[o], acc[o][q]);
+          for (int v4 = 0; v4 < SEGV; ++v4) {
+            seg[4 * v4 + 0] = sg[cur][v4].x; seg[4 * v4 + 1] = sg[cur][v4].y; seg[4 * v4 + 2] = sg[cur][v4].z; seg[4 * v4 + 3] = sg[cur][v4].w;
+          }
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const float wv[4] = {wq[cur][kw].x, wq[cur][kw].y, wq[cur][kw].z, wq[cur][kw].w};
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+              for (int q = 0; q < PX; ++q) acc[o][q] = fmaf(seg[q + kw], wv[o], acc[o][q]);
+          }
         }
       }
     }
+    if (more) sstore(b ^ 1);      // the other buffer: last read one iteration ago, before that iteration's barrier
+    __syncthreads();
   }
   const int oy = ty0 + ty;
   if (oy < OH) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < NO; ++o)
       if (o < Cout) {
 #pragma unroll
         for (int q = 0; q < PX; ++q) {
@@ -1053,15 +1138,17 @@ int launch_small_cout(const float* x, const float* w, const float* bias, const f
   const int OH = H + 2 * pad - ks + 1, OW = W + 2 * pad - ks + 1;
   const bool wide = OW > 32;                       // 16 x 64 tiles on wide maps, 32 x 32 otherwise
   dim3 g(wide ? agl_cdiv(OH, 16) * agl_cdiv(OW, 64) : agl_cdiv(OH, 32) * agl_cdiv(OW, 32), N);
-#define AGL_SC(KS_)                                                                                                        \
-  case KS_:                                                                                                                \
-    if (wide) hipLaunchKernelGGL((small_cout_conv<KS_, 16>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, Cout, OH, OW, \
-                                 pad, s_co, s_ci, flip, relu, accumulate);                                                 \
-    else hipLaunchKernelGGL((small_cout_conv<KS_, 8>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, Cout, OH, OW, pad,  \
-                            s_co, s_ci, flip, relu, accumulate);                                                           \
+#define AGL_SC2(KS_, TXT_, NO_)                                                                                                   \
+  hipLaunchKernelGGL((small_cout_conv<KS_, TXT_, NO_>), g, dim3(256), 0, st, x, w, bias, pos_mask, y, Cin, H, W, Cout, OH, OW, pad, \
+                     s_co, s_ci, flip, relu, accumulate)
+#define AGL_SC(KS_)                                                                          \
+  case KS_:                                                                                  \
+    if (wide) { if (Cout == 3) AGL_SC2(KS_, 16, 3); else AGL_SC2(KS_, 16, 4); }              \
+    else { if (Cout == 3) AGL_SC2(KS_, 8, 3); else AGL_SC2(KS_, 8, 4); }                     \
     break;
   switch (ks) { AGL_SC(1) AGL_SC(3) AGL_SC(4) AGL_SC(5) AGL_SC(7) default: return AGL_ERR_ARG; }
 #undef AGL_SC
+#undef AGL_SC2
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
@@ -1452,7 +1539,7 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64)   // (linear layers, HW = 1, stay on the GEMM)
+  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64 && (long)H * W * 8 < (1L << 18))   // (linear layers, HW = 1, stay on the GEMM; 18-bit patch table)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
@@ -1551,7 +1638,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cin <= 4 && stride == 1 && IH * IW >= 64)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+  if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18))   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
   if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
@@ -1700,8 +1787,8 @@ static int pos_conv_bww(const float* dy, const float* x, float* dw, void* ws, in
 #undef AGL_PW
   if (rc != AGL_OK) return rc;
   if (pl.splits > 1) {
-    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(pl.dwt, 256)), dim3(256), 0, st, (const float*)slabs, dwt, pl.dwt, pl.splits, 0);
-    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(position-major reduce)");
+    rc = agl_launch_slab_reduce((const float*)slabs, dwt, pl.dwt, pl.splits, 0, st, "agl_conv2d_bwd_weight(position-major reduce)");
+    if (rc != AGL_OK) return rc;
   }
   hipLaunchKernelGGL(tap_major_to_w_k, dim3(agl_cdiv(pl.dwt, 256)), dim3(256), 0, st, (const float*)dwt, dw, Cout, Cin, KK, accumulate);
   AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(position-major weights)");
@@ -1732,6 +1819,16 @@ long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, in
   return need;
 }
 static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW) {
+  if (Cin <= 4) {                                    // few-input-channel kernel (few.hip); the slab count does not depend on the padding
+    const FewBwwShape f{N, Cin, OH, OW, Cout, OH, OW, ks, 1, ks / 2, 0, 0};
+    const long few = (ks & 1) ? few_bww_ws_bytes(f) : 0;
+    if (few) {
+      long Nc = (long)Cin * ks * ks, R = (long)N * OH * OW;
+      int s = bww_splits(Cout, Nc, R, nullptr);
+      const long plain = s > 1 ? (long)s * Cout * Nc * 4 : 0;
+      return few > plain ? few : plain;
+    }
+  }
   long pos_need = 0;
   if (OH <= 8 && OW <= 8 && ks == 5 && pos_ok(kDefaultOpts, N, 64, OH, OW, Cout, ks, 0) && Cin >= 64)   // stride-1 "same" 5x5 on a small map
     pos_need = pos_bww_plan(N, Cin, OH, OW, Cout, OH, OW, ks, 1, ks / 2).total();
@@ -1769,6 +1866,16 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (Cin <= 4) {      // RGB-side layers: rows = output channels, columns = (input channel, tap), exact fp32 (few.hip)
+    const FewBwwShape f{N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up_log2, in_relu};
+    int fsplits = 0;
+    const int frc = few_bww_try(f, dy, x, ws, ws_bytes, &fsplits, (hipStream_t)stream, "agl_conv2d_bwd_weight(few input channels)");
+    if (frc == AGL_OK) {
+      const long n = (long)Cout * Cin * ks * ks;
+      return agl_launch_slab_reduce((const float*)ws, dw, n, fsplits, accumulate, (hipStream_t)stream, "agl_conv2d_bwd_weight(few input channels: reduce)");
+    }
+    if (frc > 0) return frc;
+  }
   if (co.patch && (co.prec == 1 || co.split3)) {
     PBwwArgs a;
     a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
@@ -1827,8 +1934,8 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
   if (rc != AGL_OK) return rc;
   if (!direct) {
     long n = (long)Cout * Nc;
-    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, dw, n, splits, accumulate);
-    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(reduce)");
+    rc = agl_launch_slab_reduce((const float*)ws, dw, n, splits, accumulate, st, "agl_conv2d_bwd_weight(reduce)");
+    if (rc != AGL_OK) return rc;
   }
   return AGL_OK;
 }
@@ -1840,7 +1947,7 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
   const ConvOpts co = conv_opts(flags);
   const int Hl = H << up_log2, Wl = W << up_log2;
   const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
-  const bool small = Cout <= 4 && stride == 1 && up_log2 == 0 && OH * OW >= 64;
+  const bool small = Cout <= 4 && stride == 1 && up_log2 == 0 && OH * OW >= 64 && (long)H * W * 8 < (1L << 18);
   bool mc = false;
   if (co.patch && (co.prec == 1 || co.split3)) {
     PConvArgs a{};
@@ -1854,7 +1961,7 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
 }
 double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
-  const bool small = Cin <= 4 && stride == 1 && IH * IW >= 64;
+  const bool small = Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18);
   bool mc = false;
   if (co.patch && (co.prec == 1 || co.split3) && stride == 1 && IH == OH && IW == OW) {
     PConvArgs a{};

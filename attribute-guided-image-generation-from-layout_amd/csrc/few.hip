@@ -1,0 +1,209 @@
+// Convolutions with a few (<= 4: RGB) channels on one side.  Their arithmetic is negligible — they are streams over the
+// many-channel tensor — but as GEMMs they have a 3..147-wide dimension that leaves the generic 128-wide tiles almost empty
+// (0.8..30 TFLOP/s, 0.5 TB/s).  The kernels here are shaped for them; all arithmetic is exact fp32.
+//
+//   few_bww_k   weight gradient with <= 4 INPUT channels (first layers: models/discriminator.py:29-60 OptimizedBlock 3->64,
+//               generator_obj_att.py:367 CropEncoder c1 3->64 k7) — and, through the role swap of conv.hip, with <= 4 OUTPUT
+//               channels (decoder c4 64->3 k7, generator_obj_att.py:516).  GEMM: rows = output channels (64 per workgroup),
+//               columns = (input channel, tap) <= 160, reduction = pixels, on v_mfma_f32_32x32x2_f32.
+#include "agl_internal.h"
+#include "few.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT_ = 256;
+
+struct FewBwwArgs {
+  const float* dy; const float* x; float* slabs;
+  int N, Cin, H, W, Cout, OH, OW, pad, in_relu;
+  int tiles, tiles_per_split, ncols;
+};
+
+// Tile = 128 output pixels = TH full rows of one image (OW in {32, 64, 128}, TH = 128 / OW).  The dy tile is staged as
+// [64 channels][128 pixels] (pitch 132 floats: the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots), the input
+// patch as [c][TH+KS-1][OW+KS-1] with zero padding.  Every wave takes 32 of the 128 pixels and accumulates the whole
+// 64 x (32*NTL) product for them — an MFMA consumes 2 pixels: lanes 0-31 hold pixel 4g+j, lanes 32-63 pixel 4g+4+j of an
+// 8-pixel group, so one 16-byte read of dy feeds 4 MFMAs.  The four partial products are added through LDS in a fixed
+// order at the end and the workgroup writes one slab; slab_reduce (conv.hip) adds the slabs (deterministic).
+template <int KS, int NTL>
+__global__ __launch_bounds__(NT_, 2) void few_bww_k(FewBwwArgs p) {
+  constexpr int KK = KS * KS, DP = 132, BMC = 64;
+  constexpr int RED = BMC * NTL * 32;                  // floats of the cross-wave reduction buffer
+  constexpr int DYF = BMC * DP;                        // floats of the dy tile
+  // patch floats, worst case over OW in {32, 64, 128} (TH = 4, 2, 1) with 4 channels
+  constexpr int P32 = 4 * (KS + 3) * (KS + 31), P64 = 4 * (KS + 1) * (KS + 63), P128 = 4 * KS * (KS + 127);
+  constexpr int PATCHF = P32 > P64 ? (P32 > P128 ? P32 : P128) : (P64 > P128 ? P64 : P128);
+  constexpr int STAGEF = DYF + PATCHF;
+  __shared__ __attribute__((aligned(16))) float lds[STAGEF > RED ? STAGEF : RED];
+  float* const Dl = lds;
+  float* const Pl = lds + DYF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int co0 = blockIdx.y * BMC;
+  const int OW = p.OW, TH = 128 / OW, PH = TH + KS - 1, PW = OW + KS - 1;
+  const int tpi = p.OH / TH;                           // tiles per image
+  const int t_beg = blockIdx.x * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
+  const long OHW = (long)p.OH * OW, HW = (long)p.H * p.W;
+
+  // column of this lane in every column tile: (c, kh, kw) -> patch offset; columns >= ncols read offset 0 (discarded)
+  int boff[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int col = 32 * nt + l31;
+    const int c = col / KK, t = col - c * KK, kh = t / KS, kw = t - kh * KS;
+    boff[nt] = col < p.ncols ? (c * PH + kh) * PW + kw : 0;
+  }
+  // the wave's 32 pixels: pixel index q = 32*wave + 8*g + 4*lh + j  ->  (row, column) of the tile
+  int pixoff[4];                                       // patch offset of pixel 32*wave + 8*g + 4*lh (j adds 1 per pixel: OW >= 32)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int q = 32 * wave + 8 * g + 4 * lh;
+    pixoff[g] = (q / OW) * PW + (q % OW);
+  }
+
+  f32x16 acc[2][NTL];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+
+  // dy staging: item e = (channel, 16-byte piece of its 128 contiguous pixels); 8 items per thread
+  float4 pd[8];
+  auto gload_dy = [&](int tile) {
+    const int img = tile / tpi, ty0 = (tile - img * tpi) * TH;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + NT_ * r, co = e >> 5, pc = e & 31;
+      const bool ok = co0 + co < p.Cout;
+      const long idx = ok ? ((long)img * p.Cout + co0 + co) * OHW + (long)ty0 * OW + 4 * pc : 0;
+      const float4 v = *reinterpret_cast<const float4*>(p.dy + idx);
+      pd[r] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto sstore_dy = [&]() {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + NT_ * r, co = e >> 5, pc = e & 31;
+      *reinterpret_cast<float4*>(Dl + co * DP + 4 * pc) = pd[r];
+    }
+  };
+  auto stage_patch = [&](int tile) {
+    const int img = tile / tpi, ty0 = (tile - img * tpi) * TH;
+    const int np = p.Cin * PH * PW;
+    for (int e = tid; e < np; e += NT_) {
+      const int c = e / (PH * PW), r = e - c * (PH * PW), yy = r / PW, xx = r - yy * PW;
+      const int iy = ty0 - p.pad + yy, ix = xx - p.pad;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = p.x[((long)img * p.Cin + c) * HW + (long)iy * p.W + ix];
+      if (p.in_relu) v = fmaxf(v, 0.f);
+      Pl[e] = v;
+    }
+  };
+
+  constexpr bool PREF = NTL < 5;                       // (160 accumulator registers leave no room for the prefetch: the 7x7 case is MFMA-bound)
+  if (PREF && t_beg < t_end) gload_dy(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    if (!PREF) gload_dy(tile);
+    __syncthreads();                                   // everyone is done reading the previous tile
+    sstore_dy();
+    stage_patch(tile);
+    __syncthreads();
+    if (PREF && tile + 1 < t_end) gload_dy(tile + 1);  // in flight during this tile's MFMAs
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = 32 * wave + 8 * g + 4 * lh;
+      float4 a[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(Dl + (32 * m + l31) * DP + q);
+      float b[NTL][4];
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[nt][j] = Pl[boff[nt] + pixoff[g] + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float av = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+#pragma unroll
+          for (int nt = 0; nt < NTL; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[nt][j], acc[m][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave sum in wave order, then the slab.  C tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* const R = lds;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float* dst = R + row * (NTL * 32) + 32 * nt + l31;
+            *dst = w == 0 ? acc[m][nt][r] : *dst + acc[m][nt][r];
+          }
+    }
+  }
+  __syncthreads();
+  float* out = p.slabs + (long)blockIdx.x * p.Cout * p.ncols;
+  for (int e = tid; e < BMC * p.ncols; e += NT_) {
+    const int co = e / p.ncols, col = e - co * p.ncols;
+    if (co0 + co < p.Cout) out[(long)(co0 + co) * p.ncols + col] = R[co * (NTL * 32) + col];
+  }
+}
+
+}  // namespace
+
+static int few_bww_plan(const FewBwwShape& a, int* ntl, int* splits, int* tps, int* tiles) {
+  if (a.Cin > 4 || a.Cout < 16 || a.stride != 1 || a.up != 0) return -1;
+  if (!(a.ks == 1 || a.ks == 3 || a.ks == 5 || a.ks == 7)) return -1;
+  if (!(a.OW == 32 || a.OW == 64 || a.OW == 128) || a.OH % (128 / a.OW) != 0) return -1;
+  if (a.H + 2 * a.pad - a.ks + 1 != a.OH || a.W + 2 * a.pad - a.ks + 1 != a.OW || a.pad >= a.ks) return -1;
+  const int ncols = a.Cin * a.ks * a.ks;
+  const int n = (ncols + 31) / 32;
+  if (n > 5) return -1;                                // accumulators: 32 * n registers per lane
+  if ((long)a.N * a.Cout * a.OH * a.OW >= (1L << 31) || (long)a.N * a.Cin * a.H * a.W >= (1L << 31)) return -1;
+  const long t = (long)a.N * (a.OH / (128 / a.OW));
+  const int blocks = agl_cdiv(a.Cout, 64);
+  long z = (512 + blocks - 1) / blocks;                // two workgroups per CU
+  if (z > t) z = t;
+  const long per = (t + z - 1) / z;
+  z = (t + per - 1) / per;
+  *ntl = n; *splits = (int)z; *tps = (int)per; *tiles = (int)t;
+  return 0;
+}
+
+long few_bww_ws_bytes(const FewBwwShape& a) {
+  int ntl, splits, tps, tiles;
+  if (few_bww_plan(a, &ntl, &splits, &tps, &tiles) != 0) return 0;
+  return (long)splits * a.Cout * a.Cin * a.ks * a.ks * 4;
+}
+
+int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws, long ws_bytes, int* splits_out, hipStream_t st,
+                const char* name) {
+  int ntl, splits, tps, tiles;
+  if (few_bww_plan(a, &ntl, &splits, &tps, &tiles) != 0) return -1;
+  const long need = (long)splits * a.Cout * a.Cin * a.ks * a.ks * 4;
+  if (!ws || ws_bytes < need) return -1;
+  FewBwwArgs p;
+  p.dy = dy; p.x = x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
+  p.pad = a.pad; p.in_relu = a.in_relu; p.tiles = tiles; p.tiles_per_split = tps; p.ncols = a.Cin * a.ks * a.ks;
+  dim3 g((unsigned)splits, agl_cdiv(a.Cout, 64));
+#define FEW_LAUNCH(KS_, NT2_) hipLaunchKernelGGL((few_bww_k<KS_, NT2_>), g, dim3(NT_), 0, st, p)
+  if (a.ks == 1) FEW_LAUNCH(1, 1);
+  else if (a.ks == 3) { if (ntl == 1) FEW_LAUNCH(3, 1); else FEW_LAUNCH(3, 2); }
+  else if (a.ks == 5) { if (ntl <= 3) FEW_LAUNCH(5, 3); else FEW_LAUNCH(5, 4); }
+  else { if (ntl <= 4) FEW_LAUNCH(7, 4); else FEW_LAUNCH(7, 5); }
+#undef FEW_LAUNCH
+  AGL_CHECK_LAUNCH(name);
+  *splits_out = splits;
+  return AGL_OK;
+}

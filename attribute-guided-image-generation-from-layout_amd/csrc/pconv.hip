@@ -413,7 +413,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 //     16-channel block (each lane supplies the address of one 8-byte row quarter, so the tap shift and the convolution
 //     stride are just address arithmetic, with no alignment constraint) and hands lane i column i.
 // A workgroup owns 64*RT output channels x 16*CT input channels x all taps (accumulators in registers), walks its share of
-// the 128-pixel tiles, and writes one slab; slab_sum_k adds the slabs in fixed order (deterministic).
+// the 128-pixel tiles, and writes one slab; the slabs are added in a fixed order (agl_launch_slab_reduce: deterministic).
 struct WArgs {
   const float* dy; const float* x; float* slabs;
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
@@ -604,14 +604,6 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
           }
         }
       }
-}
-
-__global__ void slab_sum_k(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
-  out[i] = accumulate ? out[i] + s : s;
 }
 
 }  // namespace
@@ -888,7 +880,5 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   }
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
-  hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.dw, n, splits, a.accumulate);
-  AGL_CHECK_LAUNCH(name);
-  return AGL_OK;
+  return agl_launch_slab_reduce((const float*)ws, a.dw, n, splits, a.accumulate, st, name);
 }

@@ -717,6 +717,33 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
         assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
 
 
+FEW_BWW_CASES = [  # N, Cin, H, Cout, ks, pad, in_relu: weight gradients with <= 4 channels on one side (csrc/few.hip)
+    (5, 3, 32, 64, 3, 1, 0), (4, 3, 32, 64, 1, 0, 0), (3, 3, 32, 64, 7, 3, 0), (2, 3, 64, 64, 3, 1, 1), (2, 3, 64, 80, 1, 0, 0),
+    (2, 4, 32, 32, 3, 1, 0), (2, 1, 32, 48, 5, 2, 1), (1, 3, 128, 64, 5, 2, 0), (3, 2, 64, 128, 7, 3, 0), (2, 3, 32, 16, 3, 0, 0),
+    (2, 64, 64, 3, 7, 3, 0), (3, 32, 32, 3, 3, 1, 0), (2, 48, 64, 1, 5, 2, 0)]   # (last three: few OUTPUT channels, roles swapped)
+
+
+@pytest.mark.parametrize("case", FEW_BWW_CASES)
+def test_few_channel_weight_gradient(case):
+    """RGB-side layers (OptimizedBlock 3->64 discriminator.py:29-60, CropEncoder c1 generator_obj_att.py:367, decoder c4 64->3):
+    the weight gradient as a 64 x (Cin*ks^2) MFMA product streamed over the pixels, exact fp32; plain and accumulating."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, pad, in_relu = case
+    x, w = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1)
+    xin = torch.relu(x) if in_relu else x
+    OH = H + 2 * pad - ks + 1
+    gy = rn(N, Cout, OH, OH, seed=3)
+    wg = w.clone().requires_grad_(True)
+    TF.conv2d(xin, wg, None, padding=pad).backward(gy)
+    for flags in (0, L.CONV_SPLIT3):
+        with L.conv_flags(flags):
+            dw = L.conv2d_bwd_weight(dev(gy), dev(x), ks, 1, pad, in_relu=bool(in_relu))
+            close(dw, wg.grad, 2e-5, f"weight gradient flags={flags}")
+            base = rn(Cout, Cin, ks, ks, seed=5)
+            dw2 = L.conv2d_bwd_weight(dev(gy), dev(x), ks, 1, pad, in_relu=bool(in_relu), out=dev(base).clone(), accumulate=True)
+            close(dw2, base + wg.grad, 2e-5, f"accumulating flags={flags}")
+
+
 def test_pconv_upsampled_input():
     """Nearest up-sampling folded into the patch staging (SPADE mlp_shared reads the 8x8 map up-sampled, normalization.py:100)."""
     from agl import lib as L

@@ -8,7 +8,7 @@ mkdir -p ../agl/ab /tmp/ab_$name
 make -s all
 hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result -Wno-pass-failed "$@" -c $src -o /tmp/ab_$name/${src%.hip}.o
 objs=""
-for o in api.o conv.o pconv.o norm.o pointwise.o sn.o loss.o layout.o; do
+for o in api.o conv.o pconv.o few.o norm.o pointwise.o sn.o loss.o layout.o; do
   if [ "$o" = "${src%.hip}.o" ]; then objs="$objs /tmp/ab_$name/$o"; else objs="$objs $o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../agl/ab/libagl_$name.so $objs

@@ -58,6 +58,8 @@ SHAPES = [
     ("Dobj.3sc 256>512 k1 @4", O, 256, 4, 512, 1, 1, 0),
     ("Dobj.4sc 512>1024 k1 @2", O, 512, 2, 1024, 1, 1, 0),
     ("Dobj.0sc 3>64 k1 @32", O, 3, 32, 64, 1, 1, 0),
+    ("Dimg.0a 3>64 k3 @64 (B=64)", N, 3, 64, 64, 3, 1, 1),
+    ("Dimg.0sc 3>64 k1 @64 (B=64)", N, 3, 64, 64, 1, 1, 0),
     ("128px SPADE5.gb 128>256 k3 @128", 32, 128, 128, 256, 3, 1, 1),
     ("128px DEC.c6 128>128 k5 @128", 32, 128, 128, 128, 5, 1, 2),
     ("128px Dobj.0b 64>64 k3 @64 (B=210)", 210, 64, 64, 64, 3, 1, 1),
