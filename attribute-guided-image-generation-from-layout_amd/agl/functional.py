@@ -40,16 +40,38 @@ def _slot(p):
     return p.grad if (p is not None and getattr(p, "_agl_slot", False) and p.grad is not None) else None
 
 
+# BatchNorm statistics produced by the convolution that feeds the norm (agl_conv2d_fwd_stats): while EMIT_STATS is set (the
+# generator's forward: every conv there is followed by a batch-statistics norm), a plain convolution also leaves per-channel
+# partial sums of its output, and the _NormAct that consumes exactly that tensor next finalises them instead of re-reading
+# the activation.  One entry at most, dropped by whatever convolution or norm runs next.
+EMIT_STATS = False
+_LAST_STATS = None      # (data_ptr, shape, partials, rows)
+
+
+def _take_stats(x):
+    global _LAST_STATS
+    e, _LAST_STATS = _LAST_STATS, None
+    if e is not None and e[0] == x.data_ptr() and e[1] == tuple(x.shape):
+        return e[2], e[3]
+    return None, 0
+
+
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu, relu_grad_by_consumer, x_relu):
+        global _LAST_STATS
+        _LAST_STATS = None
         ctx.slots = (_slot(w), _slot(bias))
         x, w = _c(x), _c(w)
         if addend is not None:
             assert not relu, "addend with fused ReLU is not supported"
             y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, False, out=addend, accumulate=True)
             ctx.mark_dirty(addend)
+        elif EMIT_STATS and not relu and (L.CONV_FLAGS & (L.CONV_BF16 | L.CONV_SPLIT3)):
+            y, part, rows = L.conv2d_fwd_stats(x, w, bias, stride, pad, up, in_relu)
+            if part is not None:
+                _LAST_STATS = (y.data_ptr(), tuple(y.shape), part, rows)
         else:
             y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, relu)
         ctx.cfg = (stride, pad, up, in_relu, relu, bias is not None, addend is not None, relu_grad_by_consumer, x_relu)
@@ -141,8 +163,12 @@ class _NormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training):
         x = _c(x)
+        part, rows = _take_stats(x)
         if training:
-            mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
+            if part is not None:
+                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
+            else:
+                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
             if BN_TAPE is not None and rmean is not None:
                 BN_TAPE.append(lambda: L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt))
         else:

@@ -341,6 +341,18 @@ class Generator(nn.Module):
         self.attribute_encoder = AttributeEncoder(attribute_dim=attribute_dim, embedding_dim=obj_att_dim,
                                                   class_num=num_embeddings)
 
+    @staticmethod
+    def _with_conv_stats(fn):
+        """Convolutions of the generator leave BatchNorm partial sums for the norm that follows them (F.EMIT_STATS)."""
+        def run(self, *a, **k):
+            prev, F.EMIT_STATS = F.EMIT_STATS, True
+            try:
+                return fn(self, *a, **k)
+            finally:
+                F.EMIT_STATS = prev
+        run.__name__, run.__doc__ = fn.__name__, fn.__doc__
+        return run
+
     def forward(self, imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est,
                 eps: Optional[Sequence[torch.Tensor]] = None):
         sh = self.part_a(imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est)
@@ -354,6 +366,7 @@ class Generator(nn.Module):
     # generator twice with unchanged weights (train64.py:195 and :280), so agl.trainer evaluates part_a / part_b once,
     # keeps their graph, and runs part_rec twice.  Per BatchNorm layer the order of batches (rec, rand, shift) is the
     # reference's in either schedule.
+    @_with_conv_stats.__func__
     def part_a(self, imgs, objs, boxes, masks, obj_to_img, z_rand, attribute, masks_shift, boxes_shift, attribute_est):
         A._need_device(imgs)
         dev = imgs.device
@@ -374,6 +387,7 @@ class Generator(nn.Module):
         O, zd = sh["mu"].shape
         return [get_z_random(O, zd) for _ in range(3)]
 
+    @_with_conv_stats.__func__
     def part_rec(self, sh, eps0):
         z_rec = self.crop_encoder.sample(sh["mu"], sh["logvar"], eps0)
         h_rec = self.layout_encoder(sh["objs_att_est"], sh["masks"], sh["obj_to_img"], z_rec, sh["objs"], sh["plan"])
@@ -381,6 +395,7 @@ class Generator(nn.Module):
         crops_input_rec = F.crop_boxes(img_rec, sh["boxes"], sh["o2i_dev"], self.obj_size)
         return img_rec, crops_input_rec
 
+    @_with_conv_stats.__func__
     def part_b(self, sh):
         objs, o2i = sh["objs"], sh["obj_to_img"]
         calls = [(sh["objs_att"], sh["masks"], sh["z_rand"]), (sh["objs_att"], sh["masks_shift"], sh["z_rand"])]

@@ -35,6 +35,9 @@ SIGNATURES = {
     "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
     "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P]),
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    "agl_bn_stats_from_partials": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "agl_conv2d_fwd_stats_floats": (_L, [_I] * 4),
+    "agl_conv2d_fwd_stats": (_I, [_P] * 5 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
     "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
@@ -128,7 +131,8 @@ def load() -> C.CDLL:
 # (name, start, end, work, dims) with work = executed FLOPs for the convolution family (agl_conv2d_*_flops, i.e. the
 # dense count minus the padded taps the position-major path skips) or algorithmic HBM bytes for the normalisation family.
 EVENT_LOG = None
-EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight", "agl_bn_stats", "agl_norm_apply_fwd", "agl_norm_bwd"}
+EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight", "agl_bn_stats",
+               "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd"}
 
 # Convolution flags passed with every agl_conv2d_* call (include/agl.h AGL_CONV_*).  This is host-side state of the
 # Python binding only — the C ABI has no process-wide switches.
@@ -166,12 +170,16 @@ def work_of(name, args) -> float:
     lib = load()
     if name == "agl_conv2d_fwd":
         return lib.agl_conv2d_fwd_flops(*args[6:15], args[18])
+    if name == "agl_conv2d_fwd_stats":
+        return lib.agl_conv2d_fwd_flops(*args[6:15], args[16])
     if name == "agl_conv2d_bwd_data":
         return lib.agl_conv2d_bwd_data_flops(*args[7:17], args[19])
     if name == "agl_conv2d_bwd_weight":
         return lib.agl_conv2d_bwd_weight_flops(*args[5:17], args[18])
     if name == "agl_bn_stats":                       # one read of x (4*N*C*HW)
         return 4.0 * args[1] * args[2] * args[3]
+    if name == "agl_bn_stats_from_partials":         # the statistics read of x the fused form avoids: algorithmic bytes 0
+        return 0.0
     if name == "agl_norm_apply_fwd":                 # x read + y write (+ gamma|beta planes for SPADE, + residual)
         mode, res, N, Cc, HW = args[3], args[7], args[10], args[11], args[12]
         return 4.0 * N * Cc * HW * (2 + (2 if mode == 3 else 0) + (1 if res is not None else 0))
@@ -253,6 +261,32 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
          int(in_relu), int(relu), int(accumulate), CONV_FLAGS, stream())
     return out
+
+
+def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False):
+    """conv2d_fwd that also returns the BatchNorm partial rows of its output: (y, partials or None, rows)."""
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, ks, ks2 = w.shape
+    assert Cin_w == Cin and ks == ks2, (x.shape, w.shape)
+    OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
+    out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
+    ws = workspace(need, x.device) if need else None
+    nst = load().agl_conv2d_fwd_stats_floats(N, Cout, OH, OW)
+    stats = torch.empty(nst, dtype=torch.float32, device=x.device)
+    rows = C.c_int(0)
+    call("agl_conv2d_fwd_stats", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), CONV_FLAGS,
+         stats.data_ptr(), nst, C.addressof(rows), stream())
+    return out, (stats if rows.value > 0 else None), rows.value
+
+
+def bn_stats_from_partials(partials, rows, Cc, count, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    mean = torch.empty(Cc, dtype=torch.float32, device=partials.device)
+    rstd = torch.empty_like(mean)
+    call("agl_bn_stats_from_partials", partials.data_ptr(), rows, Cc, count, eps, momentum, ptr(running_mean), ptr(running_var),
+         ptr(nbt, torch.int64), ptr(mean), ptr(rstd), stream())
+    return mean, rstd
 
 
 def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accumulate=False):

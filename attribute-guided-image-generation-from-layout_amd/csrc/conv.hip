@@ -1526,9 +1526,32 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
   return need;
 }
 
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                           int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
+                           int flags, void* stream, float* stats, long stats_floats, int* stat_rows);
+
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
                    int flags, void* stream) {
+  return conv2d_fwd_impl(x, w, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, relu, accumulate, flags,
+                         stream, nullptr, 0, nullptr);
+}
+
+// Forward convolution that may also hand back the BatchNorm partial sums of its output (include/agl.h)
+int agl_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                         int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int flags, float* stats,
+                         long stats_floats, int* stat_rows, void* stream) {
+  AGL_REQUIRE(stats && stat_rows && stats_floats >= 0, "agl_conv2d_fwd_stats: null statistics buffer");
+  *stat_rows = 0;
+  return conv2d_fwd_impl(x, w, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, 0, 0, flags, stream, stats,
+                         stats_floats, stat_rows);
+}
+
+long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW) { return pconv_stat_rows_max(N, OH, OW) * Cout * 2; }
+
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                           int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
+                           int flags, void* stream, float* stats, long stats_floats, int* stat_rows) {
   AGL_REQUIRE(x && w && y, "agl_conv2d_fwd: null pointer");
   const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2) && up_log2 >= 0 && up_log2 <= 4,
@@ -1543,10 +1566,11 @@ int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
-    PConvArgs a;
+    PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
     if (prc >= 0) return prc;
   }
@@ -1642,7 +1666,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
   if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
-    PConvArgs a;    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+    PConvArgs a{};    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;

@@ -67,6 +67,32 @@ __global__ void bn_stats_final(const double* __restrict__ part, int C, int S, lo
   }
 }
 
+// Statistics from the partial rows a convolution wrote beside its output (agl_conv2d_fwd_stats): part[row][c][{sum, sum sq}].
+// One wave per channel, rows summed in double in a fixed order.
+__global__ __launch_bounds__(64) void bn_stats_from_rows(const float* __restrict__ part, int rows, int C, long M, float eps, float momentum,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, long long* __restrict__ nbt) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && nbt) *nbt += 1;
+  double a = 0.0, b = 0.0;
+  for (int r = lane; r < rows; r += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((long)r * C + c) * 2);
+    a += (double)v.x; b += (double)v.y;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane != 0) return;
+  const double mu = a / (double)M;
+  double var = b / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+  }
+}
+
 // Eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
 __global__ void bn_stats_eval(const float* rmean, const float* rvar, int C, float eps, float* mean, float* rstd) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +274,16 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
   hipLaunchKernelGGL(bn_stats_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S, total, eps,
                      momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
   AGL_CHECK_LAUNCH("agl_bn_stats(final)");
+  return AGL_OK;
+}
+
+int agl_bn_stats_from_partials(const float* partials, int rows, int C, long count, float eps, float momentum, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream) {
+  AGL_REQUIRE(partials && mean && rstd && rows > 0 && C > 0 && count > 0, "agl_bn_stats_from_partials: bad argument");
+  AGL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "agl_bn_stats_from_partials: running_mean / running_var go together");
+  hipLaunchKernelGGL(bn_stats_from_rows, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, rows, C, count, eps, momentum, mean, rstd,
+                     running_mean, running_var, num_batches_tracked);
+  AGL_CHECK_LAUNCH("agl_bn_stats_from_partials");
   return AGL_OK;
 }
 

@@ -9,7 +9,10 @@ struct PConvArgs {
   int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
   int nsplit;                       // 1: bf16 operands (AGL_CONV_BF16); 3: fp32 operands as three bf16 terms, six products
   int any_grid;                     // launch also below the occupancy threshold (AGL_CONV_ANY_GRID)
+  float* stats; long stats_floats; int* stat_rows;   // optional BatchNorm partials of the output: buffer, its capacity, rows written
 };
+// Upper bound of the partial rows pconv_try writes for an output of N images of OH x OW pixels
+long pconv_stat_rows_max(int N, int OH, int OW);
 
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);

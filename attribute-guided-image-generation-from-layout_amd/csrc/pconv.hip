@@ -36,6 +36,7 @@ struct PArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu, relu, accumulate;
   int nch, mpad;
   unsigned x_bytes;
+  float* stats;      // optional: per-channel (sum, sum of squares) of the stored outputs, one row per (pixel tile, wave column)
 };
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
@@ -318,6 +319,12 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   float* const ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_PITCH);
   const long OHW = (long)p.OH * p.OW;
   const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8*pass, columns ec..ec+3
+  // BatchNorm statistics of the output (p.stats): every lane sums the values it stores, per channel row
+  float ssum[WTM][4], ssq[WTM][4];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; }
 #pragma unroll
   for (int jt = 0; jt < WTN; ++jt) {
     const int j = wn * (BN / 2) + 32 * jt + ec;
@@ -393,8 +400,27 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           if (p.accumulate) { o.x += old[ps].x; o.y += old[ps].y; o.z += old[ps].z; o.w += old[ps].w; }
           if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
           *reinterpret_cast<float4*>(p.y + pbase + (long)m * OHW) = o;
+          if (p.stats) {
+            ssum[i][ps] += (o.x + o.y) + (o.z + o.w);
+            ssq[i][ps] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+          }
         }
       }
+    }
+  }
+  if constexpr (!PHS) {
+    if (p.stats) {      // the 8 lanes of a channel row hold its pixels: butterfly within the octet, lane 0 of it writes the partial
+      float* const row = p.stats + ((long)blockIdx.x * 2 + wn) * p.Cout * 2;
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          float a = ssum[i][ps], b = ssq[i][ps];
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+          const int m = bm0 + wm * (BM / 2) + 32 * i + er + 8 * ps;
+          if ((lane & 7) == 0 && m < p.Cout) { row[2 * m] = a; row[2 * m + 1] = b; }
+        }
     }
   }
 }
@@ -661,6 +687,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 }
 
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
+long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64); }
 
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   PConvPlan pl;
@@ -678,6 +705,11 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
   if (a.ks == 1) { p.H = p.OH = pl.oh; p.W = p.OW = pl.ow; }      // the re-read map of a 1x1 convolution
+  p.stats = nullptr;
+  if (a.stats && !a.relu && !a.accumulate && !a.pos_mask && 2 * ptiles * a.Cout * 2 <= a.stats_floats) {
+    p.stats = a.stats;
+    *a.stat_rows = (int)(2 * ptiles);
+  }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
   const long per_plane = (long)nch * 2 * KK * mpad;
@@ -791,7 +823,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   PArgs p;
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
-  p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
+  p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), 4);
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)

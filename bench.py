@@ -43,8 +43,8 @@ ARITHMETIC = {
              "fp64 <= 2x that of the exact kernel, full-step fixtures at the fp32 tolerances); exact fp32 MFMA in all other kernels",
     "bf16": "fp32 tensors in HBM; convolution operands rounded to bf16 when staged, bf16 MFMA with fp32 accumulation",
 }
-CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight")
-NORM_NAMES = ("agl_bn_stats", "agl_norm_apply_fwd", "agl_norm_bwd")
+CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight")
+NORM_NAMES = ("agl_bn_stats", "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd")
 
 
 def parse_args(argv=None):
@@ -235,8 +235,8 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         # figure larger than what the hardware executes, so it is throughput, not utilisation.
         roof = {"bound": "mfma", "achieved": round(ex_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ex_tf / peak, 4),
                 "traffic": None,
-                "kernel": "convolution family: igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + small_cout_conv incl. their "
-                          "split-K reductions (all agl_conv2d_* launches of one step)",
+                "kernel": "convolution family: pconv_k / pbww_k (bf16 matrix cores) + igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + "
+                          "few_bww_k / small_cout_conv incl. their weight packing and slab / split-K reductions (all agl_conv2d_* launches of one step)",
                 "launches_per_step": len(conv), "kernel_ms_per_step": round(conv_ms, 3),
                 "executed_flops_per_step": executed, "algorithmic_flops_per_step": flops_step,
                 "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3)}

@@ -59,6 +59,15 @@ long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long 
 int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
                    int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
                    int flags, void* stream);
+/* The same forward (no output ReLU, no accumulate) that may also leave the BatchNorm partial sums of its output in
+ * `stats` — the statistics pass of the nn.BatchNorm2d that follows the convolution (generator_obj_att.py:54-57, 433, 583;
+ * normalization.py:77-78 + 97) then needs no read of y.  stats: stats_floats floats (agl_conv2d_fwd_stats_floats());
+ * *stat_rows = rows written, each row = [Cout][{sum, sum of squares}] over a disjoint set of output pixels — 0 when the
+ * launch that ran does not produce them (the caller then uses agl_bn_stats).  Feed the rows to agl_bn_stats_from_partials. */
+long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW);
+int agl_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
+                         int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int flags, float* stats,
+                         long stats_floats, int* stat_rows, void* stream);
 /* Gradient wrt the input of the conv above; ALSO the forward of nn.ConvTranspose2d(k=4,s=2,p=1)
  * (generator_obj_att.py:532,536,540) with w stored [C_in_T][C_out_T][4][4].  pos_mask (optional, shaped
  * like dx): dx is zeroed where pos_mask <= 0 (backward of a fused input ReLU).                      */
@@ -86,6 +95,10 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
                  void* stream);
 int agl_bn_stats_eval(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
                       void* stream);
+/* agl_bn_stats from the partial rows of agl_conv2d_fwd_stats (count = N*HW elements per channel); rows are added in
+ * double in a fixed order.  Same running-statistics update. */
+int agl_bn_stats_from_partials(const float* partials, int rows, int C, long count, float eps, float momentum, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream);
 /* y = modulate(xhat) (+residual) (relu).  mode 0: none; 1: gamma[C],beta[C] (BatchNorm affine);
  * 2: table[V][2C] indexed by labels[N] (ConditionalBatchNorm2d, generator_obj_att.py:40-44);
  * 3: gb[N][2C][HW], y = xhat*(1+gamma)+beta (SPADE, normalization.py:106).                           */

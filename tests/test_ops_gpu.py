@@ -717,6 +717,37 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
         assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(5, 32, 32, 64, 3, 1, 1), (9, 64, 8, 128, 3, 1, 1), (17, 32, 4, 64, 3, 1, 1), (3, 16, 24, 48, 5, 1, 2),
+                                  (6, 32, 16, 80, 1, 1, 0), (4, 64, 32, 128, 4, 2, 1), (3, 32, 17, 64, 3, 2, 0), (2, 48, 64, 200, 3, 1, 1)])
+def test_conv_emits_batchnorm_partials(case, mode):
+    """agl_conv2d_fwd_stats: the matrix-core convolution leaves per-channel (sum, sum of squares) rows of the output it stores;
+    agl_bn_stats_from_partials must then agree with agl_bn_stats run on that output (mean, rstd, running statistics, counter),
+    and the output itself must equal the plain forward."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks, stride, pad = case
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2) * 3.0
+    flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    with L.conv_flags(flags):
+        y0 = L.conv2d_fwd(xd, wd, bd, stride, pad, in_relu=True)
+        y, part, rows = L.conv2d_fwd_stats(xd, wd, bd, stride, pad, in_relu=True)
+    assert part is not None and rows > 0, "the matrix-core kernel did not take this shape"
+    assert torch.equal(y, y0)
+    C_, cnt = y.shape[1], y.numel() // y.shape[1]
+    rm = [dev(rn(C_, seed=4)).clone() for _ in range(2)]
+    rv = [dev(rn(C_, seed=5).abs() + 0.5).clone() for _ in range(2)]
+    nb = [torch.tensor(7, device=DEV, dtype=torch.int64) for _ in range(2)]
+    m1, r1 = L.bn_stats_from_partials(part, rows, C_, cnt, 1e-5, 0.1, rm[0], rv[0], nb[0])
+    m2, r2 = L.bn_stats(y, 1e-5, 0.1, rm[1], rv[1], nb[1])
+    close(m1, m2, 2e-6, "mean"); close(r1, r2, 2e-5, "rstd")
+    close(rm[0], rm[1], 2e-6, "running mean"); close(rv[0], rv[1], 2e-5, "running var")
+    assert int(nb[0]) == int(nb[1]) == 8
+    with L.conv_flags(0):           # exact-fp32 kernels do not produce the rows: the caller falls back to agl_bn_stats
+        _, part0, rows0 = L.conv2d_fwd_stats(xd, wd, bd, stride, pad)
+    assert part0 is None and rows0 == 0
+
+
 FEW_BWW_CASES = [  # N, Cin, H, Cout, ks, pad, in_relu: weight gradients with <= 4 channels on one side (csrc/few.hip)
     (5, 3, 32, 64, 3, 1, 0), (4, 3, 32, 64, 1, 0, 0), (3, 3, 32, 64, 7, 3, 0), (2, 3, 64, 64, 3, 1, 1), (2, 3, 64, 80, 1, 0, 0),
     (2, 4, 32, 32, 3, 1, 0), (2, 1, 32, 48, 5, 2, 1), (1, 3, 128, 64, 5, 2, 0), (3, 2, 64, 128, 7, 3, 0), (2, 3, 32, 16, 3, 0, 0),
