@@ -1,11 +1,16 @@
 set -o pipefail
-mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "partials or pconv" > gpurun_out/t_st.log 2>&1; rc=$?; tail -15 gpurun_out/t_st.log
-if [ $rc -ne 0 ]; then exit $rc; fi
-timeout -k 10 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu > gpurun_out/t_st2.log 2>&1; rc=$?; tail -5 gpurun_out/t_st2.log
-if [ $rc -ne 0 ]; then exit $rc; fi
-for i in 1 2; do
-timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 8 --warmup 3 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'], d['roofline']['achieved'], d['roofline_hbm']['kernel_ms_per_step'], d['roofline_hbm']['launches_per_step'])" || exit 1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for cfg in "64:--dtype f32x3" "128:--res 128 --dtype bf16"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  for pass in "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+    pt=${pass%%:*}; ctr=${pass#*:}
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/hbm2_${pt}$tag -o run -- python3 $R/bench.py $fl --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/gpurun_out/hbm2_${pt}$tag.log 2>&1; rc=$?
+    if [ $rc -ne 0 ]; then tail -3 $R/gpurun_out/hbm2_${pt}$tag.log; exit $rc; fi
+  done
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/hbm2_t$tag -o run -- python3 $R/bench.py $fl --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/gpurun_out/hbm2_t$tag.log 2>&1; rc=$?
+  if [ $rc -ne 0 ]; then exit $rc; fi
 done
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/clk64 -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/gpurun_out/clk64.log 2>&1; rc=$?
+echo done $rc
+exit $rc
