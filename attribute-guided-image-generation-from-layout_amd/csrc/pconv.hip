@@ -497,8 +497,13 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
     }
   const int arow = (wave * 16 * RT + l15) * DPITCH + lg * 16;
 
-  for (int tile = t_beg; tile < t_end; ++tile) {
-    int img0, ty0, tx0;
+  // Register prefetch: the global loads of tile t+1 are issued before the MFMAs of tile t and converted / stored after them,
+  // so that the (HBM-latency-long) loads are not exposed between the two barriers of the staging phase.
+  constexpr int ND = BMCO * (NPX / 8), DR = (ND + NT - 1) / NT;          // dy items (output channel, 8 consecutive pixels)
+  constexpr int NXI = NQ * (BC / 8), XR = (NXI + NT - 1) / NT;           // x items (channel octet, patch pixel)
+  float4 pdy[DR][2];
+  float px[XR][8];
+  auto tile_origin = [&](int tile, int& img0, int& ty0, int& tx0) {
     if constexpr (TI == 1) {
       img0 = tile / tpi;
       const int t = tile - img0 * tpi;
@@ -506,27 +511,42 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
     } else {
       img0 = tile * TI; ty0 = 0; tx0 = 0;
     }
-    __syncthreads();                                   // everyone is done reading the previous tile
-    // ---- dy tile: item = (output channel, 8 consecutive pixels)
-    constexpr int ND = BMCO * (NPX / 8);
-#pragma unroll
-    for (int r = 0; r < (ND + NT - 1) / NT; ++r) {
-      const int e = tid + NT * r;
-      if (ND % NT != 0 && e >= ND) break;
+  };
+  auto gload_dy = [&](int img0, int ty0, int tx0, int r, int sl) {
+    {
+      const int e = min(tid + NT * r, ND - 1);
       const int co = e / (NPX / 8), oc = e - co * (NPX / 8);
-      const int j = 8 * oc, ti = j / (TH * TW), rr = j - ti * (TH * TW), py = rr / TW, px = rr - py * TW;
+      const int j = 8 * oc, ti = j / (TH * TW), rr = j - ti * (TH * TW), py = rr / TW, px_ = rr - py * TW;
       const int img = img0 + ti;
       const bool ok = co0 + co < p.Cout && img < p.N;
       // (16-byte buffer loads are not usable here: this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to ONE dword
       //  load; plain 16-byte global loads from a clamped, always-valid address + a select instead)
-      const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px) : 0;
+      const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px_) : 0;
       const float4 lo = *reinterpret_cast<const float4*>(p.dy + idx);
       const float4 hi = *reinterpret_cast<const float4*>(p.dy + idx + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      if (!ok) {
+      pdy[sl][0] = ok ? lo : float4{0.f, 0.f, 0.f, 0.f};
+      pdy[sl][1] = ok ? hi : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto gload_x = [&](int img0, int ty0, int tx0, int r, int sl) {
+    {
+      const int e = min(tid + NT * r, NXI - 1);
+      const int oc = e / NQ, q = e - oc * NQ;
+      const int ti = q / IMGP, r2 = q - ti * IMGP, yy = r2 / PW, xx = r2 - yy * PW;
+      const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
+      const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+      const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = 0.f;
-      }
+      for (int jj = 0; jj < 8; ++jj)
+        px[sl][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, (unsigned)jj * cstride, 0));
+    }
+  };
+  auto sstore_dy = [&](int r, int sl) {
+    {
+      const int e = tid + NT * r;
+      if (ND % NT != 0 && e >= ND) return;
+      const int co = e / (NPX / 8), oc = e - co * (NPX / 8);
+      const float v[8] = {pdy[sl][0].x, pdy[sl][0].y, pdy[sl][0].z, pdy[sl][0].w, pdy[sl][1].x, pdy[sl][1].y, pdy[sl][1].z, pdy[sl][1].w};
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -540,21 +560,16 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
         *reinterpret_cast<u32x4*>(dst + 2 * D_PLANE) = __builtin_bit_cast(u32x4, t2);
       }
     }
-    // ---- x patch: item = (channel octet, patch pixel)
-    constexpr int NXI = NQ * (BC / 8);
-#pragma unroll
-    for (int r = 0; r < (NXI + NT - 1) / NT; ++r) {
+  };
+  auto sstore_x = [&](int r, int sl) {
+    {
       const int e = tid + NT * r;
-      if (NXI % NT != 0 && e >= NXI) break;
+      if (NXI % NT != 0 && e >= NXI) return;
       const int oc = e / NQ, q = e - oc * NQ;
-      const int ti = q / IMGP, r2 = q - ti * IMGP, yy = r2 / PW, xx = r2 - yy * PW;
-      const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
-      const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-      const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, (unsigned)jj * cstride, 0));
+        float v = px[sl][jj];
         if (p.in_relu) v = fmaxf(v, 0.f);
         if constexpr (NSPL == 1) { t0[jj] = (__bf16)v; }
         else { __bf16 a, b, d; split3(v, a, b, d); t0[jj] = a; t1[jj] = b; t2[jj] = d; }
@@ -566,7 +581,35 @@ __global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
         *reinterpret_cast<u32x4*>(dst + 2 * X_PLANE) = __builtin_bit_cast(u32x4, t2);
       }
     }
+  };
+
+  constexpr bool PREF = NSPL == 3 || RT * CT == 1;     // (the 2x2-fragment bf16 variants have no registers to spare)
+  auto gload = [&](int tile) {
+    int img0, ty0, tx0;
+    tile_origin(tile, img0, ty0, tx0);
+#pragma unroll
+    for (int r = 0; r < DR; ++r) gload_dy(img0, ty0, tx0, r, r);
+#pragma unroll
+    for (int r = 0; r < XR; ++r) gload_x(img0, ty0, tx0, r, r);
+  };
+  if (PREF && t_beg < t_end) gload(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    __syncthreads();                                   // everyone is done reading the previous tile
+    if constexpr (PREF) {
+#pragma unroll
+      for (int r = 0; r < DR; ++r) sstore_dy(r, r);
+#pragma unroll
+      for (int r = 0; r < XR; ++r) sstore_x(r, r);
+    } else {                                           // item by item through one register set
+      int img0, ty0, tx0;
+      tile_origin(tile, img0, ty0, tx0);
+#pragma unroll 2
+      for (int r = 0; r < DR; ++r) { gload_dy(img0, ty0, tx0, r, 0); sstore_dy(r, 0); }
+#pragma unroll 2
+      for (int r = 0; r < XR; ++r) { gload_x(img0, ty0, tx0, r, 0); sstore_x(r, 0); }
+    }
     __syncthreads();
+    if (PREF && tile + 1 < t_end) gload(tile + 1);
     // ---- 32 pixels per step
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
