@@ -453,7 +453,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // TSUB: taps per pass.  When 4*RT*CT*KS^2 accumulator registers (x2 in split mode) do not fit, the taps are processed in
 // ceil(KS^2/TSUB) passes by different workgroups (blockIdx.y = channel block * passes + pass), each staging the same tiles.
 template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS>
-__global__ __launch_bounds__(NT, 2) void pbww_k(WArgs p) {
+__global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
   static_assert((NPX == 128 || NPX == 64) && TW >= 8, "pbww geometry");
@@ -904,7 +904,9 @@ static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, 
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
   *rt = (a.nsplit == 1 && a.ks != 5 && a.Cout > 64) ? 2 : 1;
   *ct = (a.nsplit == 1 && a.ks == 3 && a.Cin % 32 == 0) ? 2 : 1;
-  const int npass = (a.nsplit == 3 && a.ks == 5) ? 2 : 1;      // 25 taps in split mode: 13 + 12
+  // (5x5 in split mode: 25 taps x 2 accumulator sets = 200 registers — one workgroup per CU with the accumulators in AGPRs, all
+  //  taps in one pass: 2.43 -> 1.87 ms on the ConvLSTM layer against two passes of 13 + 12 taps that stage every tile twice)
+  const int npass = 1;
   const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
   long z = (768 + blocks - 1) / blocks;       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
   if (z > tiles) z = tiles;
@@ -930,7 +932,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
-  const int npass = (a.nsplit == 3 && a.ks == 5) ? 2 : 1;
+  const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
 #define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
@@ -949,9 +951,9 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
   else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
   else {
-    if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
-    else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 13>), g, dim3(NT), 0, st, p);
+    if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
   }
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
