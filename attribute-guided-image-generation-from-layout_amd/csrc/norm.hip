@@ -6,6 +6,7 @@
 //   mode 2: y = xhat*T[lab[n]][c] + T[lab[n]][C+c]   (ConditionalBatchNorm2d, table T[V][2C])
 //   mode 3: y = xhat*(1+gb[n][c][hw]) + gb[n][C+c][hw]   (SPADE, gb = [gamma;beta] conv output)
 #include "agl_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -21,26 +22,68 @@ __device__ __forceinline__ float group_sum(float v, float* scratch4) {
 }
 
 // ---------------------------------------------------------------- statistics
+// Partial sums over a contiguous range of the channel's elements.  With HW % 4 == 0 the range is walked in 16-byte pieces
+// (a channel row is HW contiguous floats, 16-byte aligned); the sums are accumulated in double either way.
+__device__ __forceinline__ void channel_moments(const float* __restrict__ x, int C, int HW, int c, long e0, long e1, double& a, double& b) {
+  a = 0.0; b = 0.0;
+  if ((HW & 3) == 0) {
+    const int Q = HW >> 2;
+    for (long g = (e0 >> 2) + threadIdx.x; g < (e1 >> 2); g += 256) {
+      const int n = (int)(g / Q), q = (int)(g - (long)n * Q);
+      const float4 v = *reinterpret_cast<const float4*>(x + ((long)n * C + c) * HW + 4 * q);
+      a += (double)((v.x + v.y) + (v.z + v.w));
+      b += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+      const int n = (int)(e / HW), hw = (int)(e - (long)n * HW);
+      const float v = x[((long)n * C + c) * HW + hw];
+      a += v;
+      b += (double)v * v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int N, int C, int HW, int S,
                                                         double* __restrict__ part) {
   const int c = blockIdx.x, s = blockIdx.y;
   const long total = (long)N * HW;
-  const long chunk = (total + S - 1) / S;
-  const long e0 = s * chunk, e1 = min(total, e0 + chunk);
-  double a = 0.0, b = 0.0;
-  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-    int n = (int)(e / HW);
-    int hw = (int)(e - (long)n * HW);
-    float v = x[((long)n * C + c) * HW + hw];
-    a += v;
-    b += (double)v * v;
-  }
+  long chunk = (total + S - 1) / S;
+  chunk = (chunk + 3) & ~3L;                               // whole 16-byte pieces per split
+  const long e0 = min(total, s * chunk), e1 = min(total, e0 + chunk);
+  double a, b;
+  channel_moments(x, C, HW, c, e0, e1, a, b);
   __shared__ double sc[4];
   a = block_sum_256(a, sc);
   b = block_sum_256(b, sc);
   if (threadIdx.x == 0) {
     part[((long)c * S + s) * 2 + 0] = a;
     part[((long)c * S + s) * 2 + 1] = b;
+  }
+}
+
+// Small tensors (one workgroup per channel covers them): statistics and the running update in ONE launch
+__global__ __launch_bounds__(256) void bn_stats_single(const float* __restrict__ x, int N, int C, int HW, float eps, float momentum,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                                       float* __restrict__ rvar, long long* __restrict__ nbt) {
+  const int c = blockIdx.x;
+  const long M = (long)N * HW;
+  double a, b;
+  channel_moments(x, C, HW, c, 0, M, a, b);
+  __shared__ double sc[4];
+  a = block_sum_256(a, sc);
+  b = block_sum_256(b, sc);
+  if (threadIdx.x != 0) return;
+  if (c == 0 && nbt) *nbt += 1;
+  const double mu = a / (double)M;
+  double var = b / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
 }
 
@@ -261,14 +304,19 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
                  void* stream) {
   AGL_REQUIRE(x && mean && rstd && N > 0 && C > 0 && HW > 0, "agl_bn_stats: bad argument");
   const long total = (long)N * HW;
-  int S = (int)((total + 4095) / 4096);
-  if (S > 64) S = 64;
-  if (S < 1) S = 1;
+  hipStream_t st = (hipStream_t)stream;
+  // splits: enough workgroups to fill the chip (C x S >= ~1024), at least 2048 elements each
+  int S = (int)std::min<long>(std::min<long>(64, (1024 + C - 1) / C), std::max<long>(1, total / 2048));
+  if (S <= 1) {
+    hipLaunchKernelGGL(bn_stats_single, dim3(C), dim3(256), 0, st, x, N, C, HW, eps, momentum, mean, rstd, running_mean, running_var,
+                       num_batches_tracked);
+    AGL_CHECK_LAUNCH("agl_bn_stats(single)");
+    return AGL_OK;
+  }
   if (!ws || ws_bytes < (long)C * S * 2 * (long)sizeof(double)) {
     agl_set_error("agl_bn_stats: workspace too small");
     return AGL_ERR_WORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(C, S), dim3(256), 0, st, x, N, C, HW, S, (double*)ws);
   AGL_CHECK_LAUNCH("agl_bn_stats(partial)");
   hipLaunchKernelGGL(bn_stats_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S, total, eps,

@@ -258,20 +258,39 @@ __global__ void sum_hw_bwd_k(const float* __restrict__ dy, const float* __restri
   dx[i] = v;
 }
 
-// out[c] = sum_{n,hw} x[n,c,hw]   (bias gradients): (C x S) partial blocks, then a fixed-order finish -> deterministic
-__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, double* __restrict__ part, int N, int C, int HW, int S) {
+// out[c] = sum_{n,hw} x[n,c,hw]   (bias gradients): (C x S) partial blocks, then a fixed-order finish -> deterministic.
+// HW % 4 == 0: 16-byte pieces of the channel rows; S == 1 (small tensors / many channels): one launch writes the result.
+__device__ __forceinline__ double channel_range_sum(const float* __restrict__ x, int C, int HW, int c, long e0, long e1) {
+  double s = 0.0;
+  if ((HW & 3) == 0) {
+    const int Q = HW >> 2;
+    for (long g = (e0 >> 2) + threadIdx.x; g < (e1 >> 2); g += 256) {
+      const int n = (int)(g / Q), q = (int)(g - (long)n * Q);
+      const float4 v = *reinterpret_cast<const float4*>(x + ((long)n * C + c) * HW + 4 * q);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    }
+  } else {
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+      const long n = e / HW, hw = e - n * HW;
+      s += x[(n * C + c) * HW + hw];
+    }
+  }
+  return s;
+}
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, double* __restrict__ part, float* __restrict__ out,
+                                                           int N, int C, int HW, int S, int accumulate) {
   __shared__ double sc[4];
   const int c = blockIdx.x, sl = blockIdx.y;
   const long total = (long)N * HW;
-  const long chunk = (total + S - 1) / S;
-  const long e0 = sl * chunk, e1 = min(total, e0 + chunk);
-  double s = 0.0;
-  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-    const long n = e / HW, hw = e - n * HW;
-    s += x[(n * C + c) * HW + hw];
-  }
+  long chunk = (total + S - 1) / S;
+  chunk = (chunk + 3) & ~3L;
+  const long e0 = min(total, sl * chunk), e1 = min(total, e0 + chunk);
+  double s = channel_range_sum(x, C, HW, c, e0, e1);
   s = block_sum_256(s, sc);
-  if (threadIdx.x == 0) part[(long)c * S + sl] = s;
+  if (threadIdx.x == 0) {
+    if (S == 1) out[c] = accumulate ? out[c] + (float)s : (float)s;
+    else part[(long)c * S + sl] = s;
+  }
 }
 __global__ void channel_sum_final(const double* __restrict__ part, float* __restrict__ out, int C, int S, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,17 +763,20 @@ long agl_channel_sum_ws_bytes(int C) { return (long)C * 64 * sizeof(double); }
 int agl_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* ws, long ws_bytes, void* stream) {
   AGL_REQUIRE(x && out && N > 0 && C > 0 && HW > 0, "agl_channel_sum: bad argument");
   const long total = (long)N * HW;
-  int S = (int)((total + 4095) / 4096);
+  long S = (1024 + C - 1) / C;                              // C x S >= ~1024 workgroups, at least 2048 elements each
+  if (S > total / 2048) S = total / 2048;
   if (S > 64) S = 64;
   if (S < 1) S = 1;
-  if (!ws || ws_bytes < (long)C * S * (long)sizeof(double)) {
+  if (S > 1 && (!ws || ws_bytes < (long)C * S * (long)sizeof(double))) {
     agl_set_error("agl_channel_sum: workspace too small");
     return AGL_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL(channel_sum_partial, dim3(C, S), dim3(256), 0, (hipStream_t)stream, x, (double*)ws, N, C, HW, S);
+  hipLaunchKernelGGL(channel_sum_partial, dim3(C, (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, (double*)ws, out, N, C, HW, (int)S, accumulate);
   AGL_CHECK_LAUNCH("agl_channel_sum(partial)");
-  hipLaunchKernelGGL(channel_sum_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, (const double*)ws, out, C, S, accumulate);
-  AGL_CHECK_LAUNCH("agl_channel_sum(final)");
+  if (S > 1) {
+    hipLaunchKernelGGL(channel_sum_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, (const double*)ws, out, C, (int)S, accumulate);
+    AGL_CHECK_LAUNCH("agl_channel_sum(final)");
+  }
   return AGL_OK;
 }
 

@@ -1,18 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
 AB=$PWD/attribute-guided-image-generation-from-layout_amd/agl/ab
-export AGL_LIBRARY=$AB/libagl_onepass.so
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "pconv" > gpurun_out/t_pf.log 2>&1; rc=$?; tail -2 gpurun_out/t_pf.log
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu > gpurun_out/t_cs.log 2>&1; rc=$?; tail -3 gpurun_out/t_cs.log
 if [ $rc -ne 0 ]; then exit $rc; fi
-export AGL_SPLIT3=1
-for v in base onepass; do
-  if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
-  timeout -k 10 200 python tools/conv_bench.py " k5 " > gpurun_out/cb_${v}_split.txt 2>&1 || exit 1
-done
-unset AGL_SPLIT3
-for v in base onepass base onepass; do
+for v in old base old base; do
   if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 8 --warmup 3 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'])" || exit 1
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'], d['roofline_hbm']['kernel_ms_per_step'], d['roofline_hbm']['achieved'])" || exit 1
 done
