@@ -184,32 +184,50 @@ __global__ void scatter_rows_k(const float* __restrict__ src, const long long* _
 }
 
 // 2x2 average pool, optional ReLU on the input (models/discriminator.py:25-26 and the in-place ReLU of :71)
+// (index arithmetic in 32 bits: the entry points bound every tensor below 2^31 elements; 64-bit div/mod per element made
+//  these kernels instruction-bound at half the HBM rate)
 __global__ void avgpool2_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int in_relu) {
-  const int OH = H / 2, OW = W / 2;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * OH * OW) return;
-  const int ow = (int)(i % OW);
-  long t = i / OW;
-  const int oh = (int)(t % OH);
-  const long nc = t / OH;
-  const float* p = x + nc * H * W + (long)(2 * oh) * W + 2 * ow;
+  const unsigned OH = H / 2, OW = W / 2;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * OH * OW)) return;
+  const unsigned ow = i % OW, t = i / OW, oh = t % OH, nc = t / OH;
+  const float* p = x + (long)nc * H * W + (long)(2 * oh) * W + 2 * ow;
   float a = p[0], b = p[1], c = p[W], d = p[W + 1];
   if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); c = fmaxf(c, 0.f); d = fmaxf(d, 0.f); }
   y[i] = (a + b + c + d) * 0.25f;
 }
 // dx = 0.25*dy broadcast over the 2x2 window (masked by x>0 when in_relu); accumulate: dx += ...
 __global__ void avgpool2_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long NC, int H, int W, int in_relu, int accumulate) {
-  const int OH = H / 2, OW = W / 2;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * H * W) return;
-  const int w = (int)(i % W);
-  long t = i / W;
-  const int h = (int)(t % H);
-  const long nc = t / H;
+  const unsigned OH = H / 2, OW = W / 2;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W)) return;
+  const unsigned w = i % W, t = i / W, h = t % H, nc = t / H;
   float v = 0.f;
-  if (h < 2 * OH && w < 2 * OW) v = 0.25f * dy[nc * OH * OW + (long)(h / 2) * OW + w / 2];
+  if (h < 2 * OH && w < 2 * OW) v = 0.25f * dy[(long)nc * OH * OW + (long)(h / 2) * OW + w / 2];
   if (in_relu && !(x[i] > 0.f)) v = 0.f;
   dx[i] = accumulate ? dx[i] + v : v;
+}
+// the same for W % 4 == 0: four consecutive columns per thread (16-byte accesses of x / dx, one 8-byte read of dy)
+__global__ void avgpool2_bwd4_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long NC, int H, int W, int in_relu, int accumulate) {
+  const unsigned OW = W / 2, W4 = W / 4;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W4)) return;
+  const unsigned w4 = i % W4, t = i / W4, h = t % H, nc = t / H;
+  const float2 d = *reinterpret_cast<const float2*>(dy + (long)nc * (H / 2) * OW + (long)(h / 2) * OW + 2 * w4);
+  float4 v = {0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y};
+  const long o = 4L * i;
+  if (in_relu) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + o);
+    if (!(xv.x > 0.f)) v.x = 0.f;
+    if (!(xv.y > 0.f)) v.y = 0.f;
+    if (!(xv.z > 0.f)) v.z = 0.f;
+    if (!(xv.w > 0.f)) v.w = 0.f;
+  }
+  if (accumulate) {
+    const float4 ov = *reinterpret_cast<const float4*>(dx + o);
+    v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+  }
+  *reinterpret_cast<float4*>(dx + o) = v;
 }
 
 // nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
@@ -588,27 +606,25 @@ __global__ __launch_bounds__(256) void deprocess_u8_k(const float* __restrict__ 
 // j, i in [0, H] x [0, W] (out-of-range x = 0).  avg_pool2(conv3x3(x, pad 1)) equals a 3x3 STRIDE-2 convolution without
 // padding of xb (agl.functional.conv3x3_avgpool2): 9 taps per output instead of the 16 of the fused 4x4 form.
 __global__ void box2_fwd_k(const float* __restrict__ x, float* __restrict__ xb, long NC, int H, int W) {
-  const int HB = H + 1, WB = W + 1;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * HB * WB) return;
-  const int ix = (int)(i % WB), iy = (int)(i / WB % HB);
-  const long nc = i / ((long)WB * HB);
-  const float* p = x + nc * H * W;
+  const unsigned HB = H + 1, WB = W + 1;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * HB * WB)) return;
+  const unsigned ix = i % WB, t = i / WB, iy = t % HB, nc = t / HB;
+  const float* p = x + (long)nc * H * W;
   float s = 0.f;
   if (iy > 0 && ix > 0) s += p[(iy - 1) * W + ix - 1];
-  if (iy > 0 && ix < W) s += p[(iy - 1) * W + ix];
-  if (iy < H && ix > 0) s += p[iy * W + ix - 1];
-  if (iy < H && ix < W) s += p[iy * W + ix];
+  if (iy > 0 && ix < (unsigned)W) s += p[(iy - 1) * W + ix];
+  if (iy < (unsigned)H && ix > 0) s += p[iy * W + ix - 1];
+  if (iy < (unsigned)H && ix < (unsigned)W) s += p[iy * W + ix];
   xb[i] = 0.25f * s;
 }
 // dx[j][i] = (dxb[j][i] + dxb[j][i+1] + dxb[j+1][i] + dxb[j+1][i+1]) / 4, optionally masked by mask > 0 (ReLU backward)
 __global__ void box2_bwd_k(const float* __restrict__ dxb, const float* __restrict__ mask, float* __restrict__ dx, long NC, int H, int W) {
-  const int WB = W + 1;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * H * W) return;
-  const int ix = (int)(i % W), iy = (int)(i / W % H);
-  const long nc = i / ((long)W * H);
-  const float* p = dxb + nc * (H + 1) * WB + (long)iy * WB + ix;
+  const unsigned WB = W + 1;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W)) return;
+  const unsigned ix = i % W, t = i / W, iy = t % H, nc = t / H;
+  const float* p = dxb + (long)nc * (H + 1) * WB + (long)iy * WB + ix;
   float v = 0.25f * (p[0] + p[1] + p[WB] + p[WB + 1]);
   if (mask && !(mask[i] > 0.f)) v = 0.f;
   dx[i] = v;
@@ -717,15 +733,16 @@ int agl_scatter_rows(const float* src, const long long* rows, float* out, long R
 }
 
 int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream) {
-  AGL_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2, "agl_avgpool2_fwd: bad argument");
+  AGL_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2 && NC * H * W < (1L << 31), "agl_avgpool2_fwd: bad argument");
   LAUNCH1D(avgpool2_fwd_k, NC * (H / 2) * (W / 2), x, y, NC, H, W, in_relu);
   AGL_CHECK_LAUNCH("agl_avgpool2_fwd");
   return AGL_OK;
 }
 
 int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate, void* stream) {
-  AGL_REQUIRE(dy && dx && (!in_relu || x) && NC > 0 && H >= 2 && W >= 2, "agl_avgpool2_bwd: bad argument");
-  LAUNCH1D(avgpool2_bwd_k, NC * H * W, dy, x, dx, NC, H, W, in_relu, accumulate);
+  AGL_REQUIRE(dy && dx && (!in_relu || x) && NC > 0 && H >= 2 && W >= 2 && NC * H * W < (1L << 31), "agl_avgpool2_bwd: bad argument");
+  if (W % 4 == 0 && H % 2 == 0) LAUNCH1D(avgpool2_bwd4_k, NC * H * (W / 4), dy, x, dx, NC, H, W, in_relu, accumulate);
+  else LAUNCH1D(avgpool2_bwd_k, NC * H * W, dy, x, dx, NC, H, W, in_relu, accumulate);
   AGL_CHECK_LAUNCH("agl_avgpool2_bwd");
   return AGL_OK;
 }
@@ -913,14 +930,14 @@ int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, i
 }
 
 int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream) {
-  AGL_REQUIRE(x && xb && NC > 0 && H > 0 && W > 0, "agl_box2_fwd: bad argument");
+  AGL_REQUIRE(x && xb && NC > 0 && H > 0 && W > 0 && NC * (H + 1) * (W + 1) < (1L << 31), "agl_box2_fwd: bad argument");
   LAUNCH1D(box2_fwd_k, NC * (H + 1) * (W + 1), x, xb, NC, H, W);
   AGL_CHECK_LAUNCH("agl_box2_fwd");
   return AGL_OK;
 }
 
 int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H, int W, void* stream) {
-  AGL_REQUIRE(dxb && dx && NC > 0 && H > 0 && W > 0, "agl_box2_bwd: bad argument");
+  AGL_REQUIRE(dxb && dx && NC > 0 && H > 0 && W > 0 && NC * (H + 1) * (W + 1) < (1L << 31), "agl_box2_bwd: bad argument");
   LAUNCH1D(box2_bwd_k, NC * H * W, dxb, mask, dx, NC, H, W);
   AGL_CHECK_LAUNCH("agl_box2_bwd");
   return AGL_OK;
