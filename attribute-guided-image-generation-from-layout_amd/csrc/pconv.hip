@@ -724,7 +724,11 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   else ptiles = (long)a.N * (oh / 8) * (ow / 8);
   // no reduction split in this kernel: a grid that cannot occupy most CUs runs one long serial K loop per workgroup and is
   // slower than the split-K im2col / position-major kernels (ConvLSTM recurrence steps over the few images still active)
-  if (ptiles * agl_cdiv(a.Cout, bm) < 200 && !a.any_grid) return -1;
+  // (measured on the ConvLSTM recurrence steps, 128 -> 512 5x5 on 8x8 maps: with a short reduction — <= 256 (chunk, tap) steps —
+  //  the kernel still wins down to ~100 workgroups: 48 images 0.150 -> 0.099 ms, 32 images 0.110 -> 0.094 ms, 16 images slower)
+  const long wgs = ptiles * agl_cdiv(a.Cout, bm);
+  const bool short_k = (long)(a.Cin / 16) * a.ks * a.ks <= 256;
+  if (wgs < 200 && !(short_k && wgs >= 96) && !a.any_grid) return -1;
   pl.geo = geo; pl.bm = bm; pl.s2 = s2; pl.w32 = w32; pl.wide = wide; pl.half = half; pl.ptiles = ptiles; pl.oh = oh; pl.ow = ow;
   return 0;
 }

@@ -14,6 +14,8 @@ if os.environ.get("AGL_POS_ALL"):
     L.CONV_FLAGS |= L.CONV_POS_ALL_KS
 if os.environ.get("AGL_NOPOS"):
     L.CONV_FLAGS |= L.CONV_NO_POS
+if os.environ.get("AGL_ANYGRID"):
+    L.CONV_FLAGS |= L.CONV_ANY_GRID
 if os.environ.get("AGL_SPLIT3"):
     L.CONV_FLAGS |= L.CONV_SPLIT3
 if os.environ.get("AGL_PREC"):
@@ -26,6 +28,12 @@ SHAPES = [
     ("LE.c4 256>512 k4s2 @16", O, 256, 16, 512, 4, 2, 1),
     ("CLSTM0.x 512>512 k5 @8", O, 512, 8, 512, 5, 1, 2),
     ("CLSTM0.h 128>512 k5 @8 (B=64)", N, 128, 8, 512, 5, 1, 2),
+    ("CLSTM0.h 128>512 k5 @8 (B=48)", 48, 128, 8, 512, 5, 1, 2),
+    ("CLSTM0.h 128>512 k5 @8 (B=32)", 32, 128, 8, 512, 5, 1, 2),
+    ("CLSTM0.h 128>512 k5 @8 (B=16)", 16, 128, 8, 512, 5, 1, 2),
+    ("CLSTM0.h 128>512 k5 @8 (B=8)", 8, 128, 8, 512, 5, 1, 2),
+    ("CLSTM1.h 64>256 k5 @8 (B=32)", 32, 64, 8, 256, 5, 1, 2),
+    ("RES 64>64 k3 @8 (B=64)", 64, 64, 8, 64, 3, 1, 1),
     ("CLSTM1.x 128>256 k5 @8", O, 128, 8, 256, 5, 1, 2),
     ("CLSTM1.h 64>256 k5 @8 (B=64)", N, 64, 8, 256, 5, 1, 2),
     ("CE.c1 3>64 k7 @32", O, 3, 32, 64, 7, 1, 3),
