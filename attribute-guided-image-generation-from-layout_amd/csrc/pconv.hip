@@ -891,9 +891,20 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
-static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, int* rt, int* ct, int* half_out) {
+static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out, int* rt, int* ct, int* half_out, int* oh_out = nullptr,
+                     int* ow_out = nullptr) {
+  PBwwArgs a = a0;
   const bool s2 = a.stride == 2;
-  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0 : !(a.stride == 1 && (a.ks == 3 || a.ks == 5))) return -1;
+  if (s2 ? !((a.ks == 4 && a.pad == 1) || (a.ks == 3 && a.pad == 0)) || a.up != 0
+         : !(a.stride == 1 && (a.ks == 3 || a.ks == 5 || (a.ks == 1 && a.pad == 0 && a.up == 0)))) return -1;
+  if (a.ks == 1) {      // no spatial structure: the map is re-read as (HW/16) x 16, or as it is when 8 x 8 (cf. pconv_plan)
+    const int hw = a.OH * a.OW;
+    if (a.H != a.OH || a.W != a.OW) return -1;
+    if (hw % 128 == 0) { a.OW = a.W = 16; a.OH = a.H = hw / 16; }
+    else if (hw != 64) return -1;
+    else { a.OW = a.W = 8; a.OH = a.H = 8; }
+  }
+  if (oh_out) { *oh_out = a.OH; *ow_out = a.OW; }
   if (a.Cin % 16 != 0 || a.Cout < 32) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
@@ -907,7 +918,7 @@ static int pbww_plan(const PBwwArgs& a, int* splits, int* tps, long* tiles_out, 
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
   *rt = (a.nsplit == 1 && a.ks != 5 && a.Cout > 64) ? 2 : 1;
-  *ct = (a.nsplit == 1 && a.ks == 3 && a.Cin % 32 == 0) ? 2 : 1;
+  *ct = ((a.nsplit == 1 && a.ks == 3) || a.ks == 1) && a.Cin % 32 == 0 ? 2 : 1;   // (1x1: staging-bound — dy is read once per 32 input channels)
   // (5x5 in split mode: 25 taps x 2 accumulator sets = 200 registers — one workgroup per CU with the accumulators in AGPRs, all
   //  taps in one pass: 2.43 -> 1.87 ms on the ConvLSTM layer against two passes of 13 + 12 taps that stage every tile twice)
   const int npass = 1;
@@ -928,12 +939,13 @@ long pbww_ws_bytes(const PBwwArgs& a) {
 }
 
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
-  int splits, tps, rt, ct, half; long tiles;
-  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half) != 0) return -1;
+  int splits, tps, rt, ct, half, oh, ow; long tiles;
+  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return -1;
   const long n = (long)a.Cout * a.Cin * a.ks * a.ks;
   if (!ws || ws_bytes < (long)splits * n * 4) return -1;
   WArgs p;
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
+  if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
@@ -949,6 +961,10 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
     else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 2, 1, 1);
            else if (ct == 2) PW_LAUNCH(3, 2, 1, 2, 1); else PW_LAUNCH(3, 2, 1, 1, 1); }
+  } else if (a.ks == 1) {
+    if (a.nsplit == 3) { if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 3); else PW_LAUNCH(1, 1, 1, 1, 3); }
+    else if (rt == 2 && ct == 2) PW_LAUNCH(1, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(1, 1, 2, 1, 1);
+    else if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 1); else PW_LAUNCH(1, 1, 1, 1, 1);
   } else if (a.ks == 3 && a.nsplit == 1) {
     if (rt == 2 && ct == 2) PW_LAUNCH(3, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 1, 2, 1, 1);
     else if (ct == 2) PW_LAUNCH(3, 1, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1, 1);
