@@ -713,6 +713,9 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   // 1x1: bandwidth-bound — read the input once per 128 output channels where that still leaves a workgroup per CU
   if (a.ks == 1 && a.Cout > 64 && px128 * agl_cdiv(a.Cout, 128) >= 256) bm = 128;
+  // 3x3 split mode: 128 output channels per workgroup (one kernel row of weights per stage) halve the conversions and patch
+  // reads per MFMA where the grid stays full: -3..-13 % per layer
+  if (a.nsplit == 3 && !s2 && a.ks == 3 && geo != 2 && a.Cout >= 128 && px128 * agl_cdiv(a.Cout, 128) >= 512) bm = 128;
   const bool w32 = ow % 32 == 0 && a.ks != 1;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
   bool wide = !s2 && geo != 3 && a.ks != 1 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
   if (geo == 0 && wide && !w32 && oh % 16 != 0) wide = false;
@@ -816,6 +819,12 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
     } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
+    else if (bm == 128) {
+      if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, 3, 3);
+      else if (geo == 0 && w32) PC_LAUNCH(3, 1, 32, 4, 1, 128, 3, 3);
+      else if (geo == 0) PC_LAUNCH(3, 1, 16, 8, 1, 128, 3, 3);
+      else PC_LAUNCH(3, 1, 8, 8, 2, 128, 3, 3);
+    }
     else PC_SHAPES3(3, 9);
   } else {
     if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
