@@ -717,7 +717,8 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   // reads per MFMA where the grid stays full: -3..-13 % per layer
   if (a.nsplit == 3 && !s2 && a.ks == 3 && geo != 2 && a.Cout >= 128 && px128 * agl_cdiv(a.Cout, 128) >= 512) bm = 128;
   const bool w32 = ow % 32 == 0 && a.ks != 1;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
-  bool wide = !s2 && geo != 3 && a.ks != 1 && a.nsplit == 1 && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  // 256-pixel tiles: bf16 mode, and the 64-channel 3x3 layers of the split mode (one kernel row of weights per stage; -2..-12 %)
+  bool wide = !s2 && geo != 3 && a.ks != 1 && (a.nsplit == 1 || (a.ks == 3 && bm == 64 && geo == 0)) && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
   if (geo == 0 && wide && !w32 && oh % 16 != 0) wide = false;
   const bool half = s2 && a.nsplit == 3;           // 64-pixel tiles
   long ptiles;
@@ -819,6 +820,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
     } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
+    else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, 3, 3); else PC_LAUNCH(3, 1, 16, 16, 1, 64, 3, 3); }
     else if (bm == 128) {
       if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, 3, 3);
       else if (geo == 0 && w32) PC_LAUNCH(3, 1, 32, 4, 1, 128, 3, 3);
