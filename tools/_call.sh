@@ -1,16 +1,16 @@
 set -o pipefail
 mkdir -p gpurun_out
 AB=$PWD/attribute-guided-image-generation-from-layout_amd/agl/ab
-export AGL_LIBRARY=$AB/libagl_pt.so
+export AGL_LIBRARY=$AB/libagl_ms16.so
 timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "pconv" > gpurun_out/t_pf.log 2>&1; rc=$?; tail -2 gpurun_out/t_pf.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 export AGL_SPLIT3=1
-for v in base pt; do
+for v in base ms16; do
   if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
-  timeout -k 10 200 python tools/conv_bench.py "k4s2" > gpurun_out/cb_${v}_split.txt 2>&1 || exit 1
+  timeout -k 10 200 python tools/conv_bench.py " k3 @" > gpurun_out/cb_${v}_split.txt 2>&1 || exit 1
 done
 unset AGL_SPLIT3
-for v in base pt base pt; do
+for v in base ms16 base ms16; do
   if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 8 --warmup 3 2>/dev/null | python -c "
 import json,sys
