@@ -118,17 +118,23 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false>
 __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   static_assert(!PHS || (KS == 2 && S == 1 && TG == 4), "phase mode");
+  // PAIR (phase mode, tiles >= 4 wide): one workgroup evaluates BOTH column phases pw = 0, 1 of its row phase — they share the
+  // dy patch (one more column) and their outputs interleave to 16-byte stores of the twice-as-wide row instead of stride-2
+  // 4-byte stores from two workgroups (which also made every output line a partial write: 1.85x the bytes at the HBM)
+  constexpr bool PAIR = PHS && TW >= 4;
+  constexpr int NPW = PAIR ? 2 : 1, TGA = PAIR ? 2 * TG : TG;      // column phases per workgroup; taps staged per stage
   constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = PHS ? 1 : KK / TG, KKW = PHS ? 16 : KK;
   static_assert((BN == 64 || BN == 128 || BN == 256) && (TG == KK || TG == KS) && (S == 1 || S == 2), "pconv geometry");
-  constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;
-  using PitchT = typename PitchSel<S, TW, KS, NSPL>::type;
+  constexpr int KSX = PAIR ? 3 : KS;           // patch columns per output column
+  constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KSX;
+  using PitchT = typename PitchSel<S, TW, KSX, NSPL>::type;
   constexpr int PWP = PitchT::PWP;             // row pitch (of a parity plane when S == 2)
   static_assert(S * PWP >= PW, "pitch");
   constexpr int IMGP = PH * PWP + PitchT::IMG_EXTRA;
   constexpr int PAR = TI * IMGP;               // pieces per parity plane
   constexpr int NQ = S * PAR;
   constexpr int P_PLANE = 2 * NQ;              // 16-byte pieces per plane: [h][q]
-  constexpr int A_PLANE = 2 * TG * BM;         //                           [h][t][row]
+  constexpr int A_PLANE = 2 * TGA * BM;        //                           [h][t][row]
   constexpr int NB = 2 * TI * PH * PW, BR = (NB + NT - 1) / NT;
   constexpr int NA = NSPL * A_PLANE, AR = (NA + NT - 1) / NT;
   constexpr int WTM = BM / 64, WTN = BN / 64;   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/2 pixels)
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
   const int bm0 = blockIdx.y * BM;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const int phase = PHS ? (int)blockIdx.z : 0, ph_y = phase >> 1, ph_x = phase & 1;
-  const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? 1 - ph_x : p.pad;
+  const int phase = PHS ? (PAIR ? 2 * (int)blockIdx.z : (int)blockIdx.z) : 0, ph_y = phase >> 1, ph_x = phase & 1;
+  const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? (PAIR ? 1 : 1 - ph_x) : p.pad;
 
   // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
   // the stage term is wave-uniform and travels in the scalar offset of the loads: no per-load vector arithmetic)
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   for (int r = 0; r < AR; ++r) {
     const int e = min(tid + NT * r, NA - 1);
     const int plane = e / A_PLANE, r1 = e - plane * A_PLANE;
-    const int h = r1 / (TG * BM), r2 = r1 - h * (TG * BM), t = r2 / BM, row = r2 - t * BM;
+    const int h = r1 / (TGA * BM), r2 = r1 - h * (TGA * BM), t = r2 / BM, row = r2 - t * BM;
     asrc[r] = (unsigned)((((plane * p.nch) * 2 + h) * KKW + t) * p.mpad + bm0 + row);
   }
 
@@ -238,17 +244,20 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
     qlane[jt] = lh * NQ + ti * IMGP + S * py * PWP + px;
   }
-  const int arow = lh * (TG * BM) + wm * (BM / 2) + l31;
+  const int arow = lh * (TGA * BM) + wm * (BM / 2) + l31;
 
-  f32x16 acc[NACC][WTM][WTN];
+  f32x16 accs[NPW][NACC][WTM][WTN];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a)
+  for (int w = 0; w < NPW; ++w)
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int j = 0; j < WTN; ++j)
+      for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] = 0.f;
+  auto& acc = accs[0];
 
   const int nstage = p.nch * NTG;      // stage s = (channel chunk s / NTG, tap group s % NTG)
   gload_b(0);
@@ -267,9 +276,10 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const u32x4* const Pc = Pl + (DBB ? (cc & 1) * PB : 0);
     const u32x4* const Ac = Al + (DBA ? (s & 1) * AB : 0);
 #pragma unroll
-    for (int t = 0; t < TG; ++t) {
+    for (int t = 0; t < TGA; ++t) {
       int toff;                                  // LDS piece offset of tap (kh, kw)
-      if constexpr (TG == KK) toff = (t / KS) * PWP + (S == 2 ? ((t % KS) & 1) * PAR + ((t % KS) >> 1) : (t % KS));
+      const int pw = PAIR ? t / TG : 0, tt = PAIR ? t % TG : t;      // (PAIR: taps 0..3 belong to column phase 0, 4..7 to phase 1)
+      if constexpr (TG == KK) toff = (tt / KS) * PWP + (S == 2 ? ((tt % KS) & 1) * PAR + ((tt % KS) >> 1) : (tt % KS)) + pw;
       else toff = tg * PWP + (S == 2 ? (t & 1) * PAR + (t >> 1) : t);
       (void)tg;
       bf16x8 fa[NSPL][WTM], fb[NSPL][WTN];
@@ -284,9 +294,9 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int jt = 0; jt < WTN; ++jt) {
-          acc[0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][jt], acc[0][i][jt], 0, 0, 0);
+          accs[pw][0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][jt], accs[pw][0][i][jt], 0, 0, 0);
           if constexpr (NSPL == 3) {      // the small terms (<= 2^-8 of the leading one) accumulate apart: their rounding errors
-            f32x16& lo = acc[NACC - 1][i][jt];   // are 2^-8 smaller and the leading chain sees one rounding per K-step
+            f32x16& lo = accs[pw][NACC - 1][i][jt];   // are 2^-8 smaller and the leading chain sees one rounding per K-step
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][jt], lo, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][jt], lo, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][jt], lo, 0, 0, 0);
@@ -304,11 +314,13 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
   if constexpr (NSPL == 3) {
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
+    for (int w = 0; w < NPW; ++w)
 #pragma unroll
-      for (int j = 0; j < WTN; ++j)
+      for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][i][j][r] += acc[1][i][j][r];
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[w][0][i][j][r] += accs[w][1][i][j][r];
   }
 
   // ---- epilogue.  D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel) — a lane holds 16
@@ -340,6 +352,50 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
       const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
+      if constexpr (PAIR) {       // both column phases: pixel (a, b..b+3) -> row 2a+ph, columns 2b .. 2b+7 — two 16-byte stores
+        float4 v1[4];
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) ep[((r2 & 3) + 8 * (r2 >> 2) + 4 * lh) * EP_PITCH + l31] = accs[NPW - 1][0][i][jt][r2];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) v1[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+        const long OHW2 = 4 * OHW;
+        const bool iok = img < p.N;
+        const long ob = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * (2 * p.OW) + 2 * (tx0 + px);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          if (m < p.Cout && iok) {
+            const float bb = p.bias ? p.bias[m] : 0.f;
+            float4 lo = {v[ps].x + bb, v1[ps].x + bb, v[ps].y + bb, v1[ps].y + bb};
+            float4 hi = {v[ps].z + bb, v1[ps].z + bb, v[ps].w + bb, v1[ps].w + bb};
+            float* dst = p.y + ob + (long)m * OHW2;
+            if (p.pos_mask) {
+              const float4 m0 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2);
+              const float4 m1 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2 + 4);
+              if (!(m0.x > 0.f)) lo.x = 0.f;
+              if (!(m0.y > 0.f)) lo.y = 0.f;
+              if (!(m0.z > 0.f)) lo.z = 0.f;
+              if (!(m0.w > 0.f)) lo.w = 0.f;
+              if (!(m1.x > 0.f)) hi.x = 0.f;
+              if (!(m1.y > 0.f)) hi.y = 0.f;
+              if (!(m1.z > 0.f)) hi.z = 0.f;
+              if (!(m1.w > 0.f)) hi.w = 0.f;
+            }
+            if (p.accumulate) {
+              const float4 o0 = *reinterpret_cast<const float4*>(dst), o1 = *reinterpret_cast<const float4*>(dst + 4);
+              lo.x += o0.x; lo.y += o0.y; lo.z += o0.z; lo.w += o0.w;
+              hi.x += o1.x; hi.y += o1.y; hi.z += o1.z; hi.w += o1.w;
+            }
+            if (p.relu) {
+              lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+              hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(dst) = lo;
+            *reinterpret_cast<float4*>(dst + 4) = hi;
+          }
+        }
+        continue;
+      }
       if constexpr (PHS) {        // pixel (a, b) of this phase -> (2a+ph, 2b+pw) of the 2*OH x 2*OW map: scalar accesses
         const long OHW2 = 4 * OHW;
         long pb2[4];
@@ -883,7 +939,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
-  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), 4);
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), geo == 3 ? 4 : 2);      // 2x2 maps: one workgroup per phase; else per row phase
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
 #define PT_GEO(BM_, NS_)                                          \
   do {                                                            \
