@@ -7,7 +7,7 @@ for m in split bf16; do
 for v in old base; do
   if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
   if [ $m = split ]; then export AGL_SPLIT3=1; unset AGL_PREC; else unset AGL_SPLIT3; export AGL_PREC=bf16; fi
-  timeout -k 10 200 python tools/conv_bench.py "k4s2" > gpurun_out/cb_${v}_${m}.txt 2>&1 || exit 1
+  timeout -k 10 200 python tools/conv_bench.py "" > gpurun_out/cb_${v}_${m}.txt 2>&1 || exit 1
 done
 done
 unset AGL_SPLIT3 AGL_PREC
