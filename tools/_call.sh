@@ -1,19 +1,26 @@
 set -o pipefail
 mkdir -p gpurun_out
-AB=$PWD/attribute-guided-image-generation-from-layout_amd/agl/ab
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "pconv or conv" > gpurun_out/t_pf.log 2>&1; rc=$?; tail -2 gpurun_out/t_pf.log
-if [ $rc -ne 0 ]; then grep -E "Error|assert|FAILED" gpurun_out/t_pf.log | head; exit $rc; fi
-for m in split bf16; do
-for v in old base; do
-  if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
-  if [ $m = split ]; then export AGL_SPLIT3=1; unset AGL_PREC; else unset AGL_SPLIT3; export AGL_PREC=bf16; fi
-  timeout -k 10 200 python tools/conv_bench.py "" > gpurun_out/cb_${v}_${m}.txt 2>&1 || exit 1
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2_t23.log 2>&1; rc=$?; tail -3 gpurun_out/r2_t23.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 500 python bench.py > gpurun_out/bench_r2k.log 2>&1; rc=$?; tail -1 gpurun_out/bench_r2k.log | cut -c1-200
+if [ $rc -ne 0 ]; then exit $rc; fi
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for cfg in "64_f32x3:--dtype f32x3" "64_f32:--dtype f32" "128_bf16:--res 128 --dtype bf16"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2k_$tag -o run -- python3 $R/bench.py $fl --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $R/gpurun_out/prof_r2k_$tag.log 2>&1; rc=$?
+  grep -o '"value": [0-9.]*' $R/gpurun_out/prof_r2k_$tag.log
+  if [ $rc -ne 0 ]; then exit $rc; fi
+  rm -f $R/gpurun_out/prof_r2k_$tag/run_kernel_trace.csv
 done
+for cfg in "64:--dtype f32x3" "128:--res 128 --dtype bf16"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  for pass in "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+    pt=${pass%%:*}; ctr=${pass#*:}
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/hbm4_${pt}$tag -o run -- python3 $R/bench.py $fl --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/gpurun_out/hbm4_${pt}$tag.log 2>&1; rc=$?
+    if [ $rc -ne 0 ]; then tail -3 $R/gpurun_out/hbm4_${pt}$tag.log; exit $rc; fi
+  done
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/hbm4_t$tag -o run -- python3 $R/bench.py $fl --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/gpurun_out/hbm4_t$tag.log 2>&1; rc=$?
+  if [ $rc -ne 0 ]; then exit $rc; fi
 done
-unset AGL_SPLIT3 AGL_PREC
-for v in old base old base; do
-  if [ $v = base ]; then unset AGL_LIBRARY; else export AGL_LIBRARY=$AB/libagl_$v.so; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 8 --warmup 3 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'])" || exit 1
-done
+echo all done
