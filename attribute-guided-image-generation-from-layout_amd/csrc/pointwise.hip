@@ -232,24 +232,18 @@ __global__ void avgpool2_bwd4_k(const float* __restrict__ dy, const float* __res
 
 // nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
 __global__ void upsample_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int k) {
-  const int OH = H << k, OW = W << k;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * OH * OW) return;
-  const int ow = (int)(i % OW);
-  long t = i / OW;
-  const int oh = (int)(t % OH);
-  const long nc = t / OH;
-  y[i] = x[nc * H * W + (long)(oh >> k) * W + (ow >> k)];
+  const unsigned OH = H << k, OW = W << k;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;        // (32-bit index arithmetic: tensors are bounded below 2^31 elements)
+  if (i >= (unsigned)(NC * OH * OW)) return;
+  const unsigned ow = i % OW, t = i / OW, oh = t % OH, nc = t / OH;
+  y[i] = x[(long)nc * H * W + (long)(oh >> k) * W + (ow >> k)];
 }
 __global__ void upsample_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, long NC, int H, int W, int k, int accumulate) {
   const int OH = H << k, OW = W << k, f = 1 << k;
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * H * W) return;
-  const int w = (int)(i % W);
-  long t = i / W;
-  const int h = (int)(t % H);
-  const long nc = t / H;
-  const float* p = dy + nc * OH * OW + (long)(h << k) * OW + (w << k);
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W)) return;
+  const unsigned w = i % W, t = i / W, h = t % H, nc = t / H;
+  const float* p = dy + (long)nc * OH * OW + (long)(h << k) * OW + (w << k);
   float s = 0.f;
   for (int a = 0; a < f; ++a)
     for (int b = 0; b < f; ++b) s += p[(long)a * OW + b];
@@ -635,19 +629,17 @@ __global__ void box2_bwd_k(const float* __restrict__ dxb, const float* __restric
 // [xlo[j], xlo[j+1]) — every cell has one owner and a fixed order (deterministic, no atomics).
 __global__ void grid_gather_fwd_k(const float* __restrict__ x, const int* __restrict__ my, const int* __restrict__ mx, float* __restrict__ y,
                                   long NC, int h, int w, int H, int W) {
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * H * W) return;
-  const int X = (int)(i % W), Y = (int)(i / W % H);
-  const long nc = i / ((long)W * H);
-  y[i] = x[(nc * h + my[Y]) * w + mx[X]];
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W)) return;
+  const unsigned X = i % W, t = i / W, Y = t % H, nc = t / H;
+  y[i] = x[((long)nc * h + my[Y]) * w + mx[X]];
 }
 __global__ void grid_gather_bwd_k(const float* __restrict__ dy, const int* __restrict__ ylo, const int* __restrict__ xlo, float* __restrict__ dx,
                                   long NC, int h, int w, int H, int W) {
-  const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NC * h * w) return;
-  const int xj = (int)(i % w), yi = (int)(i / w % h);
-  const long nc = i / ((long)w * h);
-  const float* p = dy + nc * H * W;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * h * w)) return;
+  const unsigned xj = i % w, t = i / w, yi = t % h, nc = t / h;
+  const float* p = dy + (long)nc * H * W;
   float s = 0.f;
   for (int Y = ylo[yi]; Y < ylo[yi + 1]; ++Y)
     for (int X = xlo[xj]; X < xlo[xj + 1]; ++X) s += p[(long)Y * W + X];
@@ -748,14 +740,14 @@ int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H,
 }
 
 int agl_upsample_nearest_fwd(const float* x, float* y, long NC, int H, int W, int log2_factor, void* stream) {
-  AGL_REQUIRE(x && y && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5, "agl_upsample_nearest_fwd: bad argument");
+  AGL_REQUIRE(x && y && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5 && NC * ((long)H << log2_factor) * ((long)W << log2_factor) < (1L << 31), "agl_upsample_nearest_fwd: bad argument");
   LAUNCH1D(upsample_fwd_k, NC * ((long)H << log2_factor) * ((long)W << log2_factor), x, y, NC, H, W, log2_factor);
   AGL_CHECK_LAUNCH("agl_upsample_nearest_fwd");
   return AGL_OK;
 }
 
 int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, int log2_factor, int accumulate, void* stream) {
-  AGL_REQUIRE(dy && dx && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5, "agl_upsample_nearest_bwd: bad argument");
+  AGL_REQUIRE(dy && dx && NC > 0 && H > 0 && W > 0 && log2_factor >= 0 && log2_factor <= 5 && NC * ((long)H << log2_factor) * ((long)W << log2_factor) < (1L << 31), "agl_upsample_nearest_bwd: bad argument");
   LAUNCH1D(upsample_bwd_k, NC * H * W, dy, dx, NC, H, W, log2_factor, accumulate);
   AGL_CHECK_LAUNCH("agl_upsample_nearest_bwd");
   return AGL_OK;
@@ -944,14 +936,14 @@ int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H,
 }
 
 int agl_grid_gather_fwd(const float* x, const int* map_y, const int* map_x, float* y, long NC, int h, int w, int H, int W, void* stream) {
-  AGL_REQUIRE(x && map_y && map_x && y && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0, "agl_grid_gather_fwd: bad argument");
+  AGL_REQUIRE(x && map_y && map_x && y && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0 && NC * H * W < (1L << 31) && NC * h * w < (1L << 31), "agl_grid_gather_fwd: bad argument");
   LAUNCH1D(grid_gather_fwd_k, NC * H * W, x, map_y, map_x, y, NC, h, w, H, W);
   AGL_CHECK_LAUNCH("agl_grid_gather_fwd");
   return AGL_OK;
 }
 
 int agl_grid_gather_bwd(const float* dy, const int* lo_y, const int* lo_x, float* dx, long NC, int h, int w, int H, int W, void* stream) {
-  AGL_REQUIRE(dy && lo_y && lo_x && dx && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0, "agl_grid_gather_bwd: bad argument");
+  AGL_REQUIRE(dy && lo_y && lo_x && dx && NC > 0 && h > 0 && w > 0 && H > 0 && W > 0 && NC * H * W < (1L << 31) && NC * h * w < (1L << 31), "agl_grid_gather_bwd: bad argument");
   LAUNCH1D(grid_gather_bwd_k, NC * h * w, dy, lo_y, lo_x, dx, NC, h, w, H, W);
   AGL_CHECK_LAUNCH("agl_grid_gather_bwd");
   return AGL_OK;
