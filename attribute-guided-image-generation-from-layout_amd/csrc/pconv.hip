@@ -512,7 +512,7 @@ template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int T
 __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
-  static_assert((NPX == 128 || NPX == 64) && TW >= 8, "pbww geometry");
+  static_assert((NPX == 128 || NPX == 64) && TW >= 4, "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy pieces are two full rows)
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, IMGP = PH * PW, NQ = TI * IMGP;
   constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
   constexpr int XROW = 2 * BC;                          // bytes per patch pixel
@@ -977,10 +977,12 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   if (((a.H << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OH || ((a.W << a.up) + 2 * a.pad - a.ks) / a.stride + 1 != a.OW) return -1;
   const bool half = s2 && a.nsplit == 3;       // 64-pixel tiles: the stride-2 patch of a 128-pixel tile does not fit three planes
   long tiles;
-  int shape;           // pixel tile: 0 = 8 x 16, 1 = two 8 x 8 images, 2 = 4 x 16 (64 pixels), 3 = 8 x 8 of one image (64 pixels)
+  int shape;           // pixel tile: 0 = 8 x 16, 1 = two 8 x 8 images, 2 = 4 x 16 (64 pixels), 3 = 8 x 8 of one image (64 pixels),
+                       // 4 = four whole 4 x 4 images (64 pixels)
   if (a.OW % 16 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1); shape = half ? 2 : 0; }
   else if (a.OW == 8 && a.OH == 8) { tiles = half ? a.N : agl_cdiv(a.N, 2); shape = half ? 3 : 1; }
   else if (a.OW % 8 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 8); shape = 3; }
+  else if (a.OW == 4 && a.OH == 4 && a.ks != 5) { tiles = agl_cdiv(a.N, 4); shape = 4; }
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
@@ -1019,7 +1021,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
 #define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
-    if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);           \
+    if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);           \
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
     else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
     else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);     \
     else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                    \
