@@ -968,8 +968,9 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
     const int hw = a.OH * a.OW;
     if (a.H != a.OH || a.W != a.OW) return -1;
     if (hw % 128 == 0) { a.OW = a.W = 16; a.OH = a.H = hw / 16; }
-    else if (hw != 64) return -1;
-    else { a.OW = a.W = 8; a.OH = a.H = 8; }
+    else if (hw == 64) { a.OW = a.W = 8; a.OH = a.H = 8; }
+    else if (hw == 16) { a.OW = a.W = 4; a.OH = a.H = 4; }
+    else return -1;
   }
   if (oh_out) { *oh_out = a.OH; *ow_out = a.OW; }
   if (a.Cin % 16 != 0 || a.Cout < 32) return -1;
