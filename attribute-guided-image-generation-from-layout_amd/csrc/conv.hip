@@ -920,6 +920,15 @@ __global__ void splitk_epilogue(const float* __restrict__ part, float* __restric
   out[o] = v;
 }
 
+}  // namespace
+int agl_launch_splitk_epilogue(const float* slabs, float* out, long n, int splits, int HW, int C, const float* bias, const float* pos_mask,
+                               int accumulate, int relu, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, HW, C, bias, pos_mask, accumulate, relu);
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+namespace {
+
 // Reduction splits for the forward / input-gradient passes.  Two reasons to cut K: (1) the output grid alone cannot
 // fill the chip (ConvLSTM recurrence steps, 8x8 decoder stem, 2x2 encoder tails); (2) wave quantisation — with 4
 // resident workgroups per CU there are 1024 slots, and e.g. 1050 tiles cost two full rounds; s-way splitting turns that
@@ -1522,7 +1531,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
     const long pn = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad).total();
     if (pn > need) need = pn;
   }
-  need = std::max(need, pconv_ws_bytes(Cin, Cout, ks, 3));
+  need = std::max(need, pconv_ws_bytes_split(Cin, Cout, ks, 3, (long)N * Cout * OH * OW));
   return need;
 }
 
@@ -1643,7 +1652,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
     const long pn = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad).total();
     if (pn > need) need = pn;
   }
-  if (stride == 1) need = std::max(need, pconv_ws_bytes(Cout, Cin, ks, 3));
+  if (stride == 1) need = std::max(need, pconv_ws_bytes_split(Cout, Cin, ks, 3, (long)N * Cin * IH * IW));
   if (stride == 2 && ks == 4) need = std::max(need, pconvT_ws_bytes(Cout, Cin, 3));
   return need;
 }

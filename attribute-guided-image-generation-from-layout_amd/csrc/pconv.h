@@ -16,6 +16,8 @@ long pconv_stat_rows_max(int N, int OH, int OW);
 
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
+// ... plus the slabs of a reduction split when the output (out_numel floats) is small enough for one
+long pconv_ws_bytes_split(int Cin, int Cout, int ks, int nsplit, long out_numel);
 // True when pconv_try would launch for these extents (given enough workspace).
 bool pconv_eligible(const PConvArgs& a);
 // Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.

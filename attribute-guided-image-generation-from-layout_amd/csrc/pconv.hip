@@ -21,6 +21,7 @@
 // The input-gradient of a "same" convolution runs on the same kernel through the packed weights (flipped taps,
 // channel roles swapped).  Epilogues as in conv.hip (bias, ReLU-mask of the consumer, accumulate, ReLU).
 #include "pconv.h"
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,6 +38,9 @@ struct PArgs {
   int nch, mpad;
   unsigned x_bytes;
   float* stats;      // optional: per-channel (sum, sum of squares) of the stored outputs, one row per (pixel tile, wave column)
+  float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
+  int cps;           // (each slab is shaped like y; splitk_epilogue of conv.hip adds them and applies the epilogue)
+  long out_numel;
 };
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
@@ -259,9 +263,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] = 0.f;
   auto& acc = accs[0];
 
-  const int nstage = p.nch * NTG;      // stage s = (channel chunk s / NTG, tap group s % NTG)
-  gload_b(0);
-  gload_a(0, PHS ? phase : 0);
+  const int c_lo = (!PHS && p.slabs) ? (int)blockIdx.z * p.cps : 0;                  // reduction split: this workgroup's chunk range
+  const int nchunk = (!PHS && p.slabs) ? min(p.cps, p.nch - c_lo) : p.nch;
+  const int nstage = nchunk * NTG;     // stage s = (channel chunk s / NTG, tap group s % NTG)
+  gload_b(16 * c_lo);
+  gload_a(c_lo, PHS ? phase : 0);
   sstore_b(0);
   sstore_a(0);
   __syncthreads();
@@ -271,8 +277,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     const bool first_tg = (NTG == 1) || s == cc * NTG, last_tg = (NTG == 1) || (s + 1) % NTG == 0;
     // the next chunk's patch: fetched at the chunk's first tap group when it has its own LDS buffer (the stores wait for the
     // loads only NTG stages later), else at the last one (the registers are live for one stage only)
-    if (DBB ? first_tg : last_tg) gload_b(16 * min(cc + 1, p.nch - 1));
-    gload_a(cc1, tg1);
+    if (DBB ? first_tg : last_tg) gload_b(16 * (c_lo + min(cc + 1, nchunk - 1)));
+    gload_a(c_lo + cc1, tg1);
     const u32x4* const Pc = Pl + (DBB ? (cc & 1) * PB : 0);
     const u32x4* const Ac = Al + (DBA ? (s & 1) * AB : 0);
 #pragma unroll
@@ -423,6 +429,15 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
               p.y[o] = val;
             }
           }
+        }
+        continue;
+      }
+      if (p.slabs) {      // reduction split: raw partial sums; bias / mask / accumulate / ReLU happen in the slab reduction
+        float* const sl = p.slabs + (long)blockIdx.z * p.out_numel;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          if (m < p.Cout && img < p.N) *reinterpret_cast<float4*>(sl + pbase + (long)m * OHW) = v[ps];
         }
         continue;
       }
@@ -737,8 +752,16 @@ long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
   if (!(ks == 1 || ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
   return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
 }
+constexpr int kPconvMaxSplits = 8;
+// ... plus room for the slabs of a reduction split of a small output (out_numel floats per slab)
+long pconv_ws_bytes_split(int Cin, int Cout, int ks, int nsplit, long out_numel) {
+  const long packed = pconv_ws_bytes(Cin, Cout, ks, nsplit);
+  if (!packed) return 0;
+  const long slabs = out_numel * 4 * kPconvMaxSplits;
+  return slabs <= (64L << 20) ? packed + slabs : packed;
+}
 
-struct PConvPlan { int geo, bm; bool s2, w32, wide, half; long ptiles; int oh, ow; };
+struct PConvPlan { int geo, bm; bool s2, w32, wide, half; long ptiles; int oh, ow, splits; };
 // Pure eligibility / tiling decision (no launches): 0 when pconv takes the call.
 static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   const bool s2 = a.stride == 2;
@@ -788,7 +811,16 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   //  the kernel still wins down to ~100 workgroups: 48 images 0.150 -> 0.099 ms, 32 images 0.110 -> 0.094 ms, 16 images slower)
   const long wgs = ptiles * agl_cdiv(a.Cout, bm);
   const bool short_k = (long)(a.Cin / 16) * a.ks * a.ks <= 256;
-  if (wgs < 200 && !(short_k && wgs >= 96) && !a.any_grid) return -1;
+  // Below that, a long reduction is cut over blockIdx.z (raw partial outputs in slabs, summed by the split-K epilogue of
+  // conv.hip): input gradients of the ConvLSTM recurrence steps — 512 -> 128 channels, 64 workgroups, 800 (chunk, tap) steps each
+  int splits = 1;
+  if (wgs < 200 && !(short_k && wgs >= 96) && !a.any_grid) {
+    const int nch = a.Cin / 16;
+    splits = std::min(kPconvMaxSplits, nch / 4);
+    while (splits > 2 && wgs * (splits / 2) >= 256) splits /= 2;
+    if (splits < 2 || wgs * splits < 128 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
+  }
+  pl.splits = splits;
   pl.geo = geo; pl.bm = bm; pl.s2 = s2; pl.w32 = w32; pl.wide = wide; pl.half = half; pl.ptiles = ptiles; pl.oh = oh; pl.ow = ow;
   return 0;
 }
@@ -799,7 +831,9 @@ long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * O
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   PConvPlan pl;
   if (pconv_plan(a, pl) != 0) return -1;
-  const long need = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
+  const long packed = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
+  const long out_numel = (long)a.N * a.Cout * a.OH * a.OW;
+  const long need = packed + (pl.splits > 1 ? out_numel * 4 * pl.splits : 0);
   if (!ws || ws_bytes < need) return -1;
   const int geo = pl.geo, bm = pl.bm;
   const bool s2 = pl.s2, w32 = pl.w32, wide = pl.wide, half = pl.half;
@@ -812,13 +846,14 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
   if (a.ks == 1) { p.H = p.OH = pl.oh; p.W = p.OW = pl.ow; }      // the re-read map of a 1x1 convolution
-  p.stats = nullptr;
-  if (a.stats && !a.relu && !a.accumulate && !a.pos_mask && 2 * ptiles * a.Cout * 2 <= a.stats_floats) {
+  p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel;
+  if (pl.splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, pl.splits); }
+  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && 2 * ptiles * a.Cout * 2 <= a.stats_floats) {
     p.stats = a.stats;
     *a.stat_rows = (int)(2 * ptiles);
   }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
-  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm));
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
   const long per_plane = (long)nch * 2 * KK * mpad;
   hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, KK, a.w_sm,
                      a.w_sc, a.flip, mpad, nch, a.nsplit, 0);
@@ -898,6 +933,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_LAUNCH
 #undef PC_LAUNCH_DB
   AGL_CHECK_LAUNCH(name);
+  if (pl.splits > 1)
+    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, (int)g.z, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name);
   return AGL_OK;
 }
 
@@ -938,6 +975,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
+  p.slabs = nullptr; p.cps = nch; p.out_numel = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), geo == 3 ? 4 : 2);      // 2x2 maps: one workgroup per phase; else per row phase
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)

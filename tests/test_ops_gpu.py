@@ -775,6 +775,33 @@ def test_few_channel_weight_gradient(case):
             close(dw2, base + wg.grad, 2e-5, f"accumulating flags={flags}")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+def test_pconv_reduction_split(mode):
+    """Grids that cannot fill the chip but have a long reduction (input gradients of the ConvLSTM recurrence steps: few images,
+    512 -> 128 channels) run the matrix-core kernel with the channel chunks cut over blockIdx.z; the raw partial outputs are
+    summed, and bias / ReLU mask / accumulate / ReLU applied, by the split-K epilogue.  No AGL_CONV_ANY_GRID here: the plan
+    itself must choose the split."""
+    from agl import lib as L
+    N, Cin, H, Cout, ks = 48, 256, 8, 128, 3
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    flags = L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3
+    xr, wr = r(x), r(w)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    with L.conv_flags(flags):
+        y = L.conv2d_fwd(xd, wd, bd, 1, 1, relu=True)
+        close(y, torch.relu(TF.conv2d(xr, wr, b, padding=1)), 2e-5, "forward, bias + ReLU through the slab reduction")
+        base = rn(N, Cout, H, H, seed=5)
+        y2 = L.conv2d_fwd(xd, wd, None, 1, 1, out=dev(base).clone(), accumulate=True)
+        close(y2, base + TF.conv2d(xr, wr, None, padding=1), 2e-5, "accumulate")
+        gy = rn(N, Cout, H, H, seed=7)
+        xg = xr.clone().requires_grad_(True)
+        TF.conv2d(xg, wr, None, padding=1).backward(r(gy))
+        mask = rn(N, Cin, H, H, seed=9)
+        dx = L.conv2d_bwd_data(dev(gy), wd, (H, H), 1, 1, pos_mask=dev(mask))
+        close(dx, xg.grad * (mask > 0), 1e-4 if mode == "split3" else 5e-5, "input gradient with ReLU mask")
+
+
 def test_pconv_upsampled_input():
     """Nearest up-sampling folded into the patch staging (SPADE mlp_shared reads the 8x8 map up-sampled, normalization.py:100)."""
     from agl import lib as L
