@@ -1653,7 +1653,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
     if (pn > need) need = pn;
   }
   if (stride == 1) need = std::max(need, pconv_ws_bytes_split(Cout, Cin, ks, 3, (long)N * Cin * IH * IW));
-  if (stride == 2 && ks == 4) need = std::max(need, pconvT_ws_bytes(Cout, Cin, 3));
+  if (stride == 2 && ks == 4) need = std::max(need, pconvT_ws_bytes_split(Cout, Cin, 3, (long)N * Cin * IH * IW));
   return need;
 }
 

@@ -27,6 +27,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 // a.y = dx (a.Cout channels, a.OH = 2H, a.OW = 2W), a.w_sm / a.w_sc = element strides of w for (dx channel, dy channel).
 bool pconvT_eligible(const PConvArgs& a);
 long pconvT_ws_bytes(int Cred, int Crow, int nsplit);
+long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel);
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
 
 struct PBwwArgs {

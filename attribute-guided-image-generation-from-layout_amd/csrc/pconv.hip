@@ -171,7 +171,9 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
   const int bm0 = blockIdx.y * BM;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const int phase = PHS ? (PAIR ? 2 * (int)blockIdx.z : (int)blockIdx.z) : 0, ph_y = phase >> 1, ph_x = phase & 1;
+  constexpr int NZP = PHS ? (PAIR ? 2 : 4) : 1;                  // phase values carried by blockIdx.z (the reduction split index is above)
+  const int zsplit = (int)blockIdx.z / NZP, zph = (int)blockIdx.z - zsplit * NZP;
+  const int phase = PHS ? (PAIR ? 2 * zph : zph) : 0, ph_y = phase >> 1, ph_x = phase & 1;
   const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? (PAIR ? 1 : 1 - ph_x) : p.pad;
 
   // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] = 0.f;
   auto& acc = accs[0];
 
-  const int c_lo = (!PHS && p.slabs) ? (int)blockIdx.z * p.cps : 0;                  // reduction split: this workgroup's chunk range
-  const int nchunk = (!PHS && p.slabs) ? min(p.cps, p.nch - c_lo) : p.nch;
+  const int c_lo = p.slabs ? zsplit * p.cps : 0;                  // reduction split: this workgroup's chunk range
+  const int nchunk = p.slabs ? min(p.cps, p.nch - c_lo) : p.nch;
   const int nstage = nchunk * NTG;     // stage s = (channel chunk s / NTG, tap group s % NTG)
   gload_b(16 * c_lo);
   gload_a(c_lo, PHS ? phase : 0);
@@ -375,6 +377,12 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
             float4 lo = {v[ps].x + bb, v1[ps].x + bb, v[ps].y + bb, v1[ps].y + bb};
             float4 hi = {v[ps].z + bb, v1[ps].z + bb, v[ps].w + bb, v1[ps].w + bb};
             float* dst = p.y + ob + (long)m * OHW2;
+            if (p.slabs) {      // reduction split: raw partial sums (bias and the rest happen in the slab reduction)
+              float* sd = p.slabs + (long)zsplit * p.out_numel + ob + (long)m * OHW2;
+              *reinterpret_cast<float4*>(sd) = float4{v[ps].x, v1[ps].x, v[ps].y, v1[ps].y};
+              *reinterpret_cast<float4*>(sd + 4) = float4{v[ps].z, v1[ps].z, v[ps].w, v1[ps].w};
+              continue;
+            }
             if (p.pos_mask) {
               const float4 m0 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2);
               const float4 m1 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2 + 4);
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
         continue;
       }
       if (p.slabs) {      // reduction split: raw partial sums; bias / mask / accumulate / ReLU happen in the slab reduction
-        float* const sl = p.slabs + (long)blockIdx.z * p.out_numel;
+        float* const sl = p.slabs + (long)zsplit * p.out_numel;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
@@ -941,7 +949,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 // ---- 4x4 / stride-2 / pad-1 input gradient (and ConvTranspose2d(4,2,1) forward): four 2x2-tap phases, blockIdx.z = phase ----
 // a.x = dy (N, a.Cin = reduction channels, a.H x a.W), a.y = dx (N, a.Cout, 2H x 2W); w[co][ci][4][4] addressed through
 // w_sm (stride of the output row m = ci: 16) and w_sc (stride of the reduction channel c = co: Cin*16).
-static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles) {
+static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles, int* splits_out = nullptr) {
   if (a.ks != 4 || a.stride != 2 || a.pad != 1 || a.up != 0 || a.Cin % 16 != 0 || a.Cout < 48) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
   if (a.OH != 2 * a.H || a.OW != 2 * a.W) return -1;
@@ -953,7 +961,15 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles) {
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;
   *bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : (*geo == 2 ? agl_cdiv(a.N, 8) : agl_cdiv(a.N, 32)));
-  if (*ptiles * agl_cdiv(a.Cout, *bm) * 4 < 200 && !a.any_grid) return -1;
+  int splits = 1;
+  const long wgs = *ptiles * agl_cdiv(a.Cout, *bm) * 4;         // (in units of single-phase workgroups)
+  if (wgs < 200 && !a.any_grid) {      // small grid: cut the reduction (paired-phase geometries only: they write whole slab rows)
+    const int nch = a.Cin / 16;
+    splits = std::min(kPconvMaxSplits, nch / 4);
+    while (splits > 2 && wgs * (splits / 2) >= 512) splits /= 2;
+    if (*geo == 3 || splits < 2 || wgs * splits < 256 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
+  }
+  if (splits_out) *splits_out = splits;
   return 0;
 }
 bool pconvT_eligible(const PConvArgs& a) { int g, b; long t; return pconvT_plan(a, &g, &b, &t) == 0; }
@@ -961,10 +977,17 @@ long pconvT_ws_bytes(int Cred, int Crow, int nsplit) {
   if (Cred % 16 != 0 || Crow < 48) return 0;
   return (long)nsplit * (Cred / 16) * 2 * 16 * round_up(Crow, 128) * 16;
 }
+long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel) {
+  const long packed = pconvT_ws_bytes(Cred, Crow, nsplit);
+  if (!packed) return 0;
+  const long slabs = out_numel * 4 * kPconvMaxSplits;
+  return slabs <= (64L << 20) ? packed + slabs : packed;
+}
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
-  int geo, bm; long ptiles;
-  if (pconvT_plan(a, &geo, &bm, &ptiles) != 0) return -1;
-  if (!ws || ws_bytes < pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit)) return -1;
+  int geo, bm, splits; long ptiles;
+  if (pconvT_plan(a, &geo, &bm, &ptiles, &splits) != 0) return -1;
+  const long packed = pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit), out_numel = (long)a.N * a.Cout * a.OH * a.OW;
+  if (!ws || ws_bytes < packed + (splits > 1 ? out_numel * 4 * splits : 0)) return -1;
   const int nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
   u32x4* wp = (u32x4*)ws;
   const long per_plane = (long)nch * 2 * 16 * mpad;
@@ -975,9 +998,10 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
-  p.slabs = nullptr; p.cps = nch; p.out_numel = 0;
+  p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel;
+  if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
-  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), geo == 3 ? 4 : 2);      // 2x2 maps: one workgroup per phase; else per row phase
+  dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
 #define PT_GEO(BM_, NS_)                                          \
   do {                                                            \
@@ -992,6 +1016,8 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
 #undef PT_GEO
 #undef PT_LAUNCH
   AGL_CHECK_LAUNCH(name);
+  if (splits > 1)
+    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, splits, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name);
   return AGL_OK;
 }
 

@@ -802,6 +802,25 @@ def test_pconv_reduction_split(mode):
         close(dx, xg.grad * (mask > 0), 1e-4 if mode == "split3" else 5e-5, "input gradient with ReLU mask")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(32, 256, 8, 128), (24, 512, 16, 64)])
+def test_pconv_phase_reduction_split(case, mode):
+    """The paired-phase stride-2 input gradient on a grid that cannot fill the chip: the plan cuts the reduction channels over
+    blockIdx.z (no AGL_CONV_ANY_GRID), the slab reduction applies mask / accumulate."""
+    from agl import lib as L
+    N, Cout, OH, Cin = case            # dy: (N, Cout, OH, OH); dx: (N, Cin, 2*OH, 2*OH)
+    w = rn(Cout, Cin, 4, 4, seed=1) * (1.0 / (Cout * 4) ** 0.5)
+    gy = rn(N, Cout, OH, OH, seed=3)
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    ref = TF.conv_transpose2d(r(gy), r(w), None, stride=2, padding=1)
+    mask, base = rn(N, Cin, 2 * OH, 2 * OH, seed=5), rn(N, Cin, 2 * OH, 2 * OH, seed=6)
+    with L.conv_flags(L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3):
+        dx = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1)
+        dx2 = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1, pos_mask=dev(mask), out=dev(base).clone(), accumulate=True)
+    close(dx, ref, 5e-5 if mode == "bf16" else 2e-5, "stride-2 input gradient (reduction split)")
+    close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
+
+
 def test_pconv_upsampled_input():
     """Nearest up-sampling folded into the patch staging (SPADE mlp_shared reads the 8x8 map up-sampled, normalization.py:100)."""
     from agl import lib as L
