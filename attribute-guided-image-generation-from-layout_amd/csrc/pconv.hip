@@ -108,6 +108,7 @@ template <int KS> struct Pitch2<16, KS> { static constexpr int PWP = 24; static 
 template <int KS> struct Pitch2<8, KS> { static constexpr int PWP = 12; static constexpr int IMG_EXTRA = 0; };
 template <> struct Pitch2<4, 4> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 4; };
 template <> struct Pitch2<4, 3> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 10; };
+template <int KS> struct Pitch2<2, KS> { static constexpr int PWP = 3; static constexpr int IMG_EXTRA = 0; };   // 2x2 outputs (natural pitch)
 template <int S, int TW, int KS, int NSPL> struct PitchSel { using type = Pitch<TW, KS, NSPL>; };
 template <int TW, int KS, int NSPL> struct PitchSel<2, TW, KS, NSPL> { using type = Pitch2<TW, KS>; };
 
@@ -791,12 +792,13 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   if (ow % 16 == 0 && oh % 8 == 0) geo = 0;
   else if (ow == 8 && oh == 8) geo = 1;
   else if (ow == 4 && oh == 4 && (a.ks == 3 || a.ks == 4 || a.ks == 1)) geo = 2;
+  else if (s2 && ow == 2 && oh == 2) geo = 5;               // stride 2 down to 2 x 2 maps: 16 (split mode) or 32 images per tile
   else if (!s2 && ow % 8 == 0 && oh % 8 == 0) geo = 3;      // 8 x 8 tiles of one image (64 pixels)
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;   // 32-bit offsets
   // nsplit 1: 128 channels (64 when Cout <= 64) x 256 pixels per workgroup, 128 pixels when the wider tile would leave CUs
   // without work; nsplit 3: 64 x 128 (three LDS planes).  Stride 2 (patch = 4x the tile): 128 pixels, 64 in split mode.
-  const long px128 = geo == 0 ? (long)a.N * (oh / 8) * (ow / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : agl_cdiv(a.N, 8));
+  const long px128 = geo == 0 ? (long)a.N * (oh / 8) * (ow / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : (geo == 5 ? agl_cdiv(a.N, 32) : agl_cdiv(a.N, 8)));
   int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   // 1x1: bandwidth-bound — read the input once per 128 output channels where that still leaves a workgroup per CU
   if (a.ks == 1 && a.Cout > 64 && px128 * agl_cdiv(a.Cout, 128) >= 256) bm = 128;
@@ -812,6 +814,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   if (geo == 0) ptiles = half ? px128 * 2 : px128 / (wide ? 2 : 1);
   else if (geo == 1) ptiles = half ? a.N : agl_cdiv(a.N, wide ? 4 : 2);
   else if (geo == 2) ptiles = agl_cdiv(a.N, half ? 4 : (wide ? 16 : 8));
+  else if (geo == 5) ptiles = agl_cdiv(a.N, half ? 16 : 32);
   else ptiles = (long)a.N * (oh / 8) * (ow / 8);
   // no reduction split in this kernel: a grid that cannot occupy most CUs runs one long serial K loop per workgroup and is
   // slower than the split-K im2col / position-major kernels (ConvLSTM recurrence steps over the few images still active)
@@ -891,14 +894,17 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     if (a.nsplit == 3) {                                                                                 \
       if (geo == 0) PC_LAUNCH(KS_, 2, 16, 4, 1, 64, 3, TG_);                                             \
       else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 1, 64, 3, TG_);                                         \
+      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 16, 64, 3, TG_);                                        \
       else PC_LAUNCH(KS_, 2, 4, 4, 4, 64, 3, TG_);                                                       \
     } else if (bm == 128) {                                                                              \
       if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 128, 1, TG_);                                            \
       else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 128, 1, TG_);                                        \
+      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 32, 128, 1, TG_);                                       \
       else PC_LAUNCH(KS_, 2, 4, 4, 8, 128, 1, TG_);                                                      \
     } else {                                                                                             \
       if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 64, 1, TG_);                                             \
       else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 64, 1, TG_);                                         \
+      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 32, 64, 1, TG_);                                        \
       else PC_LAUNCH(KS_, 2, 4, 4, 8, 64, 1, TG_);                                                       \
     }                                                                                                    \
   } while (0)

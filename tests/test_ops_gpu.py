@@ -835,7 +835,7 @@ def test_pconv_upsampled_input():
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
 @pytest.mark.parametrize("case", [(4, 64, 32, 128, 4, 1), (5, 32, 16, 64, 4, 1), (9, 16, 8, 96, 4, 1), (4, 64, 33, 128, 3, 0), (6, 32, 17, 64, 3, 0),
-                                  (10, 32, 9, 96, 3, 0), (2, 128, 64, 64, 4, 1), (3, 48, 66, 64, 4, 1)])
+                                  (10, 32, 9, 96, 3, 0), (2, 128, 64, 64, 4, 1), (3, 48, 66, 64, 4, 1), (37, 64, 5, 128, 3, 0), (21, 32, 4, 96, 4, 1)])
 def test_pconv_stride2_forward(case, mode):
     """Stride-2 forward forms of the bf16-matrix-core patch kernel (4x4/pad 1: layout- and crop-encoder layers; 3x3/pad 0: the
     box form of the down-sampling discriminator blocks): the patch is split by column parity in LDS.  Same tolerances as the

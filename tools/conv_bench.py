@@ -52,6 +52,7 @@ SHAPES = [
     ("Dobj.2 box 128>256 k3s2 @17", O, 128, 17, 256, 3, 2, 0),
     ("Dobj.3 box 256>512 k3s2 @9", O, 256, 9, 512, 3, 2, 0),
     ("Dobj.4 box 512>1024 k3s2 @5", O, 512, 5, 1024, 3, 2, 0),
+    ("Dobj.4 box 512>1024 k3s2 @5 to2x2", O, 512, 5, 1024, 3, 2, 0),
     ("Dimg.0b 64>64 k3 @64", N, 64, 64, 64, 3, 1, 1),
     ("Dimg.1b 64>128 k3 @32", N, 64, 32, 128, 3, 1, 1),
     ("Dobj.0a 3>64 k3 @32", O, 3, 32, 64, 3, 1, 1),
