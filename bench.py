@@ -37,10 +37,11 @@ PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (
 DTYPE_NAME = {"f32": "f32", "f32x3": "f32", "bf16": "bf16"}
 ARITHMETIC = {
     "f32": "fp32 tensors; every convolution on exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-    "f32x3": "fp32 tensors and fp32 accumulation; in the LDS-patch kernels (csrc/pconv.hip: 3x3/5x5 stride 1, 4x4/3x3 stride 2 "
-             "forward, stride-1 input gradients, weight gradients) each fp32 operand is carried as three bf16 terms (exact to "
-             "2^-27) and six bf16-MFMA products are accumulated in fp32 — as accurate as the fp32 MFMA chain (tests: error vs "
-             "fp64 <= 2x that of the exact kernel, full-step fixtures at the fp32 tolerances); exact fp32 MFMA in all other kernels",
+    "f32x3": "fp32 tensors and fp32 accumulation; in the LDS-patch kernels (csrc/pconv.hip: 1x1/3x3/5x5 stride 1, 4x4/3x3 stride 2 "
+             "forward, stride-1 and 4x4/stride-2 input gradients, weight gradients) each fp32 operand is carried as three bf16 "
+             "terms (exact to 2^-27) and six bf16-MFMA products are accumulated in fp32 — as accurate as the fp32 MFMA chain "
+             "(tests: error vs fp64 <= 2x that of the exact kernel; whole step at this size vs the CPU oracle at the fp32 "
+             "tolerances); exact fp32 MFMA in all other kernels",
     "bf16": "fp32 tensors in HBM; convolution operands rounded to bf16 when staged, bf16 MFMA with fp32 accumulation",
 }
 CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight")
