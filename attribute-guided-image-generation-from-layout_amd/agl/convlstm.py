@@ -82,12 +82,16 @@ class _LayoutConvLSTM(torch.autograd.Function):
         S = SH * SW
         dev = x.device
         saved = []
+        wsrcs = []          # packed-weight cache handles of the two halves of every layer's weight (agl.lib.WeightSrc)
         X = x
         for li, hid in enumerate(hidden):
             W, b = params[2 * li], params[2 * li + 1]
             cx = X.shape[1]
             Wx, Wh = _split_w(W, cx)
-            ccx = L.conv2d_fwd(X, Wx, b, 1, 2)                                    # (O, 4h, 8, 8)
+            wsw = getattr(W, "_agl_wsrc", None)
+            sx, sh = (wsw.derived("x"), wsw.derived("h")) if wsw is not None else (None, None)
+            wsrcs.append((sx, sh))
+            ccx = L.conv2d_fwd(X, Wx, b, 1, 2, wsrc=sx)                           # (O, 4h, 8, 8)
             H = torch.empty((O, hid, SH, SW), dtype=torch.float32, device=dev)    # time-major
             Cs = torch.empty_like(H)
             gates = torch.empty((O, 4 * hid, SH, SW), dtype=torch.float32, device=dev)
@@ -101,13 +105,13 @@ class _LayoutConvLSTM(torch.autograd.Function):
                     cch = cprev = None
                 else:
                     po = plan.off[t - 1]
-                    cch = L.conv2d_fwd(H[po:po + n], Wh, None, 1, 2)
+                    cch = L.conv2d_fwd(H[po:po + n], Wh, None, 1, 2, wsrc=sh)
                     cprev = Cs[po:po + n]
                 L.lstm_gates_fwd(src, rows, cch, cprev, H[o:o + n], Cs[o:o + n], gates[o:o + n], n, hid, S)
             saved += [X, Wx, Wh, H, Cs, gates]
             X = H
         out = L.gather_rows(X, plan.last_rows)
-        ctx.plan, ctx.hidden = plan, tuple(hidden)
+        ctx.plan, ctx.hidden, ctx.wsrcs = plan, tuple(hidden), wsrcs
         ctx.save_for_backward(*saved)
         return out
 
@@ -127,6 +131,7 @@ class _LayoutConvLSTM(torch.autograd.Function):
         for li in reversed(range(nl)):
             hid = hidden[li]
             X, Wx, Wh, H, Cs, gates = saved[6 * li: 6 * li + 6]
+            sx, sh = ctx.wsrcs[li]
             dCC = torch.empty_like(gates)
             dc_carry = dh_rec = None
             n_next = 0
@@ -137,7 +142,7 @@ class _LayoutConvLSTM(torch.autograd.Function):
                 L.lstm_gates_bwd(dH_ext[o:o + n], dh_rec, n_next, dc_carry, n_next, gates[o:o + n], cprev, Cs[o:o + n],
                                  dCC[o:o + n], dc_prev, n, hid, S)
                 dc_carry = dc_prev
-                dh_rec = L.conv2d_bwd_data(dCC[o:o + n], Wh, (SH, SW), 1, 2) if t > 0 else None
+                dh_rec = L.conv2d_bwd_data(dCC[o:o + n], Wh, (SH, SW), 1, 2, wsrc=sh) if t > 0 else None
                 n_next = n
             n0 = plan.n_t[0]
             if plan.T > 1:
@@ -154,7 +159,7 @@ class _LayoutConvLSTM(torch.autograd.Function):
             grads[2 * li] = _join_w(dWx, dWh)
             grads[2 * li + 1] = L.channel_sum(dCCx)
             if li > 0 or ctx.needs_input_grad[0]:
-                dX = L.conv2d_bwd_data(dCCx, Wx, (SH, SW), 1, 2)
+                dX = L.conv2d_bwd_data(dCCx, Wx, (SH, SW), 1, 2, wsrc=sx)
             dH_ext = dX
         return (dX if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 

@@ -28,6 +28,8 @@ class FlatParams:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.epoch = 0      # bumped whenever the arena is written through a raw pointer or an alias (Adam kernel, broadcast): the
+                            # packed-weight caches of the parameters (agl.lib.WeightSrc) are keyed by (epoch, tensor version)
         o = 0
         with torch.no_grad():
             for p in self.params:
@@ -36,6 +38,8 @@ class FlatParams:
                 p.data = self.p[o:o + k].view(p.shape)
                 p.grad = self.g[o:o + k].view(p.shape)
                 p._agl_slot = True          # backward kernels accumulate straight into this slot (functional._slot)
+                if p.dim() == 4:            # convolution weights: handle of their packed forms
+                    p._agl_wsrc = L.WeightSrc(p, (lambda p=p: (self.epoch, p._version)))
                 o += k
 
     def zero_grad(self):
@@ -48,6 +52,11 @@ class FlatParams:
         for p in self.params:
             p.requires_grad_(flag)
 
+    def touch(self):
+        """Call after writing the arena through anything but the parameters themselves (e.g. a broadcast into .p)."""
+        self.epoch += 1
+
     def adam_step(self, lr, beta1, beta2, eps, grad_scale=1.0):
         self.step_count += 1
+        self.epoch += 1
         L.adam_step(self.p, self.g, self.m, self.v, lr, beta1, beta2, eps, self.step_count, grad_scale)

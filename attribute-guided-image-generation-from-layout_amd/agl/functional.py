@@ -45,13 +45,14 @@ def _slot(p):
 # partial sums of its output, and the _NormAct that consumes exactly that tensor next finalises them instead of re-reading
 # the activation.  One entry at most, dropped by whatever convolution or norm runs next.
 EMIT_STATS = False
-_LAST_STATS = None      # (data_ptr, shape, partials, rows)
+_LAST_STATS = None      # (y, y._version at emission, partials, rows): the entry holds y itself, so its storage cannot be recycled
+                        # for another tensor while the entry is alive, and an in-place write to y invalidates it
 
 
 def _take_stats(x):
     global _LAST_STATS
     e, _LAST_STATS = _LAST_STATS, None
-    if e is not None and e[0] == x.data_ptr() and e[1] == tuple(x.shape):
+    if e is not None and e[0] is x and e[1] == x._version:
         return e[2], e[3]
     return None, 0
 
@@ -63,17 +64,18 @@ class _Conv2d(torch.autograd.Function):
         global _LAST_STATS
         _LAST_STATS = None
         ctx.slots = (_slot(w), _slot(bias))
+        ctx.wsrc = wsrc = getattr(w, "_agl_wsrc", None)        # packed-weight cache handle (agl.lib.WeightSrc), if the weight has one
         x, w = _c(x), _c(w)
         if addend is not None:
             assert not relu, "addend with fused ReLU is not supported"
-            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, False, out=addend, accumulate=True)
+            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, False, out=addend, accumulate=True, wsrc=wsrc)
             ctx.mark_dirty(addend)
         elif EMIT_STATS and not relu and (L.CONV_FLAGS & (L.CONV_BF16 | L.CONV_SPLIT3)):
-            y, part, rows = L.conv2d_fwd_stats(x, w, bias, stride, pad, up, in_relu)
+            y, part, rows = L.conv2d_fwd_stats(x, w, bias, stride, pad, up, in_relu, wsrc=wsrc)
             if part is not None:
-                _LAST_STATS = (y.data_ptr(), tuple(y.shape), part, rows)
+                _LAST_STATS = (y, y._version, part, rows)
         else:
-            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, relu)
+            y = L.conv2d_fwd(x, w, bias, stride, pad, up, in_relu, relu, wsrc=wsrc)
         ctx.cfg = (stride, pad, up, in_relu, relu, bias is not None, addend is not None, relu_grad_by_consumer, x_relu)
         ctx.save_for_backward(x, w, y if (relu and not relu_grad_by_consumer) else None)
         return y
@@ -91,11 +93,12 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if up:
                 H, W = x.shape[2] << up, x.shape[3] << up
-                dxu = L.conv2d_bwd_data(g, w, (H, W), stride, pad)
+                dxu = L.conv2d_bwd_data(g, w, (H, W), stride, pad, wsrc=ctx.wsrc)
                 dx = L.upsample_bwd(dxu, up)
                 assert not in_relu
             else:
-                dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if (in_relu or x_relu) else None)
+                dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if (in_relu or x_relu) else None,
+                                       wsrc=ctx.wsrc)
         wslot, bslot = ctx.slots
         if ctx.needs_input_grad[1]:
             if wslot is not None:
@@ -136,15 +139,16 @@ class _ConvT4s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.slot = _slot(w)
+        ctx.wsrc = getattr(w, "_agl_wsrc", None)
         x, w = _c(x), _c(w)
         ctx.save_for_backward(x, w)
-        return L.conv2d_bwd_data(x, w, (2 * x.shape[2], 2 * x.shape[3]), 2, 1)
+        return L.conv2d_bwd_data(x, w, (2 * x.shape[2], 2 * x.shape[3]), 2, 1, wsrc=ctx.wsrc)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
-        dx = L.conv2d_fwd(dy, w, None, 2, 1) if ctx.needs_input_grad[0] else None
+        dx = L.conv2d_fwd(dy, w, None, 2, 1, wsrc=ctx.wsrc) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.slot is not None:
@@ -446,9 +450,10 @@ class _Conv3x3AvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, bias, x_relu):
         ctx.slots = (_slot(w3), _slot(bias))
+        ctx.wsrc = getattr(w3, "_agl_wsrc", None)
         x, w3 = _c(x), _c(w3)
         xb = L.box2_fwd(x)
-        y = L.conv2d_fwd(xb, w3, bias, 2, 0)
+        y = L.conv2d_fwd(xb, w3, bias, 2, 0, wsrc=ctx.wsrc)
         ctx.cfg = (x_relu, tuple(x.shape), bias is not None)
         ctx.save_for_backward(x if x_relu else None, xb, w3)
         return y
@@ -466,9 +471,15 @@ class _Conv3x3AvgPool(torch.autograd.Function):
             dxb = L.conv2d_bwd_data(dy, w3, (xshape[2] + 1, xshape[3] + 1), 2, 0)
             dx = L.box2_bwd(dxb, x if x_relu else None)
         elif ctx.needs_input_grad[0]:
-            w4 = torch.empty(w3.shape[:2] + (4, 4), dtype=torch.float32, device=w3.device)
-            L.call("agl_pool_fuse_weight_fwd", L.ptr(w3), L.ptr(w4), w3.shape[0] * w3.shape[1], L.stream())
-            dx = L.conv2d_bwd_data(dy, w4, (xshape[2], xshape[3]), 2, 1, pos_mask=x if x_relu else None)
+            def pooled(src):
+                w4 = torch.empty(src.shape[:2] + (4, 4), dtype=torch.float32, device=src.device)
+                L.call("agl_pool_fuse_weight_fwd", L.ptr(src), L.ptr(w4), src.shape[0] * src.shape[1], L.stream())
+                return w4
+            ws = ctx.wsrc         # the pooled filter is only built when its packed form is not cached (once per weight version)
+            dx = L.conv2d_bwd_data(dy, None, (xshape[2], xshape[3]), 2, 1, pos_mask=x if x_relu else None,
+                                   wsrc=ws.derived("pool4") if ws is not None else None, w_shape=tuple(w3.shape[:2]) + (4, 4),
+                                   make_w=lambda: pooled(w3),
+                                   make_base=lambda: pooled(_c(ws.base.detach()) if ws.base is not None else w3))
         wslot, bslot = ctx.slots
         if ctx.needs_input_grad[1]:
             if wslot is not None:
@@ -757,10 +768,12 @@ class _SpectralNormWeights(torch.autograd.Function):
         ctx.shapes = [tuple(w.shape) for w in ws]
         slots = [_slot(w) for w in ws]
         ctx.slots = slots if all(sl is not None for sl in slots) else None
-        return tuple(outs)
+        ctx.mark_non_differentiable(sigma)
+        return tuple(outs) + (sigma,)
 
     @staticmethod
     def backward(ctx, *gs):
+        gs = gs[:-1]                 # (the last output is sigma: non-differentiable)
         descs = ctx.descs
         arena = ctx.keep[0]
         n = len(gs)
@@ -788,4 +801,12 @@ class _SpectralNormWeights(torch.autograd.Function):
 
 def spectral_norm_weights(weights: Sequence[torch.Tensor], us: Sequence[torch.Tensor], vs: Sequence[torch.Tensor],
                           training: bool = True) -> List[torch.Tensor]:
-    return list(_SpectralNormWeights.apply(training, list(us), list(vs), *weights))
+    outs = _SpectralNormWeights.apply(training, list(us), list(vs), *weights)
+    ws, sigma = list(outs[:-1]), outs[-1]
+    # packed-weight cache: the convolutions read the packed weight_orig (re-packed once per optimiser update) and divide by
+    # this call's sigma in their epilogue
+    for i, (w_sn, w) in enumerate(zip(ws, weights)):
+        src = getattr(w, "_agl_wsrc", None)
+        if src is not None:
+            w_sn._agl_wsrc = L.WeightSrc(src.owner, src.version, base=w, div=sigma[i:i + 1], tag="sn")
+    return ws

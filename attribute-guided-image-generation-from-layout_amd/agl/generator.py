@@ -236,8 +236,12 @@ class SPADE(nn.Module):
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
         assert segmap.shape[2] == segmap.shape[3]
-        w = F.concat_rows(self.mlp_gamma.weight, self.mlp_beta.weight)
+        wg, wb = self.mlp_gamma.weight, self.mlp_beta.weight
+        w = F.concat_rows(wg, wb)
         b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
+        sg, sb = getattr(wg, "_agl_wsrc", None), getattr(wb, "_agl_wsrc", None)
+        if sg is not None and sb is not None:      # packed-weight cache of the concatenation, valid while neither half changes
+            w._agl_wsrc = F.L.WeightSrc(wg, (lambda: (sg.version(), sb.version())), tag="gamma|beta")
         nb = segmap.shape[2]
         if self.block_grids and f >= 4:
             # The f-fold nearest up-sampling of the segmentation map is constant on f x f blocks, so a 3x3 convolution of

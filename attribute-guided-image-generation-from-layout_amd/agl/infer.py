@@ -34,7 +34,12 @@ def edit_attributes_batch(netG, netD_att, batch: Dict[str, torch.Tensor], *, tgt
                           eps_edit: Optional[Sequence[torch.Tensor]] = None, threshold: float = 0.9) -> Dict[str, torch.Tensor]:
     """One iteration of the loop of test64.py:114-198.  `batch`: device tensors imgs, objs, boxes, masks, attribute, masks_shift,
     boxes_shift and the CPU obj_to_img.  z / z_edit (O, z_dim) and the eps triples pin the random draws (default: torch.randn on
-    the CPU like the reference).  Returns device tensors; nothing is written to disk."""
+    the CPU like the reference).  Returns device tensors; nothing is written to disk.
+
+    Module modes follow the reference: test64.py:114 puts ONLY netG in eval mode; netD_att keeps the mode it has (the reference
+    never calls netD_att.eval(), so there its spectral norm runs one power iteration in each of its FOUR forward calls per batch:
+    :129, :146, :180, :183 — this function makes the same four calls in the same order, so u/v advance identically).  Call
+    netD_att.eval() first for a state-free loop.  netG's training flag is restored on return."""
     dev = batch["imgs"].device
     objs, attribute = batch["objs"], batch["attribute"].contiguous()
     O = objs.shape[0]
@@ -42,9 +47,16 @@ def edit_attributes_batch(netG, netD_att, batch: Dict[str, torch.Tensor], *, tgt
     z = (torch.randn(O, zdim) if z is None else z).to(dev)
     z_edit = (torch.randn(O, zdim) if z_edit is None else z_edit).to(dev)
     o2i = batch["obj_to_img"]
+    g_was_training = netG.training
+    try:
+        return _edit(netG, netD_att, batch, dev, objs, attribute, o2i, z, z_edit, eps, eps_edit, tgt, remove, threshold)
+    finally:
+        netG.train(g_was_training)
+
+
+def _edit(netG, netD_att, batch, dev, objs, attribute, o2i, z, z_edit, eps, eps_edit, tgt, remove, threshold):
     with torch.no_grad():
         netG.eval()
-        netD_att.eval()
         # (1) attribute estimate (:126-135)
         crops_input = F.crop_boxes(batch["imgs"], batch["boxes"], o2i.to(dev), netG.obj_size)
         attribute_est = L.attr_estimate(netD_att(crops_input), attribute)
@@ -52,9 +64,9 @@ def edit_attributes_batch(netG, netD_att, batch: Dict[str, torch.Tensor], *, tgt
         out = netG(batch["imgs"], objs, batch["boxes"], batch["masks"], o2i, z, attribute, batch["masks_shift"], batch["boxes_shift"],
                    attribute_est, eps=eps)
         crops_rand, img_rec, img_rand, img_shift = out[2], out[4], out[5], out[6]
-        # (3) attribute classifier on the generated crops (:142-150); rows without annotation are masked out by the caller
-        logits_rand = netD_att(crops_rand)
-        pred = L.sigmoid_threshold(logits_rand, threshold)
+        # (3) attribute classifier on the generated crops (:142-150).  The reference passes the annotated rows only; a row's
+        # logits do not depend on the other rows, so all rows are scored here and the caller masks with `annotated`
+        pred = L.sigmoid_threshold(netD_att(crops_rand), threshold)
         # (4) attribute modification for every object (:160-167)
         cols = torch.tensor(list(remove), dtype=torch.int32, device=dev)
         attribute_new = L.attr_edit_(attribute.clone(), cols, tgt)
@@ -63,7 +75,8 @@ def edit_attributes_batch(netG, netD_att, batch: Dict[str, torch.Tensor], *, tgt
         out_y = netG(batch["imgs"], objs, batch["boxes"], batch["masks"], o2i, z_edit, attribute_new, batch["masks_shift"],
                      batch["boxes_shift"], attribute_est_new, eps=eps_edit)
         crops_rand_y, img_rec_y, img_rand_y, img_shift_y = out_y[2], out_y[4], out_y[5], out_y[6]
-        # (6) success statistics (:179-184)
+        # (6) success statistics (:179-184): the reference scores crops_rand again here (:180, its third D_att call)
+        logits_rand = netD_att(crops_rand)
         changed = L.topk_contains(logits_rand, 5, tgt) == 0                 # target not yet among the top-5
         success = changed & (L.topk_contains(netD_att(crops_rand_y), 3, tgt) != 0)
         # (7) bytes (:153-155, :173-176)

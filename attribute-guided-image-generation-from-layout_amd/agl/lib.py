@@ -25,8 +25,12 @@ SIGNATURES = {
     "agl_conv2d_fwd_ws_bytes": (_L, [_I] * 9),
     "agl_conv2d_bwd_data_ws_bytes": (_L, [_I] * 10),
     "agl_conv2d_splitk_ws_bytes": (_L, [_I, _L, _I, _I, _L]),
-    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
-    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_fwd_packed_bytes": (_L, [_I] * 10),
+    "agl_conv2d_bwd_data_packed_bytes": (_L, [_I] * 11),
+    "agl_conv2d_pack_weights": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
+    "agl_conv2d_last_pipe": (_I, []),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
     "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 14 + [_P]),
     "agl_conv2d_fwd_flops": (C.c_double, [_I] * 10),
@@ -37,7 +41,7 @@ SIGNATURES = {
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
     "agl_bn_stats_from_partials": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P]),
     "agl_conv2d_fwd_stats_floats": (_L, [_I] * 4),
-    "agl_conv2d_fwd_stats": (_I, [_P] * 5 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
+    "agl_conv2d_fwd_stats": (_I, [_P] * 7 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
     "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
@@ -104,6 +108,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 2     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -117,7 +122,12 @@ def load() -> C.CDLL:
                           f"(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc). "
                           f"This package has no CPU or eager fallback.")
     lib = C.CDLL(path)
+    lib.agl_version.restype, lib.agl_version.argtypes = _I, []
+    if lib.agl_version() != ABI_VERSION:
+        raise ImportError(f"{path} has ABI version {lib.agl_version()}, this binding needs {ABI_VERSION}: rebuild it (make -C csrc)")
     for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name):
+            raise ImportError(f"{path} does not export {name}: stale build, rebuild it (make -C csrc)")
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -169,11 +179,11 @@ def work_of(name, args) -> float:
     """Executed FLOPs (convolutions) or algorithmic HBM bytes (normalisation family) of one logged call."""
     lib = load()
     if name == "agl_conv2d_fwd":
-        return lib.agl_conv2d_fwd_flops(*args[6:15], args[18])
+        return lib.agl_conv2d_fwd_flops(*args[8:17], args[20])
     if name == "agl_conv2d_fwd_stats":
-        return lib.agl_conv2d_fwd_flops(*args[6:15], args[16])
+        return lib.agl_conv2d_fwd_flops(*args[8:17], args[18])
     if name == "agl_conv2d_bwd_data":
-        return lib.agl_conv2d_bwd_data_flops(*args[7:17], args[19])
+        return lib.agl_conv2d_bwd_data_flops(*args[9:19], args[21])
     if name == "agl_conv2d_bwd_weight":
         return lib.agl_conv2d_bwd_weight_flops(*args[5:17], args[18])
     if name == "agl_bn_stats":                       # one read of x (SURVEY 8d: 4*N*C*HW)
@@ -203,7 +213,8 @@ def call(name: str, *args):
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        log.append((name, e0, e1, work_of(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-15:]))
+        pipe = lib.agl_conv2d_last_pipe() if name.startswith("agl_conv2d") else -1
+        log.append((name, e0, e1, work_of(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-15:], pipe))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
@@ -244,8 +255,72 @@ def conv_out_size(h, ks, stride, pad, up=0):
     return ((h << up) + 2 * pad - ks) // stride + 1
 
 
+# --------------------------------------------------------------------------- packed-weight cache
+# The matrix-core patch kernels read their weights in a packed bf16 layout (include/agl.h agl_conv2d_pack_weights).  Packing per
+# call cost ~640 launches / 5.6 ms per training iteration although the generator's weights are constant for a whole iteration and
+# a discriminator's weight_orig between two optimiser updates; only sigma of the spectral norm changes per forward call, and the
+# kernels divide by it in their epilogue.  A WeightSrc names where the values of a convolution weight come from; the packed
+# buffers live on the owning parameter and are re-made when its version changes.
+PACK_STATS = {"packs": 0, "hits": 0}
+
+
+class WeightSrc:
+    """Handle of the packed forms of one convolution weight.
+
+    owner   : the nn.Parameter (of a flat arena, agl.flat.FlatParams) the values derive from; holds the cache
+    version : callable -> hashable that changes whenever the values change (arena epoch, tensor version counters)
+    base    : tensor to pack on a miss (None: the weight tensor handed to the call, e.g. a fresh concatenation)
+    div     : optional 1-element device tensor with w = base / div (spectral norm's sigma of THIS forward call)
+    tag     : distinguishes derived forms that share an owner"""
+
+    __slots__ = ("owner", "version", "base", "div", "tag")
+
+    def __init__(self, owner, version, base=None, div=None, tag=""):
+        self.owner, self.version, self.base, self.div, self.tag = owner, version, base, div, tag
+
+    def derived(self, tag):
+        return WeightSrc(self.owner, self.version, self.base, self.div, self.tag + tag)
+
+    def packed(self, pass_, nbytes, w, Cin, Cout, ks, stride, make=None):
+        """Packed buffer for (pass, arithmetic) — from the cache, or packed now from `make()` / base / w."""
+        cache = self.owner.__dict__.setdefault("_agl_packs", {})
+        arith = CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3)
+        key = (self.tag, pass_, arith, ks, 2 if (pass_ == 1 and stride == 2) else 1)
+        ver = self.version()
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver and hit[1].numel() >= nbytes:
+            PACK_STATS["hits"] += 1
+            return hit[1]
+        src = make() if make is not None else (self.base if self.base is not None else w)
+        buf = hit[1] if (hit is not None and hit[1].numel() >= nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+        call("agl_conv2d_pack_weights", ptr(src.detach()), buf.data_ptr(), buf.numel(), pass_, Cin, Cout, ks, stride, CONV_FLAGS, stream())
+        PACK_STATS["packs"] += 1
+        cache[key] = (ver, buf)
+        return buf
+
+
+_packed_bytes_memo = {}
+
+
+def _packed_bytes(fn, *dims):
+    key = (fn,) + dims
+    v = _packed_bytes_memo.get(key)
+    if v is None:
+        v = _packed_bytes_memo[key] = getattr(load(), fn)(*dims)
+    return v
+
+
 # --------------------------------------------------------------------------- raw ops (no autograd)
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False):
+def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up):
+    if wsrc is None or not (CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3)):
+        return None, None
+    nb = _packed_bytes("agl_conv2d_fwd_packed_bytes", N, Cin, H, W, Cout, ks, stride, pad, up, CONV_FLAGS)
+    if not nb:
+        return None, None
+    return wsrc.packed(0, nb, w, Cin, Cout, ks, stride), wsrc.div
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None):
     N, Cin, H, W = x.shape
     Cout, Cin_w, ks, ks2 = w.shape
     assert Cin_w == Cin and ks == ks2, (x.shape, w.shape)
@@ -257,13 +332,14 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
         assert tuple(out.shape) == (N, Cout, OH, OW)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
-    call("agl_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
-         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up) if not (relu and accumulate) else (None, None)
+    call("agl_conv2d_fwd", ptr(x), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out),
+         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
          int(in_relu), int(relu), int(accumulate), CONV_FLAGS, stream())
     return out
 
 
-def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False):
+def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, wsrc=None):
     """conv2d_fwd that also returns the BatchNorm partial rows of its output: (y, partials or None, rows)."""
     N, Cin, H, W = x.shape
     Cout, Cin_w, ks, ks2 = w.shape
@@ -275,7 +351,9 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False):
     nst = load().agl_conv2d_fwd_stats_floats(N, Cout, OH, OW)
     stats = torch.empty(nst, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
-    call("agl_conv2d_fwd_stats", ptr(x), ptr(w), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up)
+    call("agl_conv2d_fwd_stats", ptr(x), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out),
+         ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), CONV_FLAGS,
          stats.data_ptr(), nst, C.addressof(rows), stream())
     return out, (stats if rows.value > 0 else None), rows.value
@@ -289,19 +367,38 @@ def bn_stats_from_partials(partials, rows, Cc, count, eps, momentum, running_mea
     return mean, rstd
 
 
-def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accumulate=False):
-    """dx (N,Cin,IH,IW) from dy (N,Cout,OH,OW), w (Cout,Cin,ks,ks).  Also ConvTranspose2d forward."""
+def bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad):
+    """Bytes of the packed weights when this input-gradient call runs on the matrix-core patch kernel, else 0."""
+    if not (CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3)):
+        return 0
+    return _packed_bytes("agl_conv2d_bwd_data_packed_bytes", N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, CONV_FLAGS)
+
+
+def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accumulate=False, wsrc=None, w_shape=None, make_w=None,
+                    make_base=None):
+    """dx (N,Cin,IH,IW) from dy (N,Cout,OH,OW), w (Cout,Cin,ks,ks).  Also ConvTranspose2d forward.
+    w may be None when w_shape + make_w are given: the weights are then a derived tensor that is only materialised when needed —
+    make_w() builds w itself (for launches that read it), make_base() the tensor whose packed form is cached under wsrc
+    (w = make_base() / wsrc.div)."""
     N, Cout, OH, OW = dy.shape
-    Cout_w, Cin, ks, _ = w.shape
-    assert Cout_w == Cout, (dy.shape, w.shape)
+    Cout_w, Cin, ks, _ = w.shape if w is not None else w_shape
+    assert Cout_w == Cout, (dy.shape, w_shape if w is None else w.shape)
     IH, IW = in_hw
     if out is None:
         assert not accumulate
         out = torch.empty((N, Cin, IH, IW), dtype=torch.float32, device=dy.device)
     need = load().agl_conv2d_bwd_data_ws_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad)
     ws = workspace(need, dy.device) if need else None
-    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(pos_mask), ptr(out), ws.data_ptr() if ws is not None else None,
-         ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, 0, int(accumulate), CONV_FLAGS, stream())
+    pk = pdiv = None
+    if wsrc is not None:
+        nb = bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad)
+        if nb:
+            pk, pdiv = wsrc.packed(1, nb, w, Cin, Cout, ks, stride, make=make_base), wsrc.div
+    if w is None and pk is None:
+        w = make_w()
+    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None, ptr(pos_mask), ptr(out),
+         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad,
+         0, int(accumulate), CONV_FLAGS, stream())
     return out
 
 

@@ -67,6 +67,8 @@ class Trainer:
         if self.sync.enabled:                       # identical replicas: rank 0's weights and buffers everywhere
             self.sync.broadcast_(self.flat_g.p)     # (spectral-norm u/v are randomly initialised buffers)
             self.sync.broadcast_(self.flat_d.p)
+            self.flat_g.touch()
+            self.flat_d.touch()
             for net in (netG, netD_image, netD_object, netD_att):
                 for buf in net.buffers():
                     self.sync.broadcast_(buf)

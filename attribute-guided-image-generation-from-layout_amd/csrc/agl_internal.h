@@ -33,8 +33,9 @@ static inline int agl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // out[i] (+)= sum over `splits` slabs of n floats (conv.hip); deterministic for a given slab count
 int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name);
 // out[o] = epilogue(sum over slabs) with bias[(o / HW) % C], ReLU mask, accumulate, ReLU (conv.hip)
+// (out_div: optional device scalar, the slab sum is divided by it first)
 int agl_launch_splitk_epilogue(const float* slabs, float* out, long n, int splits, int HW, int C, const float* bias, const float* pos_mask,
-                               int accumulate, int relu, hipStream_t st, const char* name);
+                               int accumulate, int relu, hipStream_t st, const char* name, const float* out_div = nullptr);
 
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {

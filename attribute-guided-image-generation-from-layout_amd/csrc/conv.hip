@@ -908,11 +908,13 @@ __global__ void flip_transpose_w(const float* __restrict__ t, float* __restrict_
 
 // out[o] = epilogue(sum_z part[z][o]); channel of o = (o / HW) % C
 __global__ void splitk_epilogue(const float* __restrict__ part, float* __restrict__ out, long n, int splits, int HW, int C,
-                                const float* __restrict__ bias, const float* __restrict__ pos_mask, int accumulate, int relu) {
+                                const float* __restrict__ bias, const float* __restrict__ pos_mask, int accumulate, int relu,
+                                const float* __restrict__ out_div = nullptr) {
   long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   float v = 0.f;
   for (int z = 0; z < splits; ++z) v += part[(long)z * n + o];
+  if (out_div) v *= 1.0f / *out_div;
   if (bias) v += bias[(o / HW) % C];
   if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
   if (accumulate) v += out[o];
@@ -922,8 +924,9 @@ __global__ void splitk_epilogue(const float* __restrict__ part, float* __restric
 
 }  // namespace
 int agl_launch_splitk_epilogue(const float* slabs, float* out, long n, int splits, int HW, int C, const float* bias, const float* pos_mask,
-                               int accumulate, int relu, hipStream_t st, const char* name) {
-  hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, HW, C, bias, pos_mask, accumulate, relu);
+                               int accumulate, int relu, hipStream_t st, const char* name, const float* out_div) {
+  hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, HW, C, bias, pos_mask, accumulate, relu,
+                     out_div);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
@@ -1433,7 +1436,7 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
   AGL_CHECK_LAUNCH(name);
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, a.y, out_numel, splits,
-                       a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu);
+                       a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH(name);
   }
   return AGL_OK;
@@ -1502,13 +1505,17 @@ static int pos_conv_fwd(const float* x, const float* w, const float* bias, float
   if (rc != AGL_OK) return rc;
   if (pl.splits > 1) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(pl.yt, 256)), dim3(256), 0, st, (const float*)slabs, yt, pl.yt, pl.splits, N, Cout,
-                       bias, (const float*)nullptr, 0, relu);
+                       bias, (const float*)nullptr, 0, relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH("agl_conv2d_fwd(position-major split-K epilogue)");
   }
   return launch_transpose_out(yt, y, pos_mask, N, Cout, Q, accumulate, st);
 }
 
 bool ks_ok(int k) { return k == 1 || k == 3 || k == 4 || k == 5 || k == 7; }
+
+// Arithmetic pipe of the main kernel the last agl_conv2d_* call of this thread launched (agl_conv2d_last_pipe):
+// 0 exact fp32 (fp32 MFMA or VALU), 1 bf16 MFMA (one product per MAC), 3 bf16 MFMA with split operands (six products per MAC)
+thread_local int g_last_pipe = 0;
 
 }  // namespace
 
@@ -1535,33 +1542,36 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
   return need;
 }
 
-static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                           int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                           int flags, void* stream, float* stats, long stats_floats, int* stat_rows);
+static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
+                           void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
+                           int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
+                           int* stat_rows);
 
-int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                   int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                   int flags, void* stream) {
-  return conv2d_fwd_impl(x, w, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, relu, accumulate, flags,
-                         stream, nullptr, 0, nullptr);
+int agl_conv2d_fwd(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws,
+                   long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu,
+                   int accumulate, int flags, void* stream) {
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, relu,
+                         accumulate, flags, stream, nullptr, 0, nullptr);
 }
 
 // Forward convolution that may also hand back the BatchNorm partial sums of its output (include/agl.h)
-int agl_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                         int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int flags, float* stats,
-                         long stats_floats, int* stat_rows, void* stream) {
+int agl_conv2d_fwd_stats(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
+                         void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
+                         int in_relu, int flags, float* stats, long stats_floats, int* stat_rows, void* stream) {
   AGL_REQUIRE(stats && stat_rows && stats_floats >= 0, "agl_conv2d_fwd_stats: null statistics buffer");
   *stat_rows = 0;
-  return conv2d_fwd_impl(x, w, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, 0, 0, flags, stream, stats,
-                         stats_floats, stat_rows);
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, 0, 0,
+                         flags, stream, stats, stats_floats, stat_rows);
 }
 
 long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW) { return pconv_stat_rows_max(N, OH, OW) * Cout * 2; }
 
-static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                           int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                           int flags, void* stream, float* stats, long stats_floats, int* stat_rows) {
-  AGL_REQUIRE(x && w && y, "agl_conv2d_fwd: null pointer");
+static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
+                           void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
+                           int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
+                           int* stat_rows) {
+  AGL_REQUIRE(x && (w || packed_w) && y, "agl_conv2d_fwd: null pointer");
+  g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2) && up_log2 >= 0 && up_log2 <= 4,
               "agl_conv2d_fwd: unsupported ks=%d stride=%d up=%d", ks, stride, up_log2);
@@ -1571,7 +1581,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64 && (long)H * W * 8 < (1L << 18))   // (linear layers, HW = 1, stay on the GEMM; 18-bit patch table)
+  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64 && (long)H * W * 8 < (1L << 18) && w)   // (linear layers, HW = 1, stay on the GEMM; 18-bit patch table)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
@@ -1580,9 +1590,13 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
-    if (prc >= 0) return prc;
+    if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  AGL_REQUIRE(w, "agl_conv2d_fwd: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
+                 "(ask agl_conv2d_fwd_packed_bytes first)");
+  g_last_pipe = co.prec;
   if (pos_ok(co, N, Cin, H, W, Cout, ks, up_log2) && !(relu && accumulate)) {
     const PosPlan pl = pos_fwd_plan(N, Cin, H, W, Cout, ks, stride, pad);
     if (ws && ws_bytes >= pl.total())
@@ -1617,7 +1631,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
   if (rc != AGL_OK) return rc;
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, y, out_numel, splits,
-                       OH * OW, Cout, bias, (const float*)nullptr, accumulate, relu);
+                       OH * OW, Cout, bias, (const float*)nullptr, accumulate, relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH("agl_conv2d_fwd(split-K epilogue)");
   }
   return AGL_OK;
@@ -1659,10 +1673,11 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
 
 // dx[N,Cin,IH,IW] = conv2d_backward_input(dy[N,Cout,OH,OW], w[Cout,Cin,ks,ks]).  Also the forward of
 // ConvTranspose2d (weight [C_in_T = Cout][C_out_T = Cin][ks][ks]).
-int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
-                        long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
-                        int relu, int accumulate, int flags, void* stream) {
-  AGL_REQUIRE(dy && w && dx, "agl_conv2d_bwd_data: null pointer");
+int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, const float* packed_div, const float* bias,
+                        const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
+                        int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream) {
+  AGL_REQUIRE(dy && (w || packed_w) && dx, "agl_conv2d_bwd_data: null pointer");
+  g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && (ks == 4 || ks == 3))), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 && IH > 0 && IW > 0, "agl_conv2d_bwd_data: empty extent");
@@ -1671,7 +1686,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
-  if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18))   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
+  if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18) && w)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
   if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
@@ -1679,9 +1694,14 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
-    if (prc >= 0) return prc;
+    if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  g_last_pipe = co.prec;
+  if (stride == 1)
+    AGL_REQUIRE(w, "agl_conv2d_bwd_data: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
+                   "(ask agl_conv2d_bwd_data_packed_bytes first)");
   if (stride == 1 && IH == OH && IW == OW && !bias && !relu && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0)) {
     // "same" convolution: dx = forward convolution of dy with flipped taps, channel roles swapped, pad ks-1-pad
     const PosPlan pl = pos_fwd_plan(N, Cout, OH, OW, Cin, ks, 1, ks - 1 - pad);
@@ -1703,9 +1723,13 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
     a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
     a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases)");
-    if (prc >= 0) return prc;
+    if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  AGL_REQUIRE(w, "agl_conv2d_bwd_data: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
+                 "(ask agl_conv2d_bwd_data_packed_bytes first)");
+  g_last_pipe = co.prec;
   const long out_numel = (long)N * Cin * IH * IW;
   const int tpa = (ks + stride - 1) / stride;                    // taps per axis of the fullest stride phase
   const int phases = stride * stride, Kp = Cout * tpa * tpa;
@@ -1745,7 +1769,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, cons
   if (rc != AGL_OK) return rc;
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, dx, out_numel, splits,
-                       IH * IW, Cin, bias, pos_mask, accumulate, relu);
+                       IH * IW, Cin, bias, pos_mask, accumulate, relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH("agl_conv2d_bwd_data(split-K epilogue)");
   }
   return AGL_OK;
@@ -1895,6 +1919,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
                           int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu, int accumulate, int flags,
                           void* stream) {
   AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
+  g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
@@ -1914,8 +1939,9 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
     a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = co.prec == 1 ? 1 : 3;
     const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww)");
-    if (prc >= 0) return prc;
+    if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  g_last_pipe = co.prec;
   if (stride == 1 && H == OH && W == OW && up_log2 == 0 && !in_relu && ks == 5 && pad == ks / 2 && Cin >= 64 &&
       pos_ok(co, N, 64, H, W, Cout, ks, 0)) {
     const PosBwwPlan pl = pos_bww_plan(N, Cin, H, W, Cout, OH, OW, ks, 1, pad);
@@ -1971,6 +1997,62 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, 
     if (rc != AGL_OK) return rc;
   }
   return AGL_OK;
+}
+
+int agl_conv2d_last_pipe(void) { return g_last_pipe; }
+
+// ---- pre-packed weights (include/agl.h): bytes of the packed form when the call would run on the LDS-patch kernel, else 0
+long agl_conv2d_fwd_packed_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (!(co.patch && (co.prec == 1 || co.split3)) || !ks_ok(ks) || !(stride == 1 || stride == 2)) return 0;
+  const int Hl = H << up_log2, Wl = W << up_log2;
+  const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
+  if (Cout <= 4 || OH <= 0 || OW <= 0) return 0;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
+  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+  return pconv_eligible(a) ? pconv_ws_bytes(Cin, Cout, ks, a.nsplit) : 0;
+}
+long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (!(co.patch && (co.prec == 1 || co.split3)) || !ks_ok(ks) || Cin <= 4) return 0;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.up = 0;
+  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+  if (stride == 1 && IH == OH && IW == OW) {
+    a.stride = 1; a.pad = ks - 1 - pad;
+    return pconv_eligible(a) ? pconv_ws_bytes(Cout, Cin, ks, a.nsplit) : 0;
+  }
+  if (stride == 2 && ks == 4) {
+    a.stride = 2; a.pad = pad;
+    return pconvT_eligible(a) ? pconvT_ws_bytes(Cout, Cin, a.nsplit) : 0;
+  }
+  return 0;
+}
+// pass 0: for agl_conv2d_fwd; 1: for agl_conv2d_bwd_data.  w is [Cout][Cin][ks][ks]; `packed` must hold the bytes the matching
+// *_packed_bytes query returned for the calls it will be used with (the packed form depends on Cin, Cout, ks, stride and flags only).
+int agl_conv2d_pack_weights(const float* w, void* packed, long packed_bytes, int pass, int Cin, int Cout, int ks, int stride, int flags,
+                            void* stream) {
+  AGL_REQUIRE(w && packed, "agl_conv2d_pack_weights: null pointer");
+  const ConvOpts co = conv_opts(flags);
+  AGL_REQUIRE(co.prec == 1 || co.split3, "agl_conv2d_pack_weights: flags select no matrix-core arithmetic (AGL_CONV_BF16 / AGL_CONV_SPLIT3)");
+  const int ns = co.prec == 1 ? 1 : 3;
+  hipStream_t st = (hipStream_t)stream;
+  if (pass == 0) {
+    const long need = pconv_ws_bytes(Cin, Cout, ks, ns);
+    AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_weights: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+    return pconv_pack(w, packed, Cout, Cin, ks, Cin * ks * ks, ks * ks, 0, ns, 0, st, "agl_conv2d_pack_weights(fwd)");
+  }
+  AGL_REQUIRE(pass == 1, "agl_conv2d_pack_weights: pass must be 0 (forward) or 1 (input gradient)");
+  if (stride == 2) {
+    AGL_REQUIRE(ks == 4, "agl_conv2d_pack_weights: the stride-2 input gradient is packed for 4x4 kernels only");
+    const long need = pconvT_ws_bytes(Cout, Cin, ns);
+    AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_weights: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+    return pconv_pack(w, packed, Cin, Cout, 4, 16, Cin * 16, 0, ns, 1, st, "agl_conv2d_pack_weights(bwd_data, stride 2)");
+  }
+  const long need = pconv_ws_bytes(Cout, Cin, ks, ns);
+  AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_weights: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+  return pconv_pack(w, packed, Cin, Cout, ks, ks * ks, Cin * ks * ks, 1, ns, 0, st, "agl_conv2d_pack_weights(bwd_data)");
 }
 
 // Executed FLOPs (2*MAC) of the launches one call of the entry points above issues for these extents and flags, assuming

@@ -10,7 +10,14 @@ struct PConvArgs {
   int nsplit;                       // 1: bf16 operands (AGL_CONV_BF16); 3: fp32 operands as three bf16 terms, six products
   int any_grid;                     // launch also below the occupancy threshold (AGL_CONV_ANY_GRID)
   float* stats; long stats_floats; int* stat_rows;   // optional BatchNorm partials of the output: buffer, its capacity, rows written
+  const void* packed;               // optional: the weights already in packed form (pconv_pack / pconvT_pack with the same nsplit) — no
+                                    // per-call pack_weights_k launch; the packed tensor w0 may differ from w by a scalar: w = w0 / *out_div
+  const float* out_div;             // optional device scalar: the accumulated products are divided by it before bias / mask / ReLU
 };
+// Packed form of a weight tensor for pconv_try (forward: flip 0, w_sm = Cin*ks*ks, w_sc = ks*ks; "same" input gradient: flip 1, roles
+// swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
+int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, hipStream_t st,
+               const char* name);
 // Upper bound of the partial rows pconv_try writes for an output of N images of OH x OW pixels
 long pconv_stat_rows_max(int N, int OH, int OW);
 

@@ -41,7 +41,8 @@ struct PArgs {
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
   int cps;           // (each slab is shaped like y; splitk_epilogue of conv.hip adds them and applies the epilogue)
   long out_numel;
-};
+  const float* odiv; // optional device scalar: the products are divided by it before bias / mask / ReLU (pre-packed weights of a
+};                   // spectrally normalised layer: packed W_orig, divisor sigma)
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
 __device__ __forceinline__ void split3(float a, __bf16& t0, __bf16& t1, __bf16& t2) {
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   // loads for the optional mask / accumulate operands, issued together — no per-element load-then-wait chains).
   float* const ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_PITCH);
   const long OHW = (long)p.OH * p.OW;
+  const float osc = (p.odiv && !p.slabs) ? 1.0f / *p.odiv : 1.0f;     // (slabs carry raw sums: the slab reduction divides)
   const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8*pass, columns ec..ec+3
   // BatchNorm statistics of the output (p.stats): every lane sums the values it stores, per channel row
   float ssum[WTM][4], ssq[WTM][4];
@@ -359,14 +361,20 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
       // (one wave writes and reads its own scratch: the LDS accesses of a wave are ordered, no barrier needed)
       float4 v[4];
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+      for (int ps = 0; ps < 4; ++ps) {
+        v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+        v[ps].x *= osc; v[ps].y *= osc; v[ps].z *= osc; v[ps].w *= osc;
+      }
       const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
       if constexpr (PAIR) {       // both column phases: pixel (a, b..b+3) -> row 2a+ph, columns 2b .. 2b+7 — two 16-byte stores
         float4 v1[4];
 #pragma unroll
         for (int r2 = 0; r2 < 16; ++r2) ep[((r2 & 3) + 8 * (r2 >> 2) + 4 * lh) * EP_PITCH + l31] = accs[NPW - 1][0][i][jt][r2];
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) v1[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+        for (int ps = 0; ps < 4; ++ps) {
+          v1[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
+          v1[ps].x *= osc; v1[ps].y *= osc; v1[ps].z *= osc; v1[ps].w *= osc;
+        }
         const long OHW2 = 4 * OHW;
         const bool iok = img < p.N;
         const long ob = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * (2 * p.OW) + 2 * (tx0 + px);
@@ -842,17 +850,18 @@ long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * O
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   PConvPlan pl;
   if (pconv_plan(a, pl) != 0) return -1;
-  const long packed = pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);
+  const long packed = a.packed ? 0 : pconv_ws_bytes(a.Cin, a.Cout, a.ks, a.nsplit);     // (pre-packed weights: ws holds the slabs only)
   const long out_numel = (long)a.N * a.Cout * a.OH * a.OW;
   const long need = packed + (pl.splits > 1 ? out_numel * 4 * pl.splits : 0);
-  if (!ws || ws_bytes < need) return -1;
+  if (need > 0 && (!ws || ws_bytes < need)) return -1;
   const int geo = pl.geo, bm = pl.bm;
   const bool s2 = pl.s2, w32 = pl.w32, wide = pl.wide, half = pl.half;
   const long ptiles = pl.ptiles;
   (void)half;
   const int KK = a.ks * a.ks, nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
-  u32x4* wp = (u32x4*)ws;
+  u32x4* wp = a.packed ? (u32x4*)a.packed : (u32x4*)ws;
   PArgs p;
+  p.odiv = a.out_div;
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
@@ -865,10 +874,10 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
-  const long per_plane = (long)nch * 2 * KK * mpad;
-  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, KK, a.w_sm,
-                     a.w_sc, a.flip, mpad, nch, a.nsplit, 0);
-  AGL_CHECK_LAUNCH(name);
+  if (!a.packed) {
+    const int prc = pconv_pack(a.w, wp, a.Cout, a.Cin, a.ks, a.w_sm, a.w_sc, a.flip, a.nsplit, 0, st, name);
+    if (prc != AGL_OK) return prc;
+  }
 #define PC_LAUNCH(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
 #define PC_LAUNCH_DB(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
@@ -948,7 +957,18 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_LAUNCH_DB
   AGL_CHECK_LAUNCH(name);
   if (pl.splits > 1)
-    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, (int)g.z, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name);
+    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, (int)g.z, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name,
+                                      a.out_div);
+  return AGL_OK;
+}
+
+int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, hipStream_t st,
+               const char* name) {
+  const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
+                     flip, mpad, nch, nsplit, phase4);
+  AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
 
@@ -992,15 +1012,17 @@ long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel) {
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int geo, bm, splits; long ptiles;
   if (pconvT_plan(a, &geo, &bm, &ptiles, &splits) != 0) return -1;
-  const long packed = pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit), out_numel = (long)a.N * a.Cout * a.OH * a.OW;
-  if (!ws || ws_bytes < packed + (splits > 1 ? out_numel * 4 * splits : 0)) return -1;
+  const long packed = a.packed ? 0 : pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit), out_numel = (long)a.N * a.Cout * a.OH * a.OW;
+  const long need = packed + (splits > 1 ? out_numel * 4 * splits : 0);
+  if (need > 0 && (!ws || ws_bytes < need)) return -1;
   const int nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
-  u32x4* wp = (u32x4*)ws;
-  const long per_plane = (long)nch * 2 * 16 * mpad;
-  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.Cout, a.Cin, 16, a.w_sm,
-                     a.w_sc, 0, mpad, nch, a.nsplit, 1);
-  AGL_CHECK_LAUNCH(name);
+  u32x4* wp = a.packed ? (u32x4*)a.packed : (u32x4*)ws;
+  if (!a.packed) {
+    const int prc = pconv_pack(a.w, wp, a.Cout, a.Cin, 4, a.w_sm, a.w_sc, 0, a.nsplit, 1, st, name);
+    if (prc != AGL_OK) return prc;
+  }
   PArgs p;
+  p.odiv = a.out_div;
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
@@ -1023,7 +1045,8 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
 #undef PT_LAUNCH
   AGL_CHECK_LAUNCH(name);
   if (splits > 1)
-    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, splits, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name);
+    return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, splits, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name,
+                                      a.out_div);
   return AGL_OK;
 }
 

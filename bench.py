@@ -33,8 +33,19 @@ FLOPS_PER_IMAGE = {64: (7.334e10, 6.566e10), 128: (6.202e11, 2.232e11)}
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# JSON dtype = arithmetic type of the tensors / accumulation; how the products are formed is spelled out in config.arithmetic
-DTYPE_NAME = {"f32": "f32", "f32x3": "f32", "bf16": "bf16"}
+# Peak of the pipe a convolution launch ran on (agl_conv2d_last_pipe): 0 exact fp32 (fp32 MFMA / fp32 VALU, same 157.3 peak);
+# 1 bf16 MFMA, one product per multiply-add; 3 bf16 MFMA with split operands: SIX MFMA products per fp32 multiply-add, i.e. a
+# 2500/6 = 416.7 TFLOP/s ceiling in fp32-equivalent FLOPs.
+PIPE_PEAK = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS, 3: PEAK_BF16_MFMA_TFLOPS / 6.0}
+PIPE_NAME = {0: "fp32 (MFMA 32x32x2 f32 / VALU)", 1: "bf16 MFMA", 3: "bf16 MFMA, split operands (6 products per MAC)"}
+# JSON dtype = how the multiply-adds are computed: "f32x3" = fp32 tensors and accumulation with every product formed from three
+# bf16 terms per operand on the bf16 matrix cores (config.products spells it out first); "f32" = exact fp32 MFMA everywhere
+DTYPE_NAME = {"f32": "f32", "f32x3": "f32x3", "bf16": "bf16"}
+PRODUCTS = {
+    "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution",
+    "f32x3": "bf16x3 split products: fp32 tensors, 6 bf16-MFMA products per fp32 multiply-add (fp32-accurate), fp32 accumulation",
+    "bf16": "bf16 MFMA operands (rounded once when staged), fp32 accumulation, fp32 tensors in HBM",
+}
 ARITHMETIC = {
     "f32": "fp32 tensors; every convolution on exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
     "f32x3": "fp32 tensors and fp32 accumulation; in the LDS-patch kernels (csrc/pconv.hip: 1x1/3x3/5x5 stride 1, 4x4/3x3 stride 2 "
@@ -206,6 +217,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         # collective): HIP events around every convolution launch (>99.9 % of the FLOPs) and every normalisation-family
         # launch (the dominant HBM-bound kernels) on the stream they are launched on; rank 0 reports.
         L.EVENT_LOG = [] if rank == 0 else None
+        packs0 = L.PACK_STATS["packs"]
         one_step()
         tr.finish()
         fence()
@@ -217,7 +229,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         if os.environ.get("AGL_DUMP_CONV"):
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-            for name, e0, e1, f, dims in conv:
+            for name, e0, e1, f, dims, _pipe in conv:
                 k = (name.replace('agl_conv2d_', ''), dims)
                 agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
             by_ms = os.environ.get("AGL_DUMP_SORT") == "ms"
@@ -226,21 +238,33 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/157.3e9:6.2f} ms  dims {dims}', file=sys.stderr)
         c0, c1 = FLOPS_PER_IMAGE[res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic (reference graph), per GPU per step
-        # f32x3: the peak stays the fp32-MFMA figure the fp32 workload is priced against (the split kernels run on the bf16 pipe at
-        # 6 products per fp32 product, i.e. a 417 TFLOP/s fp32-equivalent ceiling; frac is still quoted against 157.3)
-        peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        ex_tf = executed / (conv_ms * 1e-3) / 1e12
-        # achieved / frac: FLOPs the timed launches actually execute (C-ABI agl_conv2d_*_flops: dense count minus the
-        # padded taps the position-major path skips) / their measured duration.  The reference graph's FLOPs over the
-        # same time are reported separately (algorithmic_equiv_tflops): the legal savings of DESIGN.md §3 make that
-        # figure larger than what the hardware executes, so it is throughput, not utilisation.
-        roof = {"bound": "mfma", "achieved": round(ex_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ex_tf / peak, 4),
-                "traffic": None,
+        # Utilisation of the pipes actually used: every convolution launch is priced against the peak of the pipe its main kernel
+        # ran on (the C ABI reports it per call: agl_conv2d_last_pipe), frac = sum_launches(executed FLOPs / peak of its pipe) /
+        # sum_launches(measured time) = time the launches would take at peak / time they took: <= 1 by construction.  Executed
+        # FLOPs = C-ABI agl_conv2d_*_flops (dense 2*MAC count minus the padded taps the position-major path skips).  `achieved`
+        # is quoted on the bf16 matrix pipe (frac x 2500), where > 80 % of the time is spent in both arithmetic modes; by_pipe has
+        # the per-pipe numbers.  The reference graph's FLOPs over the same time are reported separately (algorithmic_equiv_tflops):
+        # the legal savings of DESIGN.md §3 make that figure larger than what the hardware executes: throughput, not utilisation.
+        by_pipe, t_at_peak = {}, 0.0
+        for pipe in sorted({e[5] for e in conv}):
+            sel = [e for e in conv if e[5] == pipe]
+            ms = sum(e[1].elapsed_time(e[2]) for e in sel)
+            fl = sum(e[3] for e in sel)
+            t_at_peak += fl / (PIPE_PEAK[pipe] * 1e12)
+            by_pipe[PIPE_NAME[pipe]] = {"launches": len(sel), "ms": round(ms, 3), "executed_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms else None,
+                                        "peak_tflops": round(PIPE_PEAK[pipe], 1), "frac": round(fl / (PIPE_PEAK[pipe] * 1e12) / (ms * 1e-3), 4) if ms else None}
+        frac = t_at_peak / (conv_ms * 1e-3)
+        roof = {"bound": "mfma", "achieved": round(frac * PEAK_BF16_MFMA_TFLOPS, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(frac, 4), "traffic": None,
+                "definition": "sum over conv launches of executed FLOPs / peak of the pipe the launch ran on (fp32 157.3, bf16 MFMA 2500, "
+                              "split-operand bf16 MFMA 2500/6 fp32-equivalent), divided by the launches' measured time; achieved = frac x 2500",
+                "by_pipe": by_pipe,
                 "kernel": "convolution family: pconv_k / pbww_k (bf16 matrix cores) + igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + "
-                          "few_bww_k / small_cout_conv incl. their weight packing and slab / split-K reductions (all agl_conv2d_* launches of one step)",
+                          "few_bww_k / small_cout_conv incl. weight packing and slab / split-K reductions (all agl_conv2d_* launches of one step)",
                 "launches_per_step": len(conv), "kernel_ms_per_step": round(conv_ms, 3),
                 "executed_flops_per_step": executed, "algorithmic_flops_per_step": flops_step,
-                "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3)}
+                "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3),
+                "weight_packs_per_step": L.PACK_STATS["packs"] - packs0}
         nrm = [e for e in log if e[0] in NORM_NAMES]
         nrm_ms = sum(e[1].elapsed_time(e[2]) for e in nrm)
         nbytes = sum(e[3] for e in nrm)
@@ -264,7 +288,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
     images = per_gpu * world * steps
     return {"value": round(images / dt, 3), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
             "dtype": DTYPE_NAME[dtype],
-            "config": {"arithmetic": ARITHMETIC[dtype], "workload": f"{res}x{res} G+D train step, batch={per_gpu}/GPU, {DTYPE_NAME[dtype]}, synthetic VG-shaped batch "
+            "config": {"products": PRODUCTS[dtype], "arithmetic": ARITHMETIC[dtype], "workload": f"{res}x{res} G+D train step, batch={per_gpu}/GPU, {DTYPE_NAME[dtype]}, synthetic VG-shaped batch "
                                    f"(P~U{{3..9}}), random-init weights; the batch and the pinned eps draws are resident in HBM "
                                    f"and reused every step (no H2D in the timed region)",
                        "global_batch": per_gpu * world, "objects_per_rank": objs, "parallelism": f"dp{world}",

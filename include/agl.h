@@ -18,6 +18,8 @@
 extern "C" {
 #endif
 
+/* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
+#define AGL_ABI_VERSION 2
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -56,24 +58,40 @@ const char* agl_last_error(void);
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
-int agl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                   int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu, int accumulate,
-                   int flags, void* stream);
+/* packed_w / packed_div (optional, both may be NULL): the weights already in the packed form of the matrix-core patch
+ * kernel (agl_conv2d_pack_weights) — the call then launches no per-call weight re-pack.  The packed tensor w0 may differ from w
+ * by a scalar divisor kept on the device, w = w0 / *packed_div: a spectrally normalised layer (discriminator.py:15-22) packs
+ * weight_orig once per optimiser update and passes sigma, which changes with every forward call.  Used only when the call runs
+ * on the patch kernel (agl_conv2d_*_packed_bytes != 0 for the same extents and flags); other launches read w, which may be NULL
+ * only when packed_w is given (the call is rejected if it then cannot run on the patch kernel). */
+int agl_conv2d_fwd(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws,
+                   long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu,
+                   int accumulate, int flags, void* stream);
+long agl_conv2d_fwd_packed_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags);
+long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+/* pass 0: packed form for agl_conv2d_fwd; 1: for agl_conv2d_bwd_data (stride 1 "same" form, or stride 2 with ks = 4).  It depends on
+ * (Cin, Cout, ks, stride, arithmetic flags) only, so one packed buffer serves every call of that layer until the weights change. */
+int agl_conv2d_pack_weights(const float* w, void* packed, long packed_bytes, int pass, int Cin, int Cout, int ks, int stride, int flags,
+                            void* stream);
+/* Arithmetic pipe of the main kernel the LAST agl_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_weight call of the calling thread
+ * launched: 0 = exact fp32 (fp32 MFMA or fp32 VALU), 1 = bf16 MFMA, one product per multiply-add (AGL_CONV_BF16), 3 = bf16 MFMA
+ * with split operands, six products per multiply-add (AGL_CONV_SPLIT3).  bench.py prices each launch against that pipe's peak. */
+int agl_conv2d_last_pipe(void);
 /* The same forward (no output ReLU, no accumulate) that may also leave the BatchNorm partial sums of its output in
  * `stats` — the statistics pass of the nn.BatchNorm2d that follows the convolution (generator_obj_att.py:54-57, 433, 583;
  * normalization.py:77-78 + 97) then needs no read of y.  stats: stats_floats floats (agl_conv2d_fwd_stats_floats());
  * *stat_rows = rows written, each row = [Cout][{sum, sum of squares}] over a disjoint set of output pixels — 0 when the
  * launch that ran does not produce them (the caller then uses agl_bn_stats).  Feed the rows to agl_bn_stats_from_partials. */
 long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW);
-int agl_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin, int H,
-                         int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int flags, float* stats,
-                         long stats_floats, int* stat_rows, void* stream);
+int agl_conv2d_fwd_stats(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
+                         void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
+                         int in_relu, int flags, float* stats, long stats_floats, int* stat_rows, void* stream);
 /* Gradient wrt the input of the conv above; ALSO the forward of nn.ConvTranspose2d(k=4,s=2,p=1)
  * (generator_obj_att.py:532,536,540) with w stored [C_in_T][C_out_T][4][4].  pos_mask (optional, shaped
  * like dx): dx is zeroed where pos_mask <= 0 (backward of a fused input ReLU).                      */
-int agl_conv2d_bwd_data(const float* dy, const float* w, const float* bias, const float* pos_mask, float* dx, void* ws,
-                        long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad,
-                        int relu, int accumulate, int flags, void* stream);
+int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, const float* packed_div, const float* bias,
+                        const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
+                        int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
 int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H,
                           int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,

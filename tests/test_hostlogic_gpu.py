@@ -167,8 +167,11 @@ def test_attribute_editing_loop_vs_oracle():
     eps = [torch.randn(O, 64, generator=gen) for _ in range(6)]
     d = {k: (v.to(DEV) if k != "obj_to_img" else v) for k, v in b.items()}
     d["attribute"] = d["attribute_gt"].clone()
+    Da.eval()                 # state-free classifier for the comparison below (the oracle calls use train=False)
+    G.train()
     res = edit_attributes_batch(G, Da, d, tgt=95, z=z, z_edit=z2, eps=eps[:3], eps_edit=eps[3:])
     torch.cuda.synchronize()
+    assert G.training and not Da.training, "module modes must be left as the caller set them"
     # ---- oracle
     with torch.no_grad():
         attr = b["attribute_gt"]
@@ -200,3 +203,37 @@ def test_attribute_editing_loop_vs_oracle():
             assert bool(ch[i]) == (i in changed), i
     img_ref = OH.imagenet_deprocess_batch(out[5])
     assert int((res["images"]["rand"].cpu().int() - img_ref.int()).abs().max()) <= 1
+
+
+def test_attribute_editing_loop_keeps_reference_module_modes():
+    """test64.py:114 puts only netG in eval mode: a train-mode netD_att runs one power iteration in each of its four forward
+    calls per batch (:129, :146, :180, :183).  The loop must make exactly those four calls and leave both modules' modes alone."""
+    import oracle.graph as OG, oracle.step as OS
+    from oracle.fill import fill_state
+    from agl import synth
+    from agl.infer import edit_attributes_batch
+    from models.generator_obj_att import Generator
+    from models.discriminator import AttributeDiscriminator, add_sn
+    G = Generator(num_embeddings=179, obj_att_dim=64, z_dim=64, clstm_layers=3, obj_size=32, attribute_dim=106)
+    Da = add_sn(AttributeDiscriminator(n_attribute=106))
+    for m in (G, Da):
+        m.load_state_dict(fill_state(m.state_dict()))
+    Pa = OS.as_params({k: v.clone() for k, v in Da.state_dict().items()})
+    G.to(DEV), Da.to(DEV)
+    bn = synth.make_batch(2, 64, seed=5, objs_per_image=[3, 2])
+    b = {k: torch.from_numpy(v) for k, v in bn.items()}
+    d = {k: (v.to(DEV) if k != "obj_to_img" else v) for k, v in b.items()}
+    d["attribute"] = d["attribute_gt"].clone()
+    G.train(), Da.train()
+    edit_attributes_batch(G, Da, d, tgt=95)
+    torch.cuda.synchronize()
+    assert G.training and Da.training
+    # the oracle's spectral-norm state after four training forwards of the attribute discriminator (inputs do not matter)
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        for _ in range(4):
+            OG.attribute_discriminator(Pa, x, True, False)
+    sd = Da.state_dict()
+    for k in sd:
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            assert torch.allclose(sd[k].cpu(), Pa[k], atol=2e-5), k

@@ -748,6 +748,79 @@ def test_conv_emits_batchnorm_partials(case, mode):
     assert part0 is None and rows0 == 0
 
 
+def test_split_products_accuracy_class_of_gradients_at_config2_extents():
+    """AGL_CONV_SPLIT3 is used by the weight-gradient kernel (pbww_k: reductions over ~4e5 pixels) and by the phase-mode
+    stride-2 input gradient as well as by the forward kernel; the accuracy-class check of the forward (error vs an fp64
+    result <= 2x the error of the exact fp32 MFMA kernel on the same problem) is repeated here for both, at BASELINE config 2
+    extents: N = 393 objects, 32x32 maps, 64 -> 128 channels (3x3 stride 1 weight gradient; 4x4 stride 2 input gradient and
+    weight gradient)."""
+    from agl import lib as L
+    N, H = 393, 32
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, 64, H, H, generator=g)
+    for ks, stride, pad, Cout in ((3, 1, 1, 128), (4, 2, 1, 128)):
+        OH = (H + 2 * pad - ks) // stride + 1
+        w = torch.randn(Cout, 64, ks, ks, generator=g) * (1.0 / (64 * ks * ks) ** 0.5)
+        dy = torch.randn(N, Cout, OH, OH, generator=g)
+        xd, wd, dyd = dev(x), dev(w), dev(dy)
+        x64 = x.double().requires_grad_(True)
+        w64 = w.double().requires_grad_(True)
+        TF.conv2d(x64, w64, None, stride=stride, padding=pad).backward(dy.double())
+        res = {}
+        for name, flags in (("exact", 0), ("split", L.CONV_SPLIT3)):
+            with L.conv_flags(flags):
+                res[name] = (L.conv2d_bwd_weight(dyd, xd, ks, stride, pad).cpu().double(),
+                             L.conv2d_bwd_data(dyd, wd, (H, H), stride, pad).cpu().double())
+        for i, (what, ref) in enumerate((("weight gradient", w64.grad), ("input gradient", x64.grad))):
+            e_exact = float((res["exact"][i] - ref).abs().max())
+            e_split = float((res["split"][i] - ref).abs().max())
+            assert e_split <= 2.0 * e_exact + 2e-7 * float(ref.abs().max()), (ks, stride, what, e_split, e_exact)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+def test_packed_weight_cache_and_divisor(mode):
+    """agl_conv2d_pack_weights + the packed_w / packed_div arguments (agl.lib.WeightSrc): a convolution that reads pre-packed
+    weights must equal the one that packs per call — forward 3x3 / 1x1 / 4x4 stride 2, the "same" input gradient, the stride-2
+    input gradient (ConvTranspose forward) — bit for bit without a divisor; with a divisor (spectral norm: packed weight_orig,
+    device scalar sigma) equal to the convolution with w / sigma to fp32 rounding; the cache must re-pack when the weight version
+    changes and only then."""
+    from agl import lib as L
+    flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
+    ver = [0]
+    for (N, Cin, H, Cout, ks, stride, pad) in ((6, 32, 16, 64, 3, 1, 1), (5, 64, 8, 128, 1, 1, 0), (4, 32, 16, 64, 4, 2, 1), (3, 48, 32, 80, 5, 1, 2)):
+        x, w = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5)
+        OH = (H + 2 * pad - ks) // stride + 1
+        dy = rn(N, Cout, OH, OH, seed=3)
+        owner = torch.nn.Parameter(dev(w).clone())
+        src = L.WeightSrc(owner, lambda: ver[0])
+        sigma = dev(torch.tensor([1.7]))
+        src_sn = L.WeightSrc(owner, lambda: ver[0], base=owner, div=sigma, tag="sn")
+        xd, dyd = dev(x), dev(dy)
+        with L.conv_flags(flags):
+            p0 = L.PACK_STATS["packs"]
+            y0 = L.conv2d_fwd(xd, owner.data, None, stride, pad)
+            y1 = L.conv2d_fwd(xd, owner.data, None, stride, pad, wsrc=src)
+            y2 = L.conv2d_fwd(xd, owner.data, None, stride, pad, wsrc=src)
+            assert torch.equal(y0, y1) and torch.equal(y0, y2)
+            assert L.PACK_STATS["packs"] == p0 + 1, "second call must hit the cache"
+            dx0 = L.conv2d_bwd_data(dyd, owner.data, (H, H), stride, pad)
+            dx1 = L.conv2d_bwd_data(dyd, owner.data, (H, H), stride, pad, wsrc=src)
+            assert torch.equal(dx0, dx1)
+            # divisor: w_sn = w / sigma is what the caller hands over as `w`; the kernels read the packed w and divide
+            w_sn = owner.data / sigma
+            ys = L.conv2d_fwd(xd, w_sn, None, stride, pad, wsrc=src_sn)
+            close(ys, L.conv2d_fwd(xd, w_sn, None, stride, pad), 2e-6 if mode == "split3" else 1e-2, "forward with divisor")
+            close(ys, y0 / 1.7, 1e-6, "forward with divisor == plain / sigma")
+            dxs = L.conv2d_bwd_data(dyd, w_sn, (H, H), stride, pad, wsrc=src_sn)
+            close(dxs, dx0 / 1.7, 1e-6, "input gradient with divisor == plain / sigma")
+            # new weight version: the cache must follow
+            owner.data.mul_(-0.5)
+            ver[0] += 1
+            y3 = L.conv2d_fwd(xd, owner.data, None, stride, pad, wsrc=src)
+            assert torch.equal(y3, L.conv2d_fwd(xd, owner.data, None, stride, pad))
+            close(y3, -0.5 * y0, 1e-5, "re-packed after the version change")
+
+
 FEW_BWW_CASES = [  # N, Cin, H, Cout, ks, pad, in_relu: weight gradients with <= 4 channels on one side (csrc/few.hip)
     (5, 3, 32, 64, 3, 1, 0), (4, 3, 32, 64, 1, 0, 0), (3, 3, 32, 64, 7, 3, 0), (2, 3, 64, 64, 3, 1, 1), (2, 3, 64, 80, 1, 0, 0),
     (2, 4, 32, 32, 3, 1, 0), (2, 1, 32, 48, 5, 2, 1), (1, 3, 128, 64, 5, 2, 0), (3, 2, 64, 128, 7, 3, 0), (2, 3, 32, 16, 3, 0, 0),
