@@ -20,6 +20,22 @@ class FlatParams:
         self.modules = list(modules)
         self.params: List[nn.Parameter] = [p for m in self.modules for p in m.parameters()]
         assert self.params, "no parameters"
+        # Arena order.  The optimiser and the gradient exchange are elementwise, so the arena need not follow .parameters()
+        # order: sub-modules may ask (agl_param_pairs) for two parameters to lie back to back, so that their concatenation along
+        # dim 0 is a zero-copy VIEW of the arena with a gradient slot of its own (SPADE's gamma|beta convolution: no concat
+        # kernels in forward / backward and no autograd add per half).
+        pairs = [(mod, name, a, b) for m in self.modules for mod in m.modules() if hasattr(mod, "agl_param_pairs")
+                 for (name, a, b) in mod.agl_param_pairs()]
+        second_of = {id(b): a for (_, _, a, b) in pairs}
+        first_of = {id(a): b for (_, _, a, b) in pairs}
+        order: List[nn.Parameter] = []
+        for p in self.params:
+            if id(p) in second_of:
+                continue                    # placed right behind its partner
+            order.append(p)
+            if id(p) in first_of:
+                order.append(first_of[id(p)])
+        assert len(order) == len(self.params) and len({id(p) for p in order}) == len(order)
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.n = n
@@ -31,9 +47,11 @@ class FlatParams:
         self.epoch = 0      # bumped whenever the arena is written through a raw pointer or an alias (Adam kernel, broadcast): the
                             # packed-weight caches of the parameters (agl.lib.WeightSrc) are keyed by (epoch, tensor version)
         o = 0
+        offset = {}
         with torch.no_grad():
-            for p in self.params:
+            for p in order:
                 k = p.numel()
+                offset[id(p)] = o
                 self.p[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.p[o:o + k].view(p.shape)
                 p.grad = self.g[o:o + k].view(p.shape)
@@ -41,6 +59,16 @@ class FlatParams:
                 if p.dim() == 4:            # convolution weights: handle of their packed forms
                     p._agl_wsrc = L.WeightSrc(p, (lambda p=p: (self.epoch, p._version)))
                 o += k
+        for mod, name, a, b in pairs:       # joined leaves: data and gradient alias the two neighbours' arena ranges
+            oa, k = offset[id(a)], a.numel() + b.numel()
+            assert offset[id(b)] == oa + a.numel() and a.shape[1:] == b.shape[1:]
+            shape = (a.shape[0] + b.shape[0],) + tuple(a.shape[1:])
+            j = self.p[oa:oa + k].view(shape).detach().requires_grad_(True)
+            j.grad = self.g[oa:oa + k].view(shape)
+            j._agl_slot = True
+            if j.dim() == 4:
+                j._agl_wsrc = L.WeightSrc(j, (lambda a=a, b=b: (self.epoch, a._version, b._version)))
+            mod.__dict__.setdefault("_agl_joined", {})[name] = j
 
     def zero_grad(self):
         self.g.zero_()

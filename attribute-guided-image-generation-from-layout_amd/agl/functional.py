@@ -100,12 +100,20 @@ class _Conv2d(torch.autograd.Function):
                 dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if (in_relu or x_relu) else None,
                                        wsrc=ctx.wsrc)
         wslot, bslot = ctx.slots
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            # the bias gradient rides on the weight-gradient kernel (it stages dy anyway) when both go the same way
+            # (both into their arena slots, or both into fresh tensors)
             if wslot is not None:
-                L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True)
+                fuse_b = want_b and bslot is not None
+                L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True, dbias=bslot if fuse_b else None)
             else:
-                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu)
-        if has_bias and ctx.needs_input_grad[2]:
+                fuse_b = want_b and bslot is None
+                if fuse_b:
+                    db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device)
+                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, dbias=db if fuse_b else None)
+            want_b = want_b and not fuse_b
+        if want_b:
             if bslot is not None:
                 L.channel_sum(g, out=bslot, accumulate=True)
             else:
@@ -166,6 +174,7 @@ def conv_transpose2d_k4s2p1(x, w):
 class _NormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training):
+        ctx.pslots = (_slot(p0), _slot(p1))      # arena gradient slots of the parameters (affine gamma/beta; class table)
         x = _c(x)
         part, rows = _take_stats(x)
         if training:
@@ -189,13 +198,23 @@ class _NormAct(torch.autograd.Function):
         x, y, mean, rstd, p0, p1, labels = ctx.saved_tensors
         dy = _c(dy)
         dp0 = dp1 = None
+        s0, s1 = ctx.pslots
+        in_slots = False          # parameter gradients accumulated by the kernel straight into the arena (no autograd add launch)
         if mode == 1:
-            dp0, dp1 = torch.empty_like(p0), torch.empty_like(p1)
+            if s0 is not None and s1 is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+                dp0, dp1, in_slots = s0, s1, True
+            else:
+                dp0, dp1 = torch.empty_like(p0), torch.empty_like(p1)
         elif mode == 2:
-            dp0 = torch.zeros_like(p0)
+            if s0 is not None and ctx.needs_input_grad[1]:
+                dp0, in_slots = s0, True
+            else:
+                dp0 = torch.zeros_like(p0)
         elif mode == 3:
             dp0 = torch.empty_like(p0)
-        dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1)
+        dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1, param_accumulate=in_slots)
+        if in_slots:
+            dp0 = dp1 = None
         dres = None
         if has_res and ctx.needs_input_grad[3]:
             dres = L.relu_bwd(dy, y) if relu else dy
@@ -481,12 +500,18 @@ class _Conv3x3AvgPool(torch.autograd.Function):
                                    make_w=lambda: pooled(w3),
                                    make_base=lambda: pooled(_c(ws.base.detach()) if ws.base is not None else w3))
         wslot, bslot = ctx.slots
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if wslot is not None:
-                L.conv2d_bwd_weight(dy, xb, 3, 2, 0, out=wslot, accumulate=True)
+                fuse_b = want_b and bslot is not None
+                L.conv2d_bwd_weight(dy, xb, 3, 2, 0, out=wslot, accumulate=True, dbias=bslot if fuse_b else None)
             else:
-                dw = L.conv2d_bwd_weight(dy, xb, 3, 2, 0)
-        if has_bias and ctx.needs_input_grad[2]:
+                fuse_b = want_b and bslot is None
+                if fuse_b:
+                    db = torch.empty(w3.shape[0], dtype=torch.float32, device=dy.device)
+                dw = L.conv2d_bwd_weight(dy, xb, 3, 2, 0, dbias=db if fuse_b else None)
+            want_b = want_b and not fuse_b
+        if want_b:
             if bslot is not None:
                 L.channel_sum(dy, out=bslot, accumulate=True)
             else:
@@ -579,6 +604,7 @@ class _LayoutStage1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, masks, labels, table, w2, rmean, rvar, nbt, training):
+        ctx.tslot = _slot(table)
         u, masks, table, w2 = _c(u), _c(masks), _c(table), _c(w2)
         O, Cc = u.shape
         R, Co = masks.shape[-1], w2.shape[0]
@@ -626,12 +652,13 @@ class _LayoutStage1(torch.autograd.Function):
         dA = L.conv2d_bwd_data(GD, Wr, (1, 1)).view(O, Cc)
         dB = L.conv2d_bwd_data(L.axpby(GB, GD, 1.0, -1.0), Wr, (1, 1)).view(O, Cc)
         du = torch.empty_like(u)
-        dtable = torch.zeros_like(table) if ctx.needs_input_grad[3] else None
+        tslot = ctx.tslot if ctx.needs_input_grad[3] else None      # the kernel adds into dtable: straight into the arena slot
+        dtable = tslot if tslot is not None else (torch.zeros_like(table) if ctx.needs_input_grad[3] else None)
         ws = L.workspace((O * Cc * 4 + 2 * Cc) * 4, dev)
         L.call("agl_layout1_levels_bwd", L.ptr(dA), L.ptr(dB), L.ptr(A), L.ptr(B), L.ptr(u), L.ptr(area), L.ptr(mean), L.ptr(rstd),
                L.ptr(table), L.ptr(labels, torch.int64), L.ptr(du), L.ptr(dtable), O, Cc, R, table.shape[0], int(training),
                ws.data_ptr(), ws.numel(), L.stream())
-        return du, None, None, dtable, dW2, None, None, None, None
+        return du, None, None, (None if tslot is not None else dtable), dW2, None, None, None, None
 
 
 def layout_stage1(u, masks, labels, table, w2, rmean, rvar, nbt, training=True):

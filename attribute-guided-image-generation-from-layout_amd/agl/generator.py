@@ -231,17 +231,27 @@ class SPADE(nn.Module):
 
     block_grids = True     # False: both convolutions on the full-resolution grid (A/B tests)
 
+    def agl_param_pairs(self):
+        """Parameters FlatParams should place back to back (their dim-0 concatenation becomes an arena view)."""
+        return [("gb_weight", self.mlp_gamma.weight, self.mlp_beta.weight), ("gb_bias", self.mlp_gamma.bias, self.mlp_beta.bias)]
+
     def forward(self, x, segmap, relu=False):
         f = x.shape[2] // segmap.shape[2]
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
         assert segmap.shape[2] == segmap.shape[3]
         wg, wb = self.mlp_gamma.weight, self.mlp_beta.weight
-        w = F.concat_rows(wg, wb)
-        b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
-        sg, sb = getattr(wg, "_agl_wsrc", None), getattr(wb, "_agl_wsrc", None)
-        if sg is not None and sb is not None:      # packed-weight cache of the concatenation, valid while neither half changes
-            w._agl_wsrc = F.L.WeightSrc(wg, (lambda: (sg.version(), sb.version())), tag="gamma|beta")
+        joined = self.__dict__.get("_agl_joined")
+        if joined is not None and joined["gb_weight"].data_ptr() == wg.data_ptr() and wg.requires_grad == joined["gb_weight"].requires_grad:
+            # gamma and beta lie back to back in the flat arena (agl.flat.FlatParams): their concatenation is a view with its
+            # own gradient slot — no concat kernels, no autograd adds
+            w, b = joined["gb_weight"], joined["gb_bias"]
+        else:
+            w = F.concat_rows(wg, wb)
+            b = F.concat_rows(self.mlp_gamma.bias, self.mlp_beta.bias)
+            sg, sb = getattr(wg, "_agl_wsrc", None), getattr(wb, "_agl_wsrc", None)
+            if sg is not None and sb is not None:      # packed-weight cache of the concatenation, valid while neither half changes
+                w._agl_wsrc = F.L.WeightSrc(wg, (lambda: (sg.version(), sb.version())), tag="gamma|beta")
         nb = segmap.shape[2]
         if self.block_grids and f >= 4:
             # The f-fold nearest up-sampling of the segmentation map is constant on f x f blocks, so a 3x3 convolution of

@@ -32,7 +32,7 @@ SIGNATURES = {
     "agl_conv2d_pack_weights": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
     "agl_conv2d_last_pipe": (_I, []),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
-    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _L] + [_I] * 14 + [_P]),
+    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 14 + [_P]),
     "agl_conv2d_fwd_flops": (C.c_double, [_I] * 10),
     "agl_conv2d_bwd_data_flops": (C.c_double, [_I] * 11),
     "agl_conv2d_bwd_weight_flops": (C.c_double, [_I] * 13),
@@ -44,7 +44,7 @@ SIGNATURES = {
     "agl_conv2d_fwd_stats": (_I, [_P] * 7 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
-    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
@@ -185,7 +185,7 @@ def work_of(name, args) -> float:
     if name == "agl_conv2d_bwd_data":
         return lib.agl_conv2d_bwd_data_flops(*args[9:19], args[21])
     if name == "agl_conv2d_bwd_weight":
-        return lib.agl_conv2d_bwd_weight_flops(*args[5:17], args[18])
+        return lib.agl_conv2d_bwd_weight_flops(*args[7:19], args[20])
     if name == "agl_bn_stats":                       # one read of x (4*N*C*HW)
         return 4.0 * args[1] * args[2] * args[3]
     if name == "agl_bn_stats_from_partials":         # the statistics read of x the fused form avoids: algorithmic bytes 0
@@ -402,7 +402,9 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     return out
 
 
-def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False):
+def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False, dbias=None):
+    """dw (+)= weight gradient.  dbias (optional, (Cout,) tensor): also (+)= the bias gradient sum_{n,oh,ow} dy — by the weight-gradient
+    kernel itself where it stages dy anyway, else by agl_channel_sum (same `accumulate` as dw)."""
     N, Cout, OH, OW = dy.shape
     _, Cin, H, W = x.shape
     if out is None:
@@ -412,9 +414,12 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
     if accumulate:
         need = max(need, Cout * Cin * ks * ks * 4)
     ws = workspace(need, dy.device) if need else None
-    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ws.data_ptr() if ws is not None else None,
-         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up, int(in_relu),
-         int(accumulate), CONV_FLAGS, stream())
+    done = C.c_int(0)
+    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ptr(dbias), C.addressof(done) if dbias is not None else None,
+         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up,
+         int(in_relu), int(accumulate), CONV_FLAGS, stream())
+    if dbias is not None and not done.value:
+        channel_sum(dy, out=dbias, accumulate=accumulate)
     return out
 
 
@@ -456,7 +461,7 @@ def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu):
     return y
 
 
-def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None):
+def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False):
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
     dx = torch.empty_like(x)
@@ -464,7 +469,7 @@ def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=
     ws = workspace(nb, x.device)
     call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
          ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
-         p0.shape[0] if mode == 2 else 0, ws.data_ptr(), ws.numel(), stream())
+         p0.shape[0] if mode == 2 else 0, int(param_accumulate), ws.data_ptr(), ws.numel(), stream())
     return dx
 
 

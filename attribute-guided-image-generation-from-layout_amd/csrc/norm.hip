@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void norm_bwd_table(NormArgs a, const float* _
 
 // K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; affine parameter grads (mode 1).  One wave per channel.
 __global__ __launch_bounds__(256) void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
-                                                         float* __restrict__ dp0, float* __restrict__ dp1) {
+                                                         float* __restrict__ dp0, float* __restrict__ dp1, int param_accumulate) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= a.C) return;
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256) void norm_bwd_channels(NormArgs a, const float
   S1 = wave_sum(S1); S2 = wave_sum(S2); A1 = wave_sum(A1); A2 = wave_sum(A2);
   if (lane == 0) {
     if (a.mode == 1) {
-      if (dp0) { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+      if (dp0) {
+        if (param_accumulate) { dp0[c] += (float)A2; dp1[c] += (float)A1; }
+        else { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+      }
       S1 *= a.p0[c]; S2 *= a.p0[c];
     }
     chansum[2 * c] = (float)S1;
@@ -384,11 +387,13 @@ long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2
 
 // Backward of (stats +) apply.  batch_stats=1: statistics were computed from x (training); 0: constants (eval).
 // y is the forward output (ReLU mask) and may be NULL when relu==0.
-// dp0/dp1: mode 1 -> dgamma[C], dbeta[C] (overwritten); mode 2 -> dtable[V][2C] (ACCUMULATED into; caller zeroes);
-//          mode 3 -> dp0 = dgb[N][2C][HW] (overwritten).  Either may be NULL to skip parameter gradients (not mode 3).
+// dp0/dp1: mode 1 -> dgamma[C], dbeta[C] (overwritten, or added to when param_accumulate); mode 2 -> dtable[V][2C] (ALWAYS
+//          accumulated into; a caller without a gradient slot zeroes it first); mode 3 -> dp0 = dgb[N][2C][HW] (overwritten).
+//          Either may be NULL to skip parameter gradients (not mode 3).
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, void* ws, long ws_bytes, void* stream) {
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
+                 void* stream) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
   if (rc) return rc;
@@ -404,7 +409,7 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
   AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
   AGL_CHECK_LAUNCH("agl_norm_bwd(rows)");
   hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 4)), dim3(256), 0, st, a, (const float*)rowsum, chansum,
-                     mode == 3 ? nullptr : dp0, dp1);
+                     mode == 3 ? nullptr : dp0, dp1, param_accumulate);
   AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
   if (mode == 2 && dp0) {
     AGL_REQUIRE(n_classes > 0, "agl_norm_bwd: mode 2 needs the number of table rows");

@@ -41,6 +41,7 @@ struct PArgs {
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
   int cps;           // (each slab is shaped like y; splitk_epilogue of conv.hip adds them and applies the epilogue)
   long out_numel;
+  int oh2, ow2;      // phase mode: extent of the output map (2*OH x 2*OW, or one more row and column for an odd-sized input)
   const float* odiv; // optional device scalar: the products are divided by it before bias / mask / ReLU (pre-packed weights of a
 };                   // spectrally normalised layer: packed W_orig, divisor sigma)
 
@@ -375,9 +376,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           v1[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
           v1[ps].x *= osc; v1[ps].y *= osc; v1[ps].z *= osc; v1[ps].w *= osc;
         }
-        const long OHW2 = 4 * OHW;
+        // (odd-sized outputs — 33 x 33, 65 x 65 — have rows that are only 4-byte aligned: under-aligned vector type)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const long OHW2 = (long)p.oh2 * p.ow2;
         const bool iok = img < p.N;
-        const long ob = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * (2 * p.OW) + 2 * (tx0 + px);
+        const long ob = (long)img * p.Cout * OHW2 + (long)(2 * (ty0 + py) + ph_y) * p.ow2 + 2 * (tx0 + px);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
@@ -388,13 +391,13 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
             float* dst = p.y + ob + (long)m * OHW2;
             if (p.slabs) {      // reduction split: raw partial sums (bias and the rest happen in the slab reduction)
               float* sd = p.slabs + (long)zsplit * p.out_numel + ob + (long)m * OHW2;
-              *reinterpret_cast<float4*>(sd) = float4{v[ps].x, v1[ps].x, v[ps].y, v1[ps].y};
-              *reinterpret_cast<float4*>(sd + 4) = float4{v[ps].z, v1[ps].z, v[ps].w, v1[ps].w};
+              *reinterpret_cast<f4u*>(sd) = f4u{v[ps].x, v1[ps].x, v[ps].y, v1[ps].y};
+              *reinterpret_cast<f4u*>(sd + 4) = f4u{v[ps].z, v1[ps].z, v[ps].w, v1[ps].w};
               continue;
             }
             if (p.pos_mask) {
-              const float4 m0 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2);
-              const float4 m1 = *reinterpret_cast<const float4*>(p.pos_mask + ob + (long)m * OHW2 + 4);
+              const f4u m0 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2);
+              const f4u m1 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2 + 4);
               if (!(m0.x > 0.f)) lo.x = 0.f;
               if (!(m0.y > 0.f)) lo.y = 0.f;
               if (!(m0.z > 0.f)) lo.z = 0.f;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
               if (!(m1.w > 0.f)) hi.w = 0.f;
             }
             if (p.accumulate) {
-              const float4 o0 = *reinterpret_cast<const float4*>(dst), o1 = *reinterpret_cast<const float4*>(dst + 4);
+              const f4u o0 = *reinterpret_cast<const f4u*>(dst), o1 = *reinterpret_cast<const f4u*>(dst + 4);
               lo.x += o0.x; lo.y += o0.y; lo.z += o0.z; lo.w += o0.w;
               hi.x += o1.x; hi.y += o1.y; hi.z += o1.z; hi.w += o1.w;
             }
@@ -413,21 +416,21 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
               lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
               hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
             }
-            *reinterpret_cast<float4*>(dst) = lo;
-            *reinterpret_cast<float4*>(dst + 4) = hi;
+            *reinterpret_cast<f4u*>(dst) = f4u{lo.x, lo.y, lo.z, lo.w};
+            *reinterpret_cast<f4u*>(dst + 4) = f4u{hi.x, hi.y, hi.z, hi.w};
           }
         }
         continue;
       }
       if constexpr (PHS) {        // pixel (a, b) of this phase -> (2a+ph, 2b+pw) of the 2*OH x 2*OW map: scalar accesses
-        const long OHW2 = 4 * OHW;
+        const long OHW2 = (long)p.oh2 * p.ow2;
         long pb2[4];
         bool iok[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {      // (with 2-wide tiles the four pixels of a lane are not in one row)
           const int jq = j + q, tq = jq / (TH * TW), rq = jq - tq * (TH * TW), pyq = rq / TW, pxq = rq - pyq * TW;
           iok[q] = img0 + tq < p.N;
-          pb2[q] = (long)(img0 + tq) * p.Cout * OHW2 + (long)(2 * (ty0 + pyq) + ph_y) * (2 * p.OW) + 2 * (tx0 + pxq) + ph_x;
+          pb2[q] = (long)(img0 + tq) * p.Cout * OHW2 + (long)(2 * (ty0 + pyq) + ph_y) * p.ow2 + 2 * (tx0 + pxq) + ph_x;
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -513,6 +516,70 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
 }
 
+// Last row (Y = 2W) and last column (X = 2W) of the 4x4 / stride-2 / pad-1 input gradient of an odd-sized input (2W+1 x 2W+1, square
+// maps): with oy = (Y + 1 - kh) / 2 only kh = 3 reaches a valid dy row there (oy = W-1), and likewise kw = 3 on the last column; along
+// the edge the other index takes its usual taps.  blockIdx.x = 2*image + {0: last row, 1: last column without the corner}; a thread
+// owns one output channel m and all 2W+1 edge pixels of it (accumulators in registers); the dy line (last row or last column, all
+// reduction channels) is staged in LDS 64 channels at a time and read as broadcasts; w[c][m][3][0..3] is one 16-byte load.
+// fp32 FMAs (operands rounded to bf16 first in bf16 mode) — 1/(2W) of the layer's work.  w[c*w_sc + m*w_sm + kh*4 + kw].
+template <int W>
+__global__ __launch_bounds__(128) void phase_edge_k(const float* __restrict__ dy, const float* __restrict__ w,
+                                                    const float* __restrict__ pos_mask, float* __restrict__ dx,
+                                                    const float* __restrict__ out_div, int N, int Cred, int M, int w_sm, int w_sc, int relu,
+                                                    int accumulate, int round_bf16) {
+  constexpr int CB = 64, OW = 2 * W + 1;
+  __shared__ float line[CB][W];
+  const int n = blockIdx.x >> 1, col = blockIdx.x & 1, m = blockIdx.y * 128 + threadIdx.x;
+  auto op = [&](float v) { return round_bf16 ? (float)(__bf16)v : v; };
+  float acc[OW];
+#pragma unroll
+  for (int i = 0; i < OW; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < Cred; c0 += CB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < CB * W; e += 128) {
+      const int c = e / W, o = e - c * W;
+      float v = 0.f;
+      if (c0 + c < Cred) v = col ? dy[(((long)n * Cred + c0 + c) * W + o) * W + (W - 1)] : dy[(((long)n * Cred + c0 + c) * W + (W - 1)) * W + o];
+      line[c][o] = op(v);
+    }
+    __syncthreads();
+    if (m < M) {
+      const int cn = min(CB, Cred - c0);
+      for (int c = 0; c < cn; ++c) {
+        const float* wp = w + (long)(c0 + c) * w_sc + (long)m * w_sm;
+        float wv[4];
+        if (col) { wv[0] = wp[3]; wv[1] = wp[7]; wv[2] = wp[11]; wv[3] = wp[15]; }
+        else { const float4 t = *reinterpret_cast<const float4*>(wp + 12); wv[0] = t.x; wv[1] = t.y; wv[2] = t.z; wv[3] = t.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[k] = op(wv[k]);
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+          const float d = line[c][o];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int X = 2 * o - 1 + k;      // edge position this (pixel, tap) pair lands on
+            if (X >= 0 && X < OW) acc[X] = fmaf(d, wv[k], acc[X]);
+          }
+        }
+      }
+    }
+  }
+  if (m >= M) return;
+  const float sc = out_div ? 1.0f / *out_div : 1.0f;
+  const int cnt = col ? OW - 1 : OW;            // (the corner belongs to the row pass)
+#pragma unroll
+  for (int i = 0; i < OW; ++i) {
+    if (i >= cnt) break;
+    const int Y = col ? i : OW - 1, X = col ? OW - 1 : i;
+    const long o = (((long)n * M + m) * OW + Y) * OW + X;
+    float v = acc[i] * sc;
+    if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+    if (accumulate) v += dx[o];
+    if (relu) v = fmaxf(v, 0.f);
+    dx[o] = v;
+  }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 
@@ -530,6 +597,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // the 128-pixel tiles, and writes one slab; the slabs are added in a fixed order (agl_launch_slab_reduce: deterministic).
 struct WArgs {
   const float* dy; const float* x; float* slabs;
+  float* bias_slabs;      // optional [split][Cout]: per-channel sums of dy (the bias gradient), by the workgroups of input-channel block 0
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
   int tiles, tiles_per_split;
   unsigned x_bytes, dy_bytes;
@@ -553,9 +621,14 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSPL * (D_PLANE + X_PLANE)];
   unsigned char* const Dl = lds;
   unsigned char* const Xl = lds + NSPL * D_PLANE;
+  // bias gradient (sum of dy over the pixels, per output channel): the 16 consecutive lanes that stage the 8-pixel pieces of one
+  // channel row add them up; one of them keeps the running sum in LDS (the same lane owns the same channel in every tile: no races)
+  __shared__ float lbias[BMCO];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int pass = NPASS == 1 ? 0 : (int)blockIdx.y % NPASS, tap0 = pass * TSUB;
+  const bool do_bias = p.bias_slabs != nullptr && blockIdx.y == 0;
+  if (do_bias && tid < BMCO) lbias[tid] = 0.f;      // (ordered before the first update by the barrier at the top of the tile loop)
   const int c0 = ((int)blockIdx.y / NPASS) * BC, co0 = blockIdx.z * BMCO;
   const int t_beg = blockIdx.x * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
   const int Hl = p.H << p.up, Wl = p.W << p.up;
@@ -635,6 +708,13 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       if (ND % NT != 0 && e >= ND) return;
       const int co = e / (NPX / 8), oc = e - co * (NPX / 8);
       const float v[8] = {pdy[sl][0].x, pdy[sl][0].y, pdy[sl][0].z, pdy[sl][0].w, pdy[sl][1].x, pdy[sl][1].y, pdy[sl][1].z, pdy[sl][1].w};
+      if (do_bias) {
+        static_assert(NPX / 8 == 16 || NPX / 8 == 8, "lanes per dy row");
+        float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+        for (int o = 1; o < NPX / 8; o <<= 1) sm += __shfl_xor(sm, o);
+        if (oc == 0) lbias[co] += sm;
+      }
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -741,6 +821,10 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     }
   }
 
+  if (do_bias) {
+    __syncthreads();
+    if (tid < BMCO && co0 + tid < p.Cout) p.bias_slabs[(long)blockIdx.x * p.Cout + co0 + tid] = lbias[tid];
+  }
   // ---- slab: C tile col = lane&15 (input channel), row = 4*(lane>>4) + reg (output channel)
   float* out = p.slabs + (long)blockIdx.x * p.Cout * p.Cin * KK;
 #pragma unroll
@@ -866,7 +950,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
   if (a.ks == 1) { p.H = p.OH = pl.oh; p.W = p.OW = pl.ow; }      // the re-read map of a 1x1 convolution
-  p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel;
+  p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = 0; p.ow2 = 0;
   if (pl.splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, pl.splits); }
   if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && 2 * ptiles * a.Cout * 2 <= a.stats_floats) {
     p.stats = a.stats;
@@ -978,7 +1062,11 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
 static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles, int* splits_out = nullptr) {
   if (a.ks != 4 || a.stride != 2 || a.pad != 1 || a.up != 0 || a.Cin % 16 != 0 || a.Cout < 48) return -1;
   if (!(a.nsplit == 1 || a.nsplit == 3)) return -1;
-  if (a.OH != 2 * a.H || a.OW != 2 * a.W) return -1;
+  // odd-sized inputs (33 x 33, 65 x 65: the layout encoder's c3): the phases cover rows / columns 0 .. 2H-1; the last row and column
+  // (one tap each) come from phase_edge_k
+  const bool odd = a.OH == 2 * a.H + 1 && a.OW == 2 * a.W + 1;
+  if (!odd && (a.OH != 2 * a.H || a.OW != 2 * a.W)) return -1;
+  if (odd && !(a.H == a.W && (a.W == 8 || a.W == 16 || a.W == 32))) return -1;      // paired-phase geometries, square maps (phase_edge_k)
   if (a.W % 16 == 0 && a.H % 8 == 0) *geo = 0;
   else if (a.W == 8 && a.H == 8) *geo = 1;
   else if (a.W == 4 && a.H == 4) *geo = 2;
@@ -993,7 +1081,7 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles, int*
     const int nch = a.Cin / 16;
     splits = std::min(kPconvMaxSplits, nch / 4);
     while (splits > 2 && wgs * (splits / 2) >= 512) splits /= 2;
-    if (*geo == 3 || splits < 2 || wgs * splits < 256 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
+    if (*geo == 3 || odd || splits < 2 || wgs * splits < 256 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
   }
   if (splits_out) *splits_out = splits;
   return 0;
@@ -1012,6 +1100,7 @@ long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel) {
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int geo, bm, splits; long ptiles;
   if (pconvT_plan(a, &geo, &bm, &ptiles, &splits) != 0) return -1;
+  if (a.OH == 2 * a.H + 1 && !a.w) return -1;      // (the edge kernel of the odd-sized form reads the unpacked weights)
   const long packed = a.packed ? 0 : pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit), out_numel = (long)a.N * a.Cout * a.OH * a.OW;
   const long need = packed + (splits > 1 ? out_numel * 4 * splits : 0);
   if (need > 0 && (!ws || ws_bytes < need)) return -1;
@@ -1026,7 +1115,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
-  p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel;
+  p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
@@ -1044,6 +1133,14 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
 #undef PT_GEO
 #undef PT_LAUNCH
   AGL_CHECK_LAUNCH(name);
+  if (a.OH == 2 * a.H + 1) {      // odd-sized input: its last row and column
+    dim3 ge((unsigned)(2 * a.N), agl_cdiv(a.Cout, 128));
+#define PE_LAUNCH(W_) hipLaunchKernelGGL((phase_edge_k<W_>), ge, dim3(128), 0, st, a.x, a.w, a.pos_mask, a.y, a.out_div, a.N, a.Cin, a.Cout, \
+                                        a.w_sm, a.w_sc, a.relu, a.accumulate, a.nsplit == 1)
+    if (a.W == 8) PE_LAUNCH(8); else if (a.W == 16) PE_LAUNCH(16); else PE_LAUNCH(32);
+#undef PE_LAUNCH
+    AGL_CHECK_LAUNCH(name);
+  }
   if (splits > 1)
     return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, splits, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name,
                                       a.out_div);
@@ -1098,8 +1195,19 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
 long pbww_ws_bytes(const PBwwArgs& a) {
   int s, t, rt, ct, half; long tiles;
   if (pbww_plan(a, &s, &t, &tiles, &rt, &ct, &half) != 0) return 0;
-  return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4;
+  return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4 + (long)s * a.Cout * 4;      // weight slabs + bias-gradient slabs
 }
+
+namespace {
+// db[c] (+)= sum over the splits' partial sums, in split order
+__global__ void bias_slab_reduce(const float* __restrict__ slabs, float* __restrict__ db, int C, int splits, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(long)z * C + c];
+  db[c] = accumulate ? db[c] + s : s;
+}
+}  // namespace
 
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int splits, tps, rt, ct, half, oh, ow; long tiles;
@@ -1107,6 +1215,9 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   const long n = (long)a.Cout * a.Cin * a.ks * a.ks;
   if (!ws || ws_bytes < (long)splits * n * 4) return -1;
   WArgs p;
+  // bias gradient alongside (a.dbias): its slabs follow the weight slabs when the workspace has room for them
+  const bool with_bias = a.dbias != nullptr && ws_bytes >= (long)splits * n * 4 + (long)splits * a.Cout * 4;
+  p.bias_slabs = with_bias ? (float*)ws + (long)splits * n : nullptr;
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
@@ -1141,5 +1252,11 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   }
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
+  if (with_bias) {
+    hipLaunchKernelGGL(bias_slab_reduce, dim3(agl_cdiv(a.Cout, 256)), dim3(256), 0, st, (const float*)p.bias_slabs, a.dbias, a.Cout, splits,
+                       a.accumulate);
+    AGL_CHECK_LAUNCH(name);
+    if (a.dbias_done) *a.dbias_done = 1;
+  }
   return agl_launch_slab_reduce((const float*)ws, a.dw, n, splits, a.accumulate, st, name);
 }

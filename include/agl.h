@@ -93,8 +93,11 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
                         const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
                         int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
-int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, void* ws, long ws_bytes, int N, int Cin, int H,
-                          int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
+/* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] (+)= sum over (n, oh, ow) of dy — the
+ * `accumulate` flag applies to it too.  The matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway;
+ * *dbias_done (host int) is 1 when the call did so and 0 when the kernel that ran does not (the caller then uses agl_channel_sum). */
+int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int* dbias_done, void* ws, long ws_bytes, int N,
+                          int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
                           int accumulate, int flags, void* stream);
 /* Executed FLOPs (2*MAC) of the launches one such call issues (dense count minus the padded taps the position-major
  * path skips) — what bench.py's roofline leg divides by the measured launch time. */
@@ -124,9 +127,12 @@ int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int
                        const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
                        void* stream);
 long agl_norm_bwd_ws_bytes(int N, int C);
+/* dp0 / dp1: parameter gradients.  mode 1: dgamma[C], dbeta[C], overwritten — or added to when param_accumulate (gradient
+ * accumulated in place, like autograd's AccumulateGrad); mode 2: dtable[V][2C], always added to; mode 3: dp0 = d(gb), overwritten. */
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, void* ws, long ws_bytes, void* stream);
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
+                 void* stream);
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;

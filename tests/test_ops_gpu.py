@@ -702,6 +702,14 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
         TF.conv2d(xr, wg, None, padding=p).backward(gyr)
         dw = L.conv2d_bwd_weight(dev(gy), xd, ks, 1, p)
         close(dw, wg.grad, 1e-4, "weight gradient")
+        # ... with the bias gradient formed by the same kernel from the dy tiles it stages (fresh, then accumulating)
+        db = torch.full((Cout,), float("nan"), device=DEV)
+        dw_b = L.conv2d_bwd_weight(dev(gy), xd, ks, 1, p, dbias=db)
+        assert torch.equal(dw_b, dw)
+        close(db, gy.double().sum((0, 2, 3)).float(), 2e-5, "bias gradient from the weight-gradient kernel")
+        db2 = dev(b).clone()
+        L.conv2d_bwd_weight(dev(gy), xd, ks, 1, p, out=dev(base_w0 := rn(Cout, Cin, ks, ks, seed=12)).clone(), accumulate=True, dbias=db2)
+        close(db2, b + gy.double().sum((0, 2, 3)).float(), 2e-5, "bias gradient, accumulating")
         wg2 = wr.clone().requires_grad_(True)
         TF.conv2d(torch.relu(xr) if mode == "split3" else r(torch.relu(x)), wg2, None, padding=p).backward(gyr)
         base_w = rn(Cout, Cin, ks, ks, seed=11)
@@ -787,7 +795,7 @@ def test_packed_weight_cache_and_divisor(mode):
     from agl import lib as L
     flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
     ver = [0]
-    for (N, Cin, H, Cout, ks, stride, pad) in ((6, 32, 16, 64, 3, 1, 1), (5, 64, 8, 128, 1, 1, 0), (4, 32, 16, 64, 4, 2, 1), (3, 48, 32, 80, 5, 1, 2)):
+    for (N, Cin, H, Cout, ks, stride, pad) in ((6, 64, 16, 64, 3, 1, 1), (5, 64, 8, 128, 1, 1, 0), (4, 64, 16, 64, 4, 2, 1), (3, 48, 32, 80, 5, 1, 2)):
         x, w = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5)
         OH = (H + 2 * pad - ks) // stride + 1
         dy = rn(N, Cout, OH, OH, seed=3)
@@ -811,6 +819,7 @@ def test_packed_weight_cache_and_divisor(mode):
             ys = L.conv2d_fwd(xd, w_sn, None, stride, pad, wsrc=src_sn)
             close(ys, L.conv2d_fwd(xd, w_sn, None, stride, pad), 2e-6 if mode == "split3" else 1e-2, "forward with divisor")
             close(ys, y0 / 1.7, 1e-6, "forward with divisor == plain / sigma")
+            assert L.bwd_data_packed_bytes(N, Cin, H, H, Cout, OH, OH, ks, stride, pad) > 0, "case must exercise the packed input-gradient path"
             dxs = L.conv2d_bwd_data(dyd, w_sn, (H, H), stride, pad, wsrc=src_sn)
             close(dxs, dx0 / 1.7, 1e-6, "input gradient with divisor == plain / sigma")
             # new weight version: the cache must follow
@@ -944,4 +953,34 @@ def test_pconv_stride2_input_gradient_phases(case, mode):
         dx = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1)
         dx2 = L.conv2d_bwd_data(dev(gy), dev(w), (2 * OH, 2 * OH), 2, 1, pos_mask=dev(mask), out=dev(base).clone(), accumulate=True)
     close(dx, ref, 5e-5 if mode == "bf16" else 2e-5, "stride-2 input gradient")
+    close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(4, 64, 16, 128), (5, 96, 32, 64), (6, 32, 8, 80)])
+def test_pconv_stride2_input_gradient_odd_sized_input(case, mode):
+    """The layout encoder's c3 (generator_obj_att.py:479) maps a 33x33 (64 px) / 65x65 (128 px) input to 16x16 / 32x32: its input
+    gradient has an ODD extent 2*OH+1.  Rows / columns 0..2*OH-1 come from the paired-phase matrix-core kernel (output pitch
+    2*OH+1: under-aligned 16-byte stores), the last row and column from phase_edge_k — against torch's conv2d input gradient,
+    plain and with ReLU mask + accumulation; the last row / column are checked on their own as well."""
+    from agl import lib as L
+    N, Cout, OH, Cin = case            # dy: (N, Cout, OH, OH); dx: (N, Cin, 2*OH+1, 2*OH+1)
+    IH = 2 * OH + 1
+    w = rn(Cout, Cin, 4, 4, seed=1) * (1.0 / (Cout * 4) ** 0.5)
+    gy = rn(N, Cout, OH, OH, seed=3)
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    xg = torch.zeros(N, Cin, IH, IH, requires_grad=True)
+    TF.conv2d(xg, r(w), None, stride=2, padding=1).backward(r(gy))
+    ref = xg.grad
+    assert float(ref[:, :, -1].abs().max()) > 0 and float(ref[:, :, :, -1].abs().max()) > 0
+    mask, base = rn(N, Cin, IH, IH, seed=5), rn(N, Cin, IH, IH, seed=6)
+    flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
+    with L.conv_flags(flags):
+        assert L.bwd_data_packed_bytes(N, Cin, IH, IH, Cout, OH, OH, 4, 2, 1) > 0, "the phase kernel must take the odd-sized form"
+        dx = L.conv2d_bwd_data(dev(gy), dev(w), (IH, IH), 2, 1)
+        dx2 = L.conv2d_bwd_data(dev(gy), dev(w), (IH, IH), 2, 1, pos_mask=dev(mask), out=dev(base).clone(), accumulate=True)
+    tol = 5e-5 if mode == "bf16" else 2e-5
+    close(dx, ref, tol, "odd-sized stride-2 input gradient")
+    close(dx[:, :, -1], ref[:, :, -1], tol, "last row")
+    close(dx[:, :, :, -1], ref[:, :, :, -1], tol, "last column")
     close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
