@@ -173,21 +173,28 @@ def conv_transpose2d_k4s2p1(x, w):
 # --------------------------------------------------------------------------- normalisation
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training):
+    def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training, gather=None):
         ctx.pslots = (_slot(p0), _slot(p1))      # arena gradient slots of the parameters (affine gamma/beta; class table)
+        # gather (mode 3): (map, range starts of the inverse map) of _grid_map — p0 lives on the coarser block-class grid
+        ctx.gather = gather
+        gmap = gather[0] if gather is not None else None
         x = _c(x)
         part, rows = _take_stats(x)
         if training:
+            # on a tape the call also leaves its (mean, unbiased variance) in double: the replay re-applies the running update
+            # from them — the same arithmetic on the same numbers, without a second read of the activation
+            mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device) if (BN_TAPE is not None and rmean is not None) else None
             if part is not None:
-                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
+                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, rmean, rvar, nbt,
+                                                      moments=mom)
             else:
-                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt)
-            if BN_TAPE is not None and rmean is not None:
-                BN_TAPE.append(lambda: L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt))
+                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt, moments=mom)
+            if mom is not None:
+                BN_TAPE.append(lambda: L.bn_running_update(mom, BN_MOMENTUM, rmean, rvar, nbt))
         else:
             mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
         p0c = _c(p0) if p0 is not None else None
-        y = L.norm_apply_fwd(x, mean, rstd, mode, p0c, p1, labels, _c(residual) if residual is not None else None, relu)
+        y = L.norm_apply_fwd(x, mean, rstd, mode, p0c, p1, labels, _c(residual) if residual is not None else None, relu, gb_map=gmap)
         ctx.cfg = (mode, relu, training, residual is not None)
         ctx.save_for_backward(x, y if relu else None, mean, rstd, p0c, p1, labels)
         return y
@@ -210,15 +217,23 @@ class _NormAct(torch.autograd.Function):
                 dp0, in_slots = s0, True
             else:
                 dp0 = torch.zeros_like(p0)
-        elif mode == 3:
-            dp0 = torch.empty_like(p0)
-        dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1, param_accumulate=in_slots)
+        elif mode == 3:      # d(gamma|beta) at the map's full resolution (reduced to the class grid below when gathered)
+            dp0 = torch.empty((x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        gather = ctx.gather
+        dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1, param_accumulate=in_slots,
+                        gb_map=gather[0] if gather is not None else None)
         if in_slots:
             dp0 = dp1 = None
+        if gather is not None:
+            lo, h = gather[1], p0.shape[-1]
+            dsrc = torch.empty_like(p0)
+            L.call("agl_grid_gather_bwd", L.ptr(dp0), L.ptr(lo, torch.int32), L.ptr(lo, torch.int32), L.ptr(dsrc), dp0.shape[0] * dp0.shape[1],
+                   h, h, dp0.shape[-1], dp0.shape[-1], L.stream())
+            dp0 = dsrc
         dres = None
         if has_res and ctx.needs_input_grad[3]:
             dres = L.relu_bwd(dy, y) if relu else dy
-        return dx, dp0, dp1, dres, None, None, None, None, None, None, None
+        return dx, dp0, dp1, dres, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, rmean, rvar, nbt, weight=None, bias=None, relu=False, residual=None, training=True):
@@ -232,9 +247,16 @@ def cond_batch_norm(x, table, labels, rmean, rvar, nbt, relu=False, training=Tru
     return _NormAct.apply(x, table, None, None, labels, rmean, rvar, nbt, 2, relu, training)
 
 
-def spade_modulate(x, gb, rmean, rvar, nbt, relu=False, training=True):
-    """SPADE apply (normalization.py:97,106): y = BN(x) * (1 + gamma) + beta with gb = [gamma; beta]."""
-    return _NormAct.apply(x, gb, None, None, None, rmean, rvar, nbt, 3, relu, training)
+def spade_modulate(x, gb, rmean, rvar, nbt, relu=False, training=True, gather=None):
+    """SPADE apply (normalization.py:97,106): y = BN(x) * (1 + gamma) + beta with gb = [gamma; beta].
+    gather = (kind, blocks, f) of _grid_map: gb lives on that block-class grid and is expanded while it is read (what
+    grid_gather(gb, kind, blocks, f) would write out first)."""
+    g = None
+    if gather is not None:
+        m, lo, src = _grid_map(gather[0], gather[1], gather[2], x.device)
+        assert gb.shape[2] == gb.shape[3] == src and x.shape[2] == x.shape[3] == m.numel(), (gb.shape, x.shape, gather)
+        g = (m, lo)
+    return _NormAct.apply(x, gb, None, None, None, rmean, rvar, nbt, 3, relu, training, g)
 
 
 # --------------------------------------------------------------------------- crop

@@ -230,6 +230,7 @@ class SPADE(nn.Module):
         self.mlp_beta = A.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
 
     block_grids = True     # False: both convolutions on the full-resolution grid (A/B tests)
+    fold_gather = True     # False: write the expanded gamma|beta out before the modulation (A/B tests)
 
     def agl_param_pairs(self):
         """Parameters FlatParams should place back to back (their dim-0 concatenation becomes an arena view)."""
@@ -264,6 +265,10 @@ class SPADE(nn.Module):
             a3 = self.mlp_shared[0](F.grid_gather(segmap, "up3", nb), relu=True)
             if f >= 8:
                 gb5 = F.conv2d(F.grid_gather(a3, "3to5", nb), w, b, 1, 1)
+                if self.fold_gather:         # the 5-classes-per-block grid is expanded inside the modulation kernel's reads
+                    n = self.param_free_norm
+                    return F.spade_modulate(x, gb5, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training,
+                                            gather=("5tof", nb, f))
                 gb = F.grid_gather(gb5, "5tof", nb, f)
             else:
                 gb = F.conv2d(F.grid_gather(a3, "3tof", nb, f), w, b, 1, 1)

@@ -37,14 +37,15 @@ SIGNATURES = {
     "agl_conv2d_bwd_data_flops": (C.c_double, [_I] * 11),
     "agl_conv2d_bwd_weight_flops": (C.c_double, [_I] * 13),
     "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
-    "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "agl_bn_running_update": (_I, [_P, _I, _F, _P, _P, _P, _P]),
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
-    "agl_bn_stats_from_partials": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "agl_bn_stats_from_partials": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "agl_conv2d_fwd_stats_floats": (_L, [_I] * 4),
     "agl_conv2d_fwd_stats": (_I, [_P] * 7 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
-    "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
-    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
@@ -359,12 +360,18 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, wsrc
     return out, (stats if rows.value > 0 else None), rows.value
 
 
-def bn_stats_from_partials(partials, rows, Cc, count, eps, momentum, running_mean=None, running_var=None, nbt=None):
+def bn_stats_from_partials(partials, rows, Cc, count, eps, momentum, running_mean=None, running_var=None, nbt=None, moments=None):
     mean = torch.empty(Cc, dtype=torch.float32, device=partials.device)
     rstd = torch.empty_like(mean)
     call("agl_bn_stats_from_partials", partials.data_ptr(), rows, Cc, count, eps, momentum, ptr(running_mean), ptr(running_var),
-         ptr(nbt, torch.int64), ptr(mean), ptr(rstd), stream())
+         ptr(nbt, torch.int64), ptr(mean), ptr(rstd), ptr(moments, torch.float64), stream())
     return mean, rstd
+
+
+def bn_running_update(moments, momentum, running_mean, running_var, nbt=None):
+    """Re-apply the running-statistics update of the statistics call that wrote `moments` (bit-identical to recomputing it)."""
+    call("agl_bn_running_update", ptr(moments, torch.float64), running_mean.numel(), momentum, ptr(running_mean), ptr(running_var),
+         ptr(nbt, torch.int64), stream())
 
 
 def bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad):
@@ -433,7 +440,7 @@ def channel_sum(x, out=None, accumulate=False):
     return out
 
 
-def bn_stats(x, eps, momentum, running_mean=None, running_var=None, nbt=None):
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, nbt=None, moments=None):
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
@@ -441,7 +448,7 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None, nbt=None):
     nb = load().agl_bn_stats_ws_bytes(N, Cc, HW)
     ws = workspace(nb, x.device)
     call("agl_bn_stats", ptr(x), N, Cc, HW, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-         ptr(nbt, torch.int64), ws.data_ptr(), ws.numel(), stream())
+         ptr(nbt, torch.int64), ptr(moments, torch.float64), ws.data_ptr(), ws.numel(), stream())
     return mean, rstd
 
 
@@ -452,16 +459,18 @@ def bn_stats_eval(running_mean, running_var, eps):
     return mean, rstd
 
 
-def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu):
+def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu, gb_map=None):
+    """gb_map (mode 3 only): int32 device tensor of W entries — p0 is then (N, 2C, s, s) on a coarser grid, read through the map."""
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
     y = torch.empty_like(x)
     call("agl_norm_apply_fwd", ptr(x), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1), ptr(labels, torch.int64),
-         ptr(residual), int(relu), ptr(y), N, Cc, HW, stream())
+         ptr(residual), int(relu), ptr(y), N, Cc, HW, ptr(gb_map, torch.int32), x.shape[-1] if gb_map is not None else 0,
+         p0.shape[-1] if gb_map is not None else 0, stream())
     return y
 
 
-def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False):
+def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False, gb_map=None):
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
     dx = torch.empty_like(x)
@@ -469,7 +478,8 @@ def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=
     ws = workspace(nb, x.device)
     call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
          ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
-         p0.shape[0] if mode == 2 else 0, int(param_accumulate), ws.data_ptr(), ws.numel(), stream())
+         p0.shape[0] if mode == 2 else 0, int(param_accumulate), ptr(gb_map, torch.int32), x.shape[-1] if gb_map is not None else 0,
+         p0.shape[-1] if gb_map is not None else 0, ws.data_ptr(), ws.numel(), stream())
     return dx
 
 

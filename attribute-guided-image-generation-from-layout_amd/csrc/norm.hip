@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 // Small tensors (one workgroup per channel covers them): statistics and the running update in ONE launch
 __global__ __launch_bounds__(256) void bn_stats_single(const float* __restrict__ x, int N, int C, int HW, float eps, float momentum,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                                                       float* __restrict__ rvar, long long* __restrict__ nbt) {
+                                                       float* __restrict__ rvar, long long* __restrict__ nbt, double* __restrict__ moments) {
   const int c = blockIdx.x;
   const long M = (long)N * HW;
   double a, b;
@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void bn_stats_single(const float* __restrict__
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+  if (moments) { moments[2 * c] = mu; moments[2 * c + 1] = unb; }      // for agl_bn_running_update (bit-identical replays)
   if (rmean) {
-    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
     rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void bn_stats_single(const float* __restrict__
 
 __global__ void bn_stats_final(const double* __restrict__ part, int C, int S, long M, float eps, float momentum,
                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                               float* __restrict__ rvar, long long* __restrict__ nbt) {
+                               float* __restrict__ rvar, long long* __restrict__ nbt, double* __restrict__ moments) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
@@ -103,8 +104,9 @@ __global__ void bn_stats_final(const double* __restrict__ part, int C, int S, lo
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+  if (moments) { moments[2 * c] = mu; moments[2 * c + 1] = unb; }      // for agl_bn_running_update (bit-identical replays)
   if (rmean) {
-    double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
     rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
@@ -114,7 +116,7 @@ __global__ void bn_stats_final(const double* __restrict__ part, int C, int S, lo
 // One wave per channel, rows summed in double in a fixed order.
 __global__ __launch_bounds__(64) void bn_stats_from_rows(const float* __restrict__ part, int rows, int C, long M, float eps, float momentum,
                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                                                         float* __restrict__ rvar, long long* __restrict__ nbt) {
+                                                         float* __restrict__ rvar, long long* __restrict__ nbt, double* __restrict__ moments) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && nbt) *nbt += 1;
   double a = 0.0, b = 0.0;
@@ -129,11 +131,23 @@ __global__ __launch_bounds__(64) void bn_stats_from_rows(const float* __restrict
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+  if (moments) { moments[2 * c] = mu; moments[2 * c + 1] = unb; }      // for agl_bn_running_update (bit-identical replays)
   if (rmean) {
-    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
     rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
+}
+
+// The running-statistics update of a statistics call, replayed from the moments it left (same double arithmetic: bit-identical)
+__global__ void bn_running_update_k(const double* __restrict__ moments, int C, float momentum, float* __restrict__ rmean,
+                                    float* __restrict__ rvar, long long* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mu = moments[2 * c], unb = moments[2 * c + 1];
+  rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+  rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
 }
 
 // Eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
@@ -149,7 +163,18 @@ struct NormArgs {
   const float* x; const float* mean; const float* rstd;
   const float* p0; const float* p1; const long long* labels;
   int mode, relu, N, C, HW;
+  // mode 3 with a gathered gamma|beta: p0 is (N, 2C, src_w, src_w) on a coarser (block-class) grid and pixel (iy, ix) of the
+  // W-wide map reads cell (map[iy], map[ix]) — the expansion agl_grid_gather_fwd would write out is folded into the reads
+  const int* map; int W, src_w;
 };
+
+// offset of pixel i's gamma (beta: + C planes) inside its (n, c) plane of p0, and the plane size
+__device__ __forceinline__ int gb_index(const NormArgs& a, int i) {
+  if (!a.map) return i;
+  const int iy = i / a.W, ix = i - iy * a.W;
+  return a.map[iy] * a.src_w + a.map[ix];
+}
+__device__ __forceinline__ long gb_plane(const NormArgs& a) { return a.map ? (long)a.src_w * a.src_w : (long)a.HW; }
 
 __device__ __forceinline__ void row_affine(const NormArgs& a, int n, int c, float& g, float& b) {
   g = 1.f; b = 0.f;
@@ -166,11 +191,13 @@ __global__ __launch_bounds__(256) void norm_apply_fwd(NormArgs a, const float* _
   float g, b;
   row_affine(a, n, c, g, b);
   const long base = (long)row * a.HW;
-  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
-  const float* bet = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + a.C + c) * a.HW : nullptr;
+  const long gp = gb_plane(a);
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gp : nullptr;
+  const float* bet = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + a.C + c) * gp : nullptr;
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float xh = (a.x[base + i] - mu) * rs;
-    float v = a.mode == 3 ? xh * (1.f + gam[i]) + bet[i] : xh * g + b;
+    const int gi = a.mode == 3 ? gb_index(a, i) : 0;
+    float v = a.mode == 3 ? xh * (1.f + gam[gi]) + bet[gi] : xh * g + b;
     if (residual) v += residual[base + i];
     if (a.relu) v = fmaxf(v, 0.f);
     y[base + i] = v;
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
   const int n = rr / a.C, c = rr - n * a.C;
   const float mu = a.mean[c], rs = a.rstd[c];
   const long base = (long)rr * a.HW;
-  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
   float* dgam = a.mode == 3 ? dgb + ((long)n * 2 * a.C + c) * a.HW : nullptr;
   float* dbet = a.mode == 3 ? dgb + ((long)n * 2 * a.C + a.C + c) * a.HW : nullptr;
   float s1 = 0.f, s2 = 0.f;
@@ -199,9 +226,9 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
       if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
       float xh = (a.x[base + i] - mu) * rs;
       if (a.mode == 3) {
-        dgam[i] = g * xh;
+        dgam[i] = g * xh;         // (full resolution either way: a gathered gamma|beta is reduced to its grid by agl_grid_gather_bwd)
         dbet[i] = g;
-        g *= 1.f + gam[i];
+        g *= 1.f + gam[gb_index(a, i)];
       }
       s1 += g;
       s2 += g * xh;
@@ -279,12 +306,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
   row_affine(a, n, c, ge, b);
   const float m1 = batch_stats ? chansum[2 * c] * inv_m : 0.f, m2 = batch_stats ? chansum[2 * c + 1] * inv_m : 0.f;
   const long base = (long)row * a.HW;
-  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * a.HW : nullptr;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float g = dy[base + i];
     if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
     float xh = (a.x[base + i] - mu) * rs;
-    float gg = a.mode == 3 ? g * (1.f + gam[i]) : g * ge;
+    float gg = a.mode == 3 ? g * (1.f + gam[gb_index(a, i)]) : g * ge;
     dx[base + i] = rs * (gg - m1 - xh * m2);
   }
 }
@@ -303,7 +330,7 @@ long agl_bn_stats_ws_bytes(int N, int C, int HW) {
 // Batch statistics of x[N,C,HW] (training mode): mean[C], rstd[C]; running stats updated like nn.BatchNorm
 // (momentum, unbiased variance) when running_mean != NULL; *num_batches_tracked += 1 when not NULL.
 int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* rstd,
-                 float* running_mean, float* running_var, long long* num_batches_tracked, void* ws, long ws_bytes,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, double* moments, void* ws, long ws_bytes,
                  void* stream) {
   AGL_REQUIRE(x && mean && rstd && N > 0 && C > 0 && HW > 0, "agl_bn_stats: bad argument");
   const long total = (long)N * HW;
@@ -312,7 +339,7 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
   int S = (int)std::min<long>(std::min<long>(64, (1024 + C - 1) / C), std::max<long>(1, total / 2048));
   if (S <= 1) {
     hipLaunchKernelGGL(bn_stats_single, dim3(C), dim3(256), 0, st, x, N, C, HW, eps, momentum, mean, rstd, running_mean, running_var,
-                       num_batches_tracked);
+                       num_batches_tracked, moments);
     AGL_CHECK_LAUNCH("agl_bn_stats(single)");
     return AGL_OK;
   }
@@ -323,17 +350,27 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
   hipLaunchKernelGGL(bn_stats_partial, dim3(C, S), dim3(256), 0, st, x, N, C, HW, S, (double*)ws);
   AGL_CHECK_LAUNCH("agl_bn_stats(partial)");
   hipLaunchKernelGGL(bn_stats_final, dim3(agl_cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S, total, eps,
-                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked, moments);
   AGL_CHECK_LAUNCH("agl_bn_stats(final)");
   return AGL_OK;
 }
 
+int agl_bn_running_update(const double* moments, int C, float momentum, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, void* stream) {
+  AGL_REQUIRE(moments && running_mean && running_var && C > 0, "agl_bn_running_update: bad argument");
+  hipLaunchKernelGGL(bn_running_update_k, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, moments, C, momentum, running_mean,
+                     running_var, num_batches_tracked);
+  AGL_CHECK_LAUNCH("agl_bn_running_update");
+  return AGL_OK;
+}
+
 int agl_bn_stats_from_partials(const float* partials, int rows, int C, long count, float eps, float momentum, float* running_mean,
-                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream) {
+                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, double* moments,
+                               void* stream) {
   AGL_REQUIRE(partials && mean && rstd && rows > 0 && C > 0 && count > 0, "agl_bn_stats_from_partials: bad argument");
   AGL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "agl_bn_stats_from_partials: running_mean / running_var go together");
   hipLaunchKernelGGL(bn_stats_from_rows, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, rows, C, count, eps, momentum, mean, rstd,
-                     running_mean, running_var, num_batches_tracked);
+                     running_mean, running_var, num_batches_tracked, moments);
   AGL_CHECK_LAUNCH("agl_bn_stats_from_partials");
   return AGL_OK;
 }
@@ -367,14 +404,24 @@ static int fill_args(NormArgs& a, const float* x, const float* mean, const float
   AGL_REQUIRE((long)N * C * HW < (1L << 31), "%s: tensor too large", who);
   a.x = x; a.mean = mean; a.rstd = rstd; a.p0 = p0; a.p1 = p1; a.labels = labels;
   a.mode = mode; a.relu = relu; a.N = N; a.C = C; a.HW = HW;
+  a.map = nullptr; a.W = 0; a.src_w = 0;
+  return AGL_OK;
+}
+// gathered gamma|beta of mode 3 (gb_map: W device ints, the row AND column map of a square W x W map onto a src_w x src_w grid)
+static int fill_gather(NormArgs& a, const int* gb_map, int W, int src_w, const char* who) {
+  if (!gb_map) return AGL_OK;
+  AGL_REQUIRE(a.mode == 3 && W > 0 && src_w > 0 && (long)W * W == a.HW, "%s: gb_map needs mode 3 and a square W x W map (W=%d, HW=%d)", who, W, a.HW);
+  a.map = gb_map; a.W = W; a.src_w = src_w;
   return AGL_OK;
 }
 
 int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
                        const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
-                       void* stream) {
+                       const int* gb_map, int W, int src_w, void* stream) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_apply_fwd");
+  if (rc) return rc;
+  rc = fill_gather(a, gb_map, W, src_w, "agl_norm_apply_fwd");
   if (rc) return rc;
   AGL_REQUIRE(y, "agl_norm_apply_fwd: null output");
   hipStream_t st = (hipStream_t)stream;
@@ -392,10 +439,12 @@ long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2
 //          Either may be NULL to skip parameter gradients (not mode 3).
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
-                 void* stream) {
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, int W,
+                 int src_w, void* ws, long ws_bytes, void* stream) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
+  if (rc) return rc;
+  rc = fill_gather(a, gb_map, W, src_w, "agl_norm_bwd");
   if (rc) return rc;
   AGL_REQUIRE(dy && dx && (!relu || y), "agl_norm_bwd: null pointer");
   AGL_REQUIRE(mode != 3 || dp0, "agl_norm_bwd: SPADE mode needs dgb output");

@@ -319,8 +319,10 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     // a buffer that is about to be overwritten may still be read by a slower wave unless it is the other one of a pair
     if constexpr (!DBA) __syncthreads();
     else if constexpr (!DBB) { if (last_tg) __syncthreads(); }
-    if (last_tg) sstore_b(DBB ? ((cc + 1) & 1) * PB : 0);
-    sstore_a(DBA ? ((s + 1) & 1) * AB : 0);
+    if (s + 1 < nstage) {      // (the last stage's prefetch is a dummy: nothing to convert or store)
+      if (last_tg) sstore_b(DBB ? ((cc + 1) & 1) * PB : 0);
+      sstore_a(DBA ? ((s + 1) & 1) * AB : 0);
+    }
     __syncthreads();
   }
   if constexpr (NSPL == 3) {
@@ -1182,8 +1184,20 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   // (5x5 in split mode: 25 taps x 2 accumulator sets = 200 registers — one workgroup per CU with the accumulators in AGPRs, all
   //  taps in one pass: 2.43 -> 1.87 ms on the ConvLSTM layer against two passes of 13 + 12 taps that stage every tile twice)
   const int npass = 1;
-  const long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
-  long z = (768 + blocks - 1) / blocks;       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
+  // Every split writes a slab of the whole weight tensor, and the reduction reads them all: on a small problem (SPADE's shared
+  // convolution on a 24 x 24 class grid of 32 images: 14 MB of operands, 295 KB per slab) one split per tile meant 85 MB of slabs
+  // — 0.13 ms for 3 GFLOP.  The slabs may not outweigh the operands; when that leaves too few workgroups for the chip, the
+  // fragment block goes back to 64 x 16 channels (more, smaller workgroups instead of more slabs).
+  const long slab_bytes = (long)a.Cout * a.Cin * a.ks * a.ks * 4;
+  const long operand_bytes = ((long)a.N * a.Cout * a.OH * a.OW + (long)a.N * a.Cin * a.H * a.W) * 4;
+  const long zcap = std::max(4L, operand_bytes / slab_bytes);
+  long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
+  long z = std::min((768 + blocks - 1) / blocks, zcap);       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
+  if (blocks * z < 256 && (*rt > 1 || *ct > 1)) {
+    *rt = 1; *ct = 1;
+    blocks = (long)agl_cdiv(a.Cout, 64) * (a.Cin / 16) * npass;
+    z = std::min((768 + blocks - 1) / blocks, zcap);
+  }
   if (z > tiles) z = tiles;
   if (z < 1) z = 1;
   const long per = (tiles + z - 1) / z;

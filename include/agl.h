@@ -111,28 +111,38 @@ double agl_conv2d_bwd_weight_flops(int N, int Cin, int H, int W, int Cout, int O
  * nn.BatchNorm2d/1d in training mode (generator_obj_att.py:35,54,57,433,583,585; normalization.py:78):
  * per-channel mean / rstd over (N,HW), running stats with momentum and unbiased variance.            */
 long agl_bn_stats_ws_bytes(int N, int C, int HW);
+/* moments (optional, 2*C doubles): the batch mean and unbiased variance per channel exactly as the running update used them;
+ * agl_bn_running_update re-applies that update from them (a second evaluation of the same layer on the same batch —
+ * train64.py evaluates the generator twice per iteration with unchanged weights — without reading the activation again). */
 int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* rstd,
-                 float* running_mean, float* running_var, long long* num_batches_tracked, void* ws, long ws_bytes,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, double* moments, void* ws, long ws_bytes,
                  void* stream);
+int agl_bn_running_update(const double* moments, int C, float momentum, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, void* stream);
 int agl_bn_stats_eval(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
                       void* stream);
 /* agl_bn_stats from the partial rows of agl_conv2d_fwd_stats (count = N*HW elements per channel); rows are added in
  * double in a fixed order.  Same running-statistics update. */
 int agl_bn_stats_from_partials(const float* partials, int rows, int C, long count, float eps, float momentum, float* running_mean,
-                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream);
+                               float* running_var, long long* num_batches_tracked, float* mean, float* rstd, double* moments,
+                               void* stream);
 /* y = modulate(xhat) (+residual) (relu).  mode 0: none; 1: gamma[C],beta[C] (BatchNorm affine);
  * 2: table[V][2C] indexed by labels[N] (ConditionalBatchNorm2d, generator_obj_att.py:40-44);
  * 3: gb[N][2C][HW], y = xhat*(1+gamma)+beta (SPADE, normalization.py:106).                           */
+/* gb_map (optional, mode 3 only; NULL = none): gamma|beta given on a coarser block-class grid — p0 is (N, 2C, src_w, src_w), the
+ * map is square W x W (HW = W*W) and pixel (iy, ix) reads cell (gb_map[iy], gb_map[ix]) (W device ints): the nearest /
+ * block-class expansion of normalization.py:100 (agl_grid_gather_fwd) folded into the reads instead of written out. */
 int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
                        const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
-                       void* stream);
+                       const int* gb_map, int W, int src_w, void* stream);
 long agl_norm_bwd_ws_bytes(int N, int C);
 /* dp0 / dp1: parameter gradients.  mode 1: dgamma[C], dbeta[C], overwritten — or added to when param_accumulate (gradient
- * accumulated in place, like autograd's AccumulateGrad); mode 2: dtable[V][2C], always added to; mode 3: dp0 = d(gb), overwritten. */
+ * accumulated in place, like autograd's AccumulateGrad); mode 2: dtable[V][2C], always added to; mode 3: dp0 = d(gb), overwritten —
+ * at the FULL resolution (N, 2C, HW) also when gamma|beta are read through gb_map (reduce it with agl_grid_gather_bwd). */
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
-                 void* stream);
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, int W,
+                 int src_w, void* ws, long ws_bytes, void* stream);
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;

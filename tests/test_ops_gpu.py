@@ -508,14 +508,21 @@ def test_grid_gather_and_spade_block_grids():
         x0, seg0 = rn(2, C, S, S), rn(2, 64, 8, 8, seed=3)
         gy = rn(2, C, S, S, seed=4).to(DEV)
         res = []
-        for flag in (True, False):
-            sp.block_grids = flag
+        # block grids with the expansion folded into the modulation kernel's reads / block grids with the expanded gamma|beta
+        # written out / both convolutions at full resolution: the first two must agree bit for bit in the forward
+        for flag, fold in ((True, True), (True, False), (False, False)):
+            sp.block_grids, sp.fold_gather = flag, fold
             sp.zero_grad()
             x, seg = dev(x0).requires_grad_(True), dev(seg0).requires_grad_(True)
             y = sp(x, seg, relu=True)
             y.backward(gy)
             res.append((y.detach(), x.grad, seg.grad, [p.grad.clone() for p in sp.parameters()]))
-        (y1, dx1, ds1, gp1), (y2, dx2, ds2, gp2) = res
+        (y1, dx1, ds1, gp1), (y1b, dx1b, ds1b, gp1b), (y2, dx2, ds2, gp2) = res
+        assert torch.equal(y1, y1b), "folded expansion must read exactly what the written-out expansion holds"
+        close(dx1, dx1b, 1e-6, f"SPADE dx folded vs written out S={S}")
+        close(ds1, ds1b, 1e-5, f"SPADE dseg folded vs written out S={S}")
+        for a, r in zip(gp1, gp1b):
+            close(a, r, 1e-5, f"SPADE parameter gradient folded vs written out S={S}")
         close(y1, y2, 1e-5, f"SPADE y S={S}")
         close(dx1, dx2, 1e-5, f"SPADE dx S={S}")
         close(ds1, ds2, 2e-4, f"SPADE dseg S={S}")
