@@ -106,7 +106,8 @@ class _Conv2d(torch.autograd.Function):
             # (both into their arena slots, or both into fresh tensors)
             if wslot is not None:
                 fuse_b = want_b and bslot is not None
-                L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True, dbias=bslot if fuse_b else None)
+                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True,
+                                                              dbias=bslot if fuse_b else None), g, x)
             else:
                 fuse_b = want_b and bslot is None
                 if fuse_b:
@@ -160,7 +161,7 @@ class _ConvT4s2(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.slot is not None:
-                L.conv2d_bwd_weight(x, dy, 4, 2, 1, out=ctx.slot, accumulate=True)
+                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(x, dy, 4, 2, 1, out=ctx.slot, accumulate=True), x, dy)
             else:
                 dw = L.conv2d_bwd_weight(x, dy, 4, 2, 1)
         return dx, dw
@@ -526,7 +527,8 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if wslot is not None:
                 fuse_b = want_b and bslot is not None
-                L.conv2d_bwd_weight(dy, xb, 3, 2, 0, out=wslot, accumulate=True, dbias=bslot if fuse_b else None)
+                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(dy, xb, 3, 2, 0, out=wslot, accumulate=True, dbias=bslot if fuse_b else None),
+                                  dy, xb)
             else:
                 fuse_b = want_b and bslot is None
                 if fuse_b:

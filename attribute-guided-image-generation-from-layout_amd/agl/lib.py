@@ -148,6 +148,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 # Convolution flags passed with every agl_conv2d_* call (include/agl.h AGL_CONV_*).  This is host-side state of the
 # Python binding only — the C ABI has no process-wide switches.
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
+CONV_W8, CONV_PRIO = 128, 256
 CONV_FLAGS = 0
 
 
@@ -242,9 +243,29 @@ def ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
 _ws_cache = {}
 
 
+# Weight-gradient side stream (set by agl.trainer.Trainer around its backward passes): dw / db of a convolution depend on dy and x
+# only and nothing in the backward chain reads them, so they run beside the input-gradient chain and fill its tails (partial last
+# rounds of workgroups, small grids of the deep layers).  Used only for gradients accumulated straight into arena slots.
+WGRAD_STREAM = None
+
+
+def on_wgrad_stream(fn, *tensors):
+    """Run fn() on WGRAD_STREAM (after everything enqueued so far on the current stream) and keep `tensors` alive for it."""
+    side = WGRAD_STREAM
+    if side is None:
+        return fn()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return out
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (all launches are ordered on the current stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream): the launches that share one are ordered on that stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

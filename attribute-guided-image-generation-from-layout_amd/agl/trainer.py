@@ -83,6 +83,9 @@ class Trainer:
         # "f32x3": fp32 tensors with fp32-accurate products on the bf16 matrix cores (three bf16 terms per operand, six
         # products, AGL_CONV_SPLIT3) in the kernels that support it, exact fp32 MFMA elsewhere
         self.conv_flags = {"f32": 0, "fp32": 0, "f32x3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[conv_dtype]
+        # weight gradients on their own stream beside the input-gradient chain (agl.lib.WGRAD_STREAM); AGL_WGRAD_STREAM=0: off
+        import os
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if os.environ.get("AGL_WGRAD_STREAM", "1") != "0" else None
         self._in_step = False
         # With data parallelism step() returns while the G all-reduce + Adam still run on the side stream.  Readers of
         # the weights outside step() (state_dict / checkpoint.save_model, eval or user forwards) join it first.
@@ -157,6 +160,19 @@ class Trainer:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def _backward(self, heads, grads):
+        """torch.autograd.backward with the weight-gradient kernels on the side stream; joined before anything reads the slots."""
+        side = self.wgrad_stream
+        if side is None:
+            torch.autograd.backward(heads, grads)
+            return
+        L.WGRAD_STREAM = side
+        try:
+            torch.autograd.backward(heads, grads)
+        finally:
+            L.WGRAD_STREAM = None
+        torch.cuda.current_stream().wait_stream(side)
+
     # ------------------------------------------------------------------ the step
     def step(self, b: Dict[str, torch.Tensor], eps_d: Optional[Sequence[torch.Tensor]] = None,
              eps_g: Optional[Sequence[torch.Tensor]] = None):
@@ -216,7 +232,7 @@ class Trainer:
         term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
         att = self.netDa(crops_input)
         term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
-        torch.autograd.backward(heads, grads)
+        self._backward(heads, grads)
         if self.on_d_backward is not None:
             self.on_d_backward(self)
         self._d_ready = self._reduce_and_step(self.flat_d)
@@ -250,7 +266,7 @@ class Trainer:
                 term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
                 att = self.netDa(x)
                 term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
-            torch.autograd.backward(heads, grads)
+            self._backward(heads, grads)
             if self.on_g_backward is not None:
                 self.on_g_backward(self)
         finally:

@@ -970,6 +970,9 @@ struct ConvOpts {
   bool pos_all_ks;   // experiments: position-major also for 3x3 / 4x4 kernels
   bool split3;       // fp32 operands as three bf16 terms, six bf16-MFMA products (pconv.hip) where that kernel applies
   bool any_grid;     // matrix-core kernels also below their occupancy threshold (unit tests)
+  bool w8;           // eight-wave workgroups in the LDS-patch kernels that have that form
+  int prio;          // start stagger of the co-resident workgroups of the LDS-patch kernels (0 off, 1..4: delay length)
+  int ablate;        // diagnostic kernel builds (flags bits 9..11; results are wrong by construction)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -981,9 +984,12 @@ static ConvOpts conv_opts(int flags) {
   o.pos_all_ks = (flags & 16) != 0;
   o.split3 = (flags & 32) != 0 && o.prec == 0;
   o.any_grid = (flags & 64) != 0;
+  o.w8 = (flags & 128) != 0;
+  o.prio = (flags >> 14) & 7;
+  o.ablate = (flags >> 9) & 31;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1588,7 +1594,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
-    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
@@ -1693,7 +1699,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
     PConvArgs a{};    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
-    a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
@@ -1722,7 +1728,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
     PConvArgs a{};
     a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
-    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
@@ -2013,7 +2019,7 @@ long agl_conv2d_fwd_packed_bytes(int N, int Cin, int H, int W, int Cout, int ks,
   if (Cout <= 4 || OH <= 0 || OW <= 0) return 0;
   PConvArgs a{};
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
-  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
   return pconv_eligible(a) ? pconv_ws_bytes(Cin, Cout, ks, a.nsplit) : 0;
 }
 long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
@@ -2021,7 +2027,7 @@ long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, 
   if (!(co.patch && (co.prec == 1 || co.split3)) || !ks_ok(ks) || Cin <= 4) return 0;
   PConvArgs a{};
   a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.up = 0;
-  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+  a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
   if (stride == 1 && IH == OH && IW == OW) {
     a.stride = 1; a.pad = ks - 1 - pad;
     return pconv_eligible(a) ? pconv_ws_bytes(Cout, Cin, ks, a.nsplit) : 0;
@@ -2070,7 +2076,7 @@ double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int 
   if (co.patch && (co.prec == 1 || co.split3)) {
     PConvArgs a{};
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
-    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     mc = pconv_eligible(a);
   }
   if (!small && !mc && pos_ok(co, N, Cin, H, W, Cout, ks, up_log2))
@@ -2084,7 +2090,7 @@ double agl_conv2d_bwd_data_flops(int N, int Cin, int IH, int IW, int Cout, int O
   if (co.patch && (co.prec == 1 || co.split3) && stride == 1 && IH == OH && IW == OW) {
     PConvArgs a{};
     a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0;
-    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     mc = pconv_eligible(a);
   }
   if (!small && !mc && stride == 1 && IH == OH && IW == OW && pos_ok(co, N, Cout, OH, OW, Cin, ks, 0))

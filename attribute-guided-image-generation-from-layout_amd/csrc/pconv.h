@@ -9,6 +9,9 @@ struct PConvArgs {
   int w_sm, w_sc, flip;             // element strides of w for (output channel m, input channel c); flipped taps
   int nsplit;                       // 1: bf16 operands (AGL_CONV_BF16); 3: fp32 operands as three bf16 terms, six products
   int any_grid;                     // launch also below the occupancy threshold (AGL_CONV_ANY_GRID)
+  int w8;                           // eight-wave workgroups where instantiated (AGL_CONV_W8)
+  int prio;                         // priority 1 for the conversion segments (AGL_CONV_PRIO)
+  int ablate;                       // diagnostic builds of pconv_k (flags bits 9..11): WRONG results, timing only
   float* stats; long stats_floats; int* stat_rows;   // optional BatchNorm partials of the output: buffer, its capacity, rows written
   const void* packed;               // optional: the weights already in packed form (pconv_pack / pconvT_pack with the same nsplit) — no
                                     // per-call pack_weights_k launch; the packed tensor w0 may differ from w by a scalar: w = w0 / *out_div

@@ -41,6 +41,7 @@ struct PArgs {
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
   int cps;           // (each slab is shaped like y; splitk_epilogue of conv.hip adds them and applies the epilogue)
   long out_numel;
+  int prio;          // raise the wave priority for the conversion / LDS-store segment of every stage (A/B switch)
   int oh2, ow2;      // phase mode: extent of the output map (2*OH x 2*OW, or one more row and column for an odd-sized input)
   const float* odiv; // optional device scalar: the products are divided by it before bias / mask / ReLU (pre-packed weights of a
 };                   // spectrally normalised layer: packed W_orig, divisor sigma)
@@ -122,8 +123,16 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // PHS: the four stride phases of a 4x4 / stride-2 / pad-1 input gradient (= ConvTranspose2d(4,2,1) forward).  Output phase
 // (ph,pw) = blockIdx.z is a 2x2-tap stride-1 correlation of dy with pads (1-ph, 1-pw) and its own quarter of the packed weights;
 // its pixels (a,b) land at (2a+ph, 2b+pw) of the twice-as-large output map.
-template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false>
-__global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
+// NTH: threads per workgroup.  256 = 2x2 waves; 512 = 2x4 waves, each owning half as many pixels: twice the waves per SIMD for the
+// same LDS footprint (two workgroups per CU either way), so that a wave waiting for its LDS fragments, a barrier or its staging
+// loads leaves the matrix pipe to three others instead of one.
+// ABL (diagnostic builds only, results are wrong), a bit mask: 1 no MFMAs, 2 no operand conversion (one rounding, the other planes
+// are copies), 4 no LDS fragment reads inside the tap loop (tap 0's fragments for every tap), 8 no global loads after the first
+// stage, 16 no LDS stores after the first stage
+template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false, int NTH = 256, int ABL = 0>
+__global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
+  constexpr int NT = NTH;                      // (shadows the file-level 256)
+  constexpr int WNW = NTH / 128;               // wave columns (pixel direction); 2 wave rows (channel direction)
   static_assert(!PHS || (KS == 2 && S == 1 && TG == 4), "phase mode");
   // PAIR (phase mode, tiles >= 4 wide): one workgroup evaluates BOTH column phases pw = 0, 1 of its row phase — they share the
   // dy patch (one more column) and their outputs interleave to 16-byte stores of the twice-as-wide row instead of stride-2
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   constexpr int A_PLANE = 2 * TGA * BM;        //                           [h][t][row]
   constexpr int NB = 2 * TI * PH * PW, BR = (NB + NT - 1) / NT;
   constexpr int NA = NSPL * A_PLANE, AR = (NA + NT - 1) / NT;
-  constexpr int WTM = BM / 64, WTN = BN / 64;   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/2 pixels)
+  constexpr int WTM = BM / 64, WTN = BN / (32 * WNW);   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/WNW pixels)
+  static_assert(WTN >= 1, "tile too small for this many waves");
   constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
   constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
   // DB: double buffering (where it does not cost a workgroup per CU).  With a second weight buffer the stores of stage s+1 need
@@ -155,13 +165,13 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   constexpr int PB = NSPL * P_PLANE, AB = NSPL * A_PLANE;          // 16-byte pieces per patch / weight buffer
   constexpr int LDS_CAP = (PB + AB <= 5120) ? 5120 : 10240;       // keep two workgroups per CU (80 KB each) when one buffer pair fits that
   constexpr bool DBA = DB && PB + 2 * AB <= LDS_CAP, DBB = DBA && 2 * PB + 2 * AB <= LDS_CAP;
-  constexpr int STAGE_PIECES = (DBB ? 2 : 1) * PB + (DBA ? 2 : 1) * AB, EP_PIECES = 4 * 32 * EP_PITCH / 4;   // 16-byte pieces
+  constexpr int STAGE_PIECES = (DBB ? 2 : 1) * PB + (DBA ? 2 : 1) * AB, EP_PIECES = (NTH / 64) * 32 * EP_PITCH / 4;   // 16-byte pieces
   __shared__ u32x4 lds[STAGE_PIECES > EP_PIECES ? STAGE_PIECES : EP_PIECES];
   u32x4* const Pl = lds;
   u32x4* const Al = lds + (DBB ? 2 : 1) * PB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   const int Hl = p.H << p.up, Wl = p.W << p.up;
   int img0, ty0, tx0;
   if constexpr (TI == 1) {
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   float pb[BR][8];
   u32x4 pa[AR];
   auto gload_b = [&](int c0) {
+    if ((ABL & 8) && c0 != 16 * (p.slabs ? (int)(blockIdx.z / (PHS ? (PAIR ? 2 : 4) : 1)) * p.cps : 0)) return;
 #pragma unroll
     for (int r = 0; r < BR; ++r)
 #pragma unroll
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
         pb[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, bsrc[r], (unsigned)(c0 + j) * cstride, 0));
   };
   auto gload_a = [&](int cc, int tg) {                     // cc is clamped by the caller (the last prefetch is never used)
+    if ((ABL & 8) && (cc != 0 || tg != 0)) return;
     const u32x4* base = p.wp + (long)(cc * 2 * KKW + tg * TG) * p.mpad;
 #pragma unroll
     for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
       for (int j = 0; j < 8; ++j) {
         const float v = p.in_relu ? fmaxf(pb[r][j], 0.f) : pb[r][j];
         if constexpr (NSPL == 1) { t0[j] = (__bf16)v; }
+        else if constexpr ((ABL & 2) != 0) { t0[j] = (__bf16)v; t1[j] = t0[j]; t2[j] = t0[j]; }
         else { __bf16 a, b, d; split3(v, a, b, d); t0[j] = a; t1[j] = b; t2[j] = d; }
       }
       Pl[bdst[r]] = __builtin_bit_cast(u32x4, t0);
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   int qlane[WTN];
 #pragma unroll
   for (int jt = 0; jt < WTN; ++jt) {
-    const int j = wn * (BN / 2) + 32 * jt + l31;
+    const int j = wn * (BN / WNW) + 32 * jt + l31;
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
     qlane[jt] = lh * NQ + ti * IMGP + S * py * PWP + px;
   }
@@ -268,6 +281,20 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
           for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] = 0.f;
   auto& acc = accs[0];
 
+  // Stagger (speed only): the two workgroups that share a CU start together, run the same program for the same time and so
+  // stay in lockstep — both in their matrix segment (sharing the pipe), then both in their staging segment (pipe idle).  The
+  // workgroup in the odd slot of the first generation waits about half a stage; later generations inherit the offset because a
+  // slot is refilled when its workgroup ends.  HW_REG_HW_ID[19:16] = workgroup slot on the CU.
+  if (p.prio > 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+    if (lin < 768 && (tg & 1)) {
+      if (p.prio == 1) __builtin_amdgcn_s_sleep(16);
+      else if (p.prio == 2) __builtin_amdgcn_s_sleep(32);
+      else if (p.prio == 3) __builtin_amdgcn_s_sleep(64);
+      else { __builtin_amdgcn_s_sleep(127); }
+    }
+  }
   const int c_lo = p.slabs ? zsplit * p.cps : 0;                  // reduction split: this workgroup's chunk range
   const int nchunk = p.slabs ? min(p.cps, p.nch - c_lo) : p.nch;
   const int nstage = nchunk * NTG;     // stage s = (channel chunk s / NTG, tap group s % NTG)
@@ -297,14 +324,19 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
 #pragma unroll
       for (int pl = 0; pl < NSPL; ++pl) {
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[pl][i] = __builtin_bit_cast(bf16x8, Ac[pl * A_PLANE + arow + t * BM + 32 * i]);
+        for (int i = 0; i < WTM; ++i) fa[pl][i] = __builtin_bit_cast(bf16x8, Ac[pl * A_PLANE + arow + ((ABL & 4) ? 0 : t) * BM + 32 * i]);
 #pragma unroll
-        for (int jt = 0; jt < WTN; ++jt) fb[pl][jt] = __builtin_bit_cast(bf16x8, Pc[pl * P_PLANE + qlane[jt] + toff]);
+        for (int jt = 0; jt < WTN; ++jt) fb[pl][jt] = __builtin_bit_cast(bf16x8, Pc[pl * P_PLANE + qlane[jt] + ((ABL & 4) ? 0 : toff)]);
       }
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int jt = 0; jt < WTN; ++jt) {
+          if constexpr ((ABL & 1) != 0) {      // keep the fragments live without the matrix instructions
+            asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][jt]));
+            if constexpr (NSPL == 3) asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][jt]), "v"(fa[2][i]), "v"(fb[2][jt]));
+            continue;
+          }
           accs[pw][0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][jt], accs[pw][0][i][jt], 0, 0, 0);
           if constexpr (NSPL == 3) {      // the small terms (<= 2^-8 of the leading one) accumulate apart: their rounding errors
             f32x16& lo = accs[pw][NACC - 1][i][jt];   // are 2^-8 smaller and the leading chain sees one rounding per K-step
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     // a buffer that is about to be overwritten may still be read by a slower wave unless it is the other one of a pair
     if constexpr (!DBA) __syncthreads();
     else if constexpr (!DBB) { if (last_tg) __syncthreads(); }
-    if (s + 1 < nstage) {      // (the last stage's prefetch is a dummy: nothing to convert or store)
+    if (s + 1 < nstage && !(ABL & 16)) {      // (the last stage's prefetch is a dummy: nothing to convert or store)
       if (last_tg) sstore_b(DBB ? ((cc + 1) & 1) * PB : 0);
       sstore_a(DBA ? ((s + 1) & 1) * AB : 0);
     }
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
     for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; }
 #pragma unroll
   for (int jt = 0; jt < WTN; ++jt) {
-    const int j = wn * (BN / 2) + 32 * jt + ec;
+    const int j = wn * (BN / WNW) + 32 * jt + ec;
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
     const int img = img0 + ti;
     const long pbase = (long)img * p.Cout * OHW + (long)(ty0 + py) * p.OW + tx0 + px;
@@ -503,7 +535,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_k(PArgs p) {
   }
   if constexpr (!PHS) {
     if (p.stats) {      // the 8 lanes of a channel row hold its pixels: butterfly within the octet, lane 0 of it writes the partial
-      float* const row = p.stats + ((long)blockIdx.x * 2 + wn) * p.Cout * 2;
+      float* const row = p.stats + ((long)blockIdx.x * WNW + wn) * p.Cout * 2;
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -947,16 +979,19 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const int KK = a.ks * a.ks, nch = a.Cin / 16, mpad = round_up(a.Cout, 128);
   u32x4* wp = a.packed ? (u32x4*)a.packed : (u32x4*)ws;
   PArgs p;
-  p.odiv = a.out_div;
+  p.odiv = a.out_div; p.prio = a.prio;
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW; p.pad = a.pad; p.up = a.up;
   p.in_relu = a.in_relu; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad;
   if (a.ks == 1) { p.H = p.OH = pl.oh; p.W = p.OW = pl.ow; }      // the re-read map of a 1x1 convolution
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = 0; p.ow2 = 0;
   if (pl.splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, pl.splits); }
-  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && 2 * ptiles * a.Cout * 2 <= a.stats_floats) {
+  // eight-wave workgroups (see pconv_k): the split-mode stride-1 3x3 / 5x5 kernels on tiles of >= 128 pixels
+  const bool w8 = a.w8 && a.nsplit == 3 && !s2 && (a.ks == 3 || a.ks == 5) && geo != 2 && geo != 3;
+  const int wcols = w8 ? 4 : 2;                 // wave columns = statistic rows per pixel tile
+  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 2 <= a.stats_floats) {
     p.stats = a.stats;
-    *a.stat_rows = (int)(2 * ptiles);
+    *a.stat_rows = (int)(wcols * ptiles);
   }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
@@ -968,6 +1003,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
 #define PC_LAUNCH_DB(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, true>), g, dim3(NT), 0, st, p)
+#define PC_LAUNCH8(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, DB_) \
+  hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, DB_, 512>), g, dim3(512), 0, st, p)
 #define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
   do {                                                                                                   \
     if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, BM_, 1, TG_);                                               \
@@ -1014,6 +1051,29 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   } else if (a.ks == 1) {
     if (a.nsplit == 3) { if (bm == 128) PC_1X1(128, 3); else PC_1X1(64, 3); }
     else { if (bm == 128) PC_1X1(128, 1); else PC_1X1(64, 1); }
+  } else if (a.ablate > 0 && a.ks == 3 && a.nsplit == 3 && wide && w32) {      // diagnostic builds of ONE geometry (tools/ablate.sh)
+#define PC_ABL(A_) hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 3, 3, false, false, 256, A_>), g, dim3(256), 0, st, p)
+    switch (a.ablate) {
+      case 1: PC_ABL(1); break; case 2: PC_ABL(2); break; case 4: PC_ABL(4); break; case 8: PC_ABL(8); break;
+      case 14: PC_ABL(14); break; case 30: PC_ABL(30); break; case 31: PC_ABL(31); break; case 16: PC_ABL(16); break;
+      default: PC_ABL(6); break;
+    }
+#undef PC_ABL
+  } else if (w8 && a.ks == 3) {
+    if (wide) { if (w32) PC_LAUNCH8(3, 1, 32, 8, 1, 64, 3, 3, false); else PC_LAUNCH8(3, 1, 16, 16, 1, 64, 3, 3, false); }
+    else if (bm == 128) {
+      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 128, 3, 3, false);
+      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 128, 3, 3, false);
+      else PC_LAUNCH8(3, 1, 8, 8, 2, 128, 3, 3, false);
+    } else {
+      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 64, 3, 9, false);
+      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 64, 3, 9, false);
+      else PC_LAUNCH8(3, 1, 8, 8, 2, 64, 3, 9, false);
+    }
+  } else if (w8 && a.ks == 5) {
+    if (geo == 0 && w32) PC_LAUNCH8(5, 1, 32, 4, 1, 64, 3, 5, true);
+    else if (geo == 0) PC_LAUNCH8(5, 1, 16, 8, 1, 64, 3, 5, true);
+    else PC_LAUNCH8(5, 1, 8, 8, 2, 64, 3, 5, true);
   } else if (a.ks == 3) {
     if (geo == 2) {
       if (a.nsplit == 3) PC_LAUNCH_DB(3, 1, 4, 4, 8, 64, 3, 3);    // one kernel row per stage, two weight + two patch buffers
@@ -1041,6 +1101,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_SHAPES3
 #undef PC_LAUNCH
 #undef PC_LAUNCH_DB
+#undef PC_LAUNCH8
   AGL_CHECK_LAUNCH(name);
   if (pl.splits > 1)
     return agl_launch_splitk_epilogue(p.slabs, a.y, out_numel, (int)g.z, a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, st, name,
@@ -1113,7 +1174,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
     if (prc != AGL_OK) return prc;
   }
   PArgs p;
-  p.odiv = a.out_div;
+  p.odiv = a.out_div; p.prio = a.prio;
   p.x = a.x; p.wp = wp; p.bias = a.bias; p.pos_mask = a.pos_mask; p.y = a.y;
   p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.H; p.OW = a.W;      // tiles run over the dy map
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;

@@ -55,6 +55,9 @@ const char* agl_last_error(void);
 #define AGL_CONV_POS_ALL_KS 16
 #define AGL_CONV_SPLIT3 32
 #define AGL_CONV_ANY_GRID 64
+#define AGL_CONV_PRIO 256 /* wave priority 1 for the conversion / LDS-store bursts of the patch kernels (A/B switch) */
+#define AGL_CONV_W8 128   /* eight-wave (512-thread) workgroups in the split-mode stride-1 3x3 / 5x5 patch kernels: same tile and LDS
+                           * footprint, twice the waves per SIMD (A/B switch; the host mirror sets it where it measured faster) */
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);

@@ -18,6 +18,10 @@ if os.environ.get("AGL_ANYGRID"):
     L.CONV_FLAGS |= L.CONV_ANY_GRID
 if os.environ.get("AGL_SPLIT3"):
     L.CONV_FLAGS |= L.CONV_SPLIT3
+if os.environ.get("AGL_W8"):
+    L.CONV_FLAGS |= L.CONV_W8
+if os.environ.get("AGL_PRIO"):
+    L.CONV_FLAGS |= L.CONV_PRIO
 if os.environ.get("AGL_PREC"):
     L.set_conv_precision(os.environ["AGL_PREC"])
 O, N = 393, 64

@@ -8,6 +8,9 @@ B, Cin, H, Cout, ks, s, p = (int(v) for v in sys.argv[1:8])
 which = sys.argv[8] if len(sys.argv) > 8 else "fwd"
 if os.environ.get("AGL_PREC"): L.set_conv_precision(os.environ["AGL_PREC"])
 if os.environ.get("AGL_SPLIT3"): L.CONV_FLAGS |= L.CONV_SPLIT3
+if os.environ.get("AGL_W8"): L.CONV_FLAGS |= L.CONV_W8
+if os.environ.get("AGL_PRIO"): L.CONV_FLAGS |= int(os.environ["AGL_PRIO"]) << 14
+if os.environ.get("AGL_ABLATE"): L.CONV_FLAGS |= int(os.environ["AGL_ABLATE"]) << 9
 x = torch.randn(B, Cin, H, H, device="cuda:0"); w = torch.randn(Cout, Cin, ks, ks, device="cuda:0") * 0.05
 y = L.conv2d_fwd(x, w, None, s, p); dy = torch.randn_like(y)
 for _ in range(5):
@@ -15,3 +18,11 @@ for _ in range(5):
     elif which == "bwd_data": L.conv2d_bwd_data(dy, w, (H, H), s, p)
     else: L.conv2d_bwd_weight(dy, x, ks, s, p)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    if which == "fwd": L.conv2d_fwd(x, w, None, s, p)
+    elif which == "bwd_data": L.conv2d_bwd_data(dy, w, (H, H), s, p)
+    else: L.conv2d_bwd_weight(dy, x, ks, s, p)
+e1.record(); torch.cuda.synchronize()
+print("%s %s stagger=%s ablate=%s: %.1f us per call" % (sys.argv[1:8], which, os.environ.get("AGL_PRIO", "0"), os.environ.get("AGL_ABLATE", "0"), 1e3 * e0.elapsed_time(e1) / 20))
