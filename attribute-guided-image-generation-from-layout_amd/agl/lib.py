@@ -243,15 +243,17 @@ def ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
 _ws_cache = {}
 
 
-# Weight-gradient side stream (set by agl.trainer.Trainer around its backward passes): dw / db of a convolution depend on dy and x
+# Weight-gradient side streams (set by agl.trainer.Trainer around its backward passes): dw / db of a convolution depend on dy and x
 # only and nothing in the backward chain reads them, so they run beside the input-gradient chain and fill its tails (partial last
 # rounds of workgroups, small grids of the deep layers).  Used only for gradients accumulated straight into arena slots.
-WGRAD_STREAM = None
+# One side stream per stream the backward chains run on: {chain stream handle: side stream}.
+WGRAD_STREAMS = None
 
 
 def on_wgrad_stream(fn, *tensors):
-    """Run fn() on WGRAD_STREAM (after everything enqueued so far on the current stream) and keep `tensors` alive for it."""
-    side = WGRAD_STREAM
+    """Run fn() on the weight-gradient stream of the current stream (after everything enqueued so far on it) and keep
+    `tensors` alive for it."""
+    side = WGRAD_STREAMS.get(torch.cuda.current_stream().cuda_stream) if WGRAD_STREAMS else None
     if side is None:
         return fn()
     side.wait_stream(torch.cuda.current_stream())

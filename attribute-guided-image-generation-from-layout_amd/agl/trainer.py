@@ -86,6 +86,16 @@ class Trainer:
         # weight gradients on their own stream beside the input-gradient chain (agl.lib.WGRAD_STREAM); AGL_WGRAD_STREAM=0: off
         import os
         self.wgrad_stream = torch.cuda.Stream(device=dev) if os.environ.get("AGL_WGRAD_STREAM", "1") != "0" else None
+        # The three discriminators are independent networks: their forward / backward chains run on three streams beside each
+        # other (calls of ONE network stay in order on its stream, so its spectral-norm state advances exactly as before, and
+        # its gradient slots have one writer chain).  Every convolution launch ends in a partial round of workgroups and the
+        # deep layers have small grids; concurrent chains fill those holes.  AGL_D_STREAMS=0: everything on one stream.
+        self.d_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if os.environ.get("AGL_D_STREAMS", "1") != "0" else None
+        self._wgrad_map = None
+        if self.wgrad_stream is not None:
+            self._wgrad_map = {torch.cuda.current_stream(dev).cuda_stream: self.wgrad_stream}
+            for st in (self.d_streams or []):
+                self._wgrad_map[st.cuda_stream] = torch.cuda.Stream(device=dev)
         self._in_step = False
         # With data parallelism step() returns while the G all-reduce + Adam still run on the side stream.  Readers of
         # the weights outside step() (state_dict / checkpoint.save_model, eval or user forwards) join it first.
@@ -162,16 +172,35 @@ class Trainer:
 
     def _backward(self, heads, grads):
         """torch.autograd.backward with the weight-gradient kernels on the side stream; joined before anything reads the slots."""
-        side = self.wgrad_stream
-        if side is None:
-            torch.autograd.backward(heads, grads)
-            return
-        L.WGRAD_STREAM = side
+        main = torch.cuda.current_stream()
+        if self._wgrad_map is not None and main.cuda_stream not in self._wgrad_map:      # (a caller-chosen stream: give it a partner)
+            self._wgrad_map[main.cuda_stream] = self.wgrad_stream
+        L.WGRAD_STREAMS = self._wgrad_map
         try:
             torch.autograd.backward(heads, grads)
         finally:
-            L.WGRAD_STREAM = None
-        torch.cuda.current_stream().wait_stream(side)
+            L.WGRAD_STREAMS = None
+        for st in (self.d_streams or []):                # the discriminator chains ran their backward on their own streams
+            main.wait_stream(st)
+        for st in (self._wgrad_map or {}).values():
+            main.wait_stream(st)
+
+    class _Chains:
+        """Context of the per-network streams: `with chains.on(k): ...` runs a discriminator's calls on stream k."""
+
+        def __init__(self, streams):
+            self.streams = streams
+            self.main = torch.cuda.current_stream()
+            for st in streams or []:
+                st.wait_stream(self.main)
+
+        def on(self, k):
+            import contextlib
+            return torch.cuda.stream(self.streams[k]) if self.streams else contextlib.nullcontext()
+
+        def join(self):
+            for st in self.streams or []:
+                self.main.wait_stream(st)
 
     # ------------------------------------------------------------------ the step
     def step(self, b: Dict[str, torch.Tensor], eps_d: Optional[Sequence[torch.Tensor]] = None,
@@ -219,19 +248,24 @@ class Trainer:
             heads.append(t)
             grads.append(g)
 
-        for name, x, w in (("d_img_rec", img_rec, MIX[0]), ("d_img_rand", img_rand, MIX[1]), ("d_img_shift", img_shift, MIX[2])):
-            lg = self.netDi(x)
-            term(lg, LS.bce_const(lg, 0.0, lam["img_adv"] * w, self._slot(name)))
-        lg = self.netDi(b["imgs"])
-        term(lg, LS.bce_const(lg, 1.0, lam["img_adv"], self._slot("d_img_real")))
-        for name, x, w in (("d_obj_rec", crops_rec, MIX[0]), ("d_obj_rand", crops_rand, MIX[1]), ("d_obj_shift", crops_shift, MIX[2])):
-            src, _ = self.netDo(x, objs)
-            term(src, LS.bce_const(src, 0.0, lam["obj_adv"] * w, self._slot(name)))
-        src, cls = self.netDo(crops_input, objs)
-        term(src, LS.bce_const(src, 1.0, lam["obj_adv"], self._slot("d_obj_real")))
-        term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
-        att = self.netDa(crops_input)
-        term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
+        ch = self._Chains(self.d_streams)
+        with ch.on(0):
+            for name, x, w in (("d_img_rec", img_rec, MIX[0]), ("d_img_rand", img_rand, MIX[1]), ("d_img_shift", img_shift, MIX[2])):
+                lg = self.netDi(x)
+                term(lg, LS.bce_const(lg, 0.0, lam["img_adv"] * w, self._slot(name)))
+            lg = self.netDi(b["imgs"])
+            term(lg, LS.bce_const(lg, 1.0, lam["img_adv"], self._slot("d_img_real")))
+        with ch.on(1):
+            for name, x, w in (("d_obj_rec", crops_rec, MIX[0]), ("d_obj_rand", crops_rand, MIX[1]), ("d_obj_shift", crops_shift, MIX[2])):
+                src, _ = self.netDo(x, objs)
+                term(src, LS.bce_const(src, 0.0, lam["obj_adv"] * w, self._slot(name)))
+            src, cls = self.netDo(crops_input, objs)
+            term(src, LS.bce_const(src, 1.0, lam["obj_adv"], self._slot("d_obj_real")))
+            term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
+        with ch.on(2):
+            att = self.netDa(crops_input)
+            term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
+        ch.join()
         self._backward(heads, grads)
         if self.on_d_backward is not None:
             self.on_d_backward(self)
@@ -257,15 +291,21 @@ class Trainer:
             dmu, dlv = LS.kl_sum(mu, logvar, lam["kl"], self._slot("g_kl"))
             term(mu, dmu)
             term(logvar, dlv)
-            for tag, x, w in (("rec", img_rec, MIX[0]), ("rand", img_rand, MIX[1]), ("shift", img_shift, MIX[2])):
-                lg = self.netDi(x)
-                term(lg, LS.bce_const(lg, 1.0, lam["img_adv"] * w, self._slot("g_img_adv_" + tag)))
-            for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
-                src, cls = self.netDo(x, objs)
-                term(src, LS.bce_const(src, 1.0, lam["obj_adv"] * w, self._slot("g_obj_adv_" + tag)))
-                term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
-                att = self.netDa(x)
-                term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
+            ch = self._Chains(self.d_streams)
+            with ch.on(0):
+                for tag, x, w in (("rec", img_rec, MIX[0]), ("rand", img_rand, MIX[1]), ("shift", img_shift, MIX[2])):
+                    lg = self.netDi(x)
+                    term(lg, LS.bce_const(lg, 1.0, lam["img_adv"] * w, self._slot("g_img_adv_" + tag)))
+            with ch.on(1):
+                for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
+                    src, cls = self.netDo(x, objs)
+                    term(src, LS.bce_const(src, 1.0, lam["obj_adv"] * w, self._slot("g_obj_adv_" + tag)))
+                    term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
+            with ch.on(2):
+                for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
+                    att = self.netDa(x)
+                    term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
+            ch.join()
             self._backward(heads, grads)
             if self.on_g_backward is not None:
                 self.on_g_backward(self)
