@@ -56,6 +56,7 @@ class FlatParams:
                 p.data = self.p[o:o + k].view(p.shape)
                 p.grad = self.g[o:o + k].view(p.shape)
                 p._agl_slot = True          # backward kernels accumulate straight into this slot (functional._slot)
+                p._agl_flat, p._agl_off = self, o     # (for the private gradient arenas of concurrent branches, functional.GRAD_ARENA)
                 if p.dim() == 4:            # convolution weights: handle of their packed forms
                     p._agl_wsrc = L.WeightSrc(p, (lambda p=p: (self.epoch, p._version)))
                 o += k
@@ -66,6 +67,7 @@ class FlatParams:
             j = self.p[oa:oa + k].view(shape).detach().requires_grad_(True)
             j.grad = self.g[oa:oa + k].view(shape)
             j._agl_slot = True
+            j._agl_flat, j._agl_off = self, oa
             if j.dim() == 4:
                 j._agl_wsrc = L.WeightSrc(j, (lambda a=a, b=b: (self.epoch, a._version, b._version)))
             mod.__dict__.setdefault("_agl_joined", {})[name] = j
@@ -79,6 +81,18 @@ class FlatParams:
     def set_requires_grad(self, flag: bool):
         for p in self.params:
             p.requires_grad_(flag)
+
+    def branch_arenas(self, k: int):
+        """k zero-filled buffers laid out like .g (allocated once): private gradient arenas of concurrent branches."""
+        if not hasattr(self, "_branch_g") or len(self._branch_g) < k:
+            self._branch_g = [torch.zeros_like(self.g) for _ in range(k)]
+        return self._branch_g[:k]
+
+    def fold_branch_arenas(self):
+        """g += every branch arena; the arenas are zeroed for their next use (all on the current stream)."""
+        for b in getattr(self, "_branch_g", []):
+            L.axpby(self.g, b, 1.0, 1.0, out=self.g)
+            b.zero_()
 
     def touch(self):
         """Call after writing the arena through anything but the parameters themselves (e.g. a broadcast into .p)."""

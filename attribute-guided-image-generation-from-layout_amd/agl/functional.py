@@ -33,11 +33,37 @@ def bn_tape_replay(tape):
         fn()
 
 
+# Deferred running-statistics updates (agl.generator's concurrent branches): while BN_DEFER is a list, a training-mode statistics
+# call leaves its moments and does NOT touch the running statistics; bn_apply_deferred performs the updates later, in list order.
+# Two branches that share BatchNorm layers can then be evaluated side by side on two streams and still update every layer's
+# running statistics in the reference's order (first branch, then second).
+BN_DEFER = None
+
+
+def bn_apply_deferred(entries):
+    for mom, rmean, rvar, nbt in entries:
+        L.bn_running_update(mom, BN_MOMENTUM, rmean, rvar, nbt)
+
+
 def _slot(p):
     """Gradient slot of a parameter owned by a flat arena (agl.flat.FlatParams marks them): backward kernels then
     accumulate straight into the arena and return None, instead of handing autograd a temporary that it adds to
     .grad with one extra elementwise launch per parameter per use (~700 launches per training iteration)."""
-    return p.grad if (p is not None and getattr(p, "_agl_slot", False) and p.grad is not None) else None
+    if p is None or not getattr(p, "_agl_slot", False) or p.grad is None:
+        return None
+    a = GRAD_ARENA
+    if a is not None and getattr(p, "_agl_flat", None) is a[0]:
+        off = p._agl_off
+        return a[1][off:off + p.numel()].view(p.shape)
+    return p.grad
+
+
+# Private gradient arena of a concurrent branch: (FlatParams, tensor laid out like its .g) or None.  Two generator branches that run
+# on two streams share their layers; their backward kernels would read-modify-write the same gradient slots at the same time.  While
+# GRAD_ARENA is set (during a branch's FORWARD: the slots are chosen there), the slots of that arena's parameters point into the
+# branch's own buffer instead; agl.trainer adds the buffers to the arena's gradient after the backward pass.
+GRAD_ARENA = None
+
 
 
 # BatchNorm statistics produced by the convolution that feeds the norm (agl_conv2d_fwd_stats): while EMIT_STATS is set (the
@@ -184,13 +210,17 @@ class _NormAct(torch.autograd.Function):
         if training:
             # on a tape the call also leaves its (mean, unbiased variance) in double: the replay re-applies the running update
             # from them — the same arithmetic on the same numbers, without a second read of the activation
-            mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device) if (BN_TAPE is not None and rmean is not None) else None
+            defer = BN_DEFER is not None and rmean is not None
+            taped = BN_TAPE is not None and rmean is not None
+            mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device) if (taped or defer) else None
+            upd = (None, None, None) if defer else (rmean, rvar, nbt)      # deferred: the kernel leaves the running statistics alone
             if part is not None:
-                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, rmean, rvar, nbt,
-                                                      moments=mom)
+                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, *upd, moments=mom)
             else:
-                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, rmean, rvar, nbt, moments=mom)
-            if mom is not None:
+                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, *upd, moments=mom)
+            if defer:
+                BN_DEFER.append((mom, rmean, rvar, nbt))
+            if taped:
                 BN_TAPE.append(lambda: L.bn_running_update(mom, BN_MOMENTUM, rmean, rvar, nbt))
         else:
             mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)

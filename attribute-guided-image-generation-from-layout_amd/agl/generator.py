@@ -182,12 +182,13 @@ class LayoutEncoder(nn.Module):
         h = self.clstm(h, obj_to_img, plan=plan)
         return self.residual(h)
 
-    def forward_many(self, calls, obj_to_img, objs):
+    def forward_many(self, calls, obj_to_img, objs, residual=True):
         """Several forward calls [(objs_att, masks, z), ...] on the same object list, results identical to calling
         forward() once per entry in order: the stages that carry batch statistics (CondBN before the ConvLSTM, BN in
         the residual blocks) run per call in call order, so every normalisation layer sees the same sequence of
         batches; the ConvLSTM between them has no batch coupling and runs ONCE on the concatenated object lists
-        (k times the images per recurrence step: k times fewer launches, fuller grids, one backward)."""
+        (k times the images per recurrence step: k times fewer launches, fuller grids, one backward).
+        residual=False: stop before the residual blocks (the caller runs them per branch, possibly on separate streams)."""
         k = len(calls)
         fronts = [self.front(a, m, z, objs) for (a, m, z) in calls]
         ids = obj_to_img.detach().cpu()
@@ -195,7 +196,8 @@ class LayoutEncoder(nn.Module):
         # image ids must stay one run per image: offset every copy past the previous one's last id
         plan = SequencePlan(torch.cat([ids + i * n_img for i in range(k)]), fronts[0].device)
         h = self.clstm(F.cat_batch(fronts), None, plan=plan)
-        return [self.residual(hh) for hh in F.split_batch(h, k)]
+        hs = F.split_batch(h, k)
+        return list(hs) if not residual else [self.residual(hh) for hh in hs]
 
     def front(self, objs_att, masks, z, objs):
         v = F.concat_channels(objs_att, z)
@@ -395,6 +397,9 @@ class Generator(nn.Module):
         sh["crops_input"] = F.crop_boxes(imgs, boxes, sh["o2i_dev"], self.obj_size)
         sh["mu"], sh["logvar"] = self.crop_encoder.trunk(sh["crops_input"], objs)
         sh["objs_att"] = self.attribute_encoder(objs, attribute)
+        ev = getattr(attribute_est, "_agl_ready", None)      # produced on another stream (agl.trainer's pre-step): wait for it here
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         sh["objs_att_est"] = self.attribute_encoder(objs, attribute_est)
         return sh
 
@@ -418,6 +423,37 @@ class Generator(nn.Module):
     def part_b(self, sh):
         objs, o2i = sh["objs"], sh["obj_to_img"]
         calls = [(sh["objs_att"], sh["masks"], sh["z_rand"]), (sh["objs_att"], sh["masks_shift"], sh["z_rand"])]
+        streams = self.__dict__.get("branch_streams")
+        s = self.obj_size
+        if streams is not None and self.batch_clstm and self.training:
+            # The `rand` and `shift` branches are independent after the (batched) ConvLSTM: residual blocks, global encoder,
+            # decoder, crop and crop-encoder trunk of each run on a stream of their own (their small grids — 64 workgroups in the
+            # residual blocks — and partial last rounds overlap), and so does their backward, which autograd runs on the forward's
+            # streams.  The BatchNorm layers they share update their running statistics afterwards, rand first, then shift —
+            # the order of the sequential schedule (F.BN_DEFER).
+            hs = self.layout_encoder.forward_many(calls, o2i, objs, residual=False)
+            main = torch.cuda.current_stream()
+            deferred = []
+            arenas = self.__dict__.get("branch_grad_arenas") or [None, None]      # private gradient slots per branch (F.GRAD_ARENA)
+            for k, (st, h0, tag, boxes) in enumerate(((streams[0], hs[0], "rand", sh["boxes"]), (streams[1], hs[1], "shift", sh["boxes_shift"]))):
+                st.wait_stream(main)
+                lst, prev, prev_a = [], F.BN_DEFER, F.GRAD_ARENA
+                F.BN_DEFER, F.GRAD_ARENA = lst, arenas[k]
+                try:
+                    with torch.cuda.stream(st):
+                        h = self.layout_encoder.residual(h0)
+                        img = self.decoder(h, self.global_encoder(h))
+                        crops = F.crop_boxes(img, boxes, sh["o2i_dev"], s)
+                        mu, lv = self.crop_encoder.trunk(crops, objs)
+                finally:
+                    F.BN_DEFER, F.GRAD_ARENA = prev, prev_a
+                sh["img_" + tag], sh["crops_" + tag], sh["mu_" + tag], sh["lv_" + tag] = img, crops, mu, lv
+                deferred.append(lst)
+            for st in streams[:2]:
+                main.wait_stream(st)
+            for lst in deferred:
+                F.bn_apply_deferred(lst)
+            return sh
         if self.batch_clstm:
             h_rand, h_shift = self.layout_encoder.forward_many(calls, o2i, objs)
         else:
@@ -426,7 +462,6 @@ class Generator(nn.Module):
         g_shift = self.global_encoder(h_shift)
         sh["img_rand"] = self.decoder(h_rand, g_rand)
         sh["img_shift"] = self.decoder(h_shift, g_shift)
-        s = self.obj_size
         sh["crops_rand"] = F.crop_boxes(sh["img_rand"], sh["boxes"], sh["o2i_dev"], s)
         sh["mu_rand"], sh["lv_rand"] = self.crop_encoder.trunk(sh["crops_rand"], objs)
         sh["crops_shift"] = F.crop_boxes(sh["img_shift"], sh["boxes_shift"], sh["o2i_dev"], s)

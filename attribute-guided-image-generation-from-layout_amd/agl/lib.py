@@ -312,14 +312,22 @@ class WeightSrc:
         key = (self.tag, pass_, arith, ks, 2 if (pass_ == 1 and stride == 2) else 1)
         ver = self.version()
         hit = cache.get(key)
+        cur = torch.cuda.current_stream()
         if hit is not None and hit[0] == ver and hit[1].numel() >= nbytes:
             PACK_STATS["hits"] += 1
+            if hit[3] != cur.cuda_stream:      # packed on another stream (concurrent chains share layers): order this stream behind it
+                cur.wait_event(hit[2])
             return hit[1]
         src = make() if make is not None else (self.base if self.base is not None else w)
-        buf = hit[1] if (hit is not None and hit[1].numel() >= nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+        reuse = hit is not None and hit[1].numel() >= nbytes
+        buf = hit[1] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+        if reuse and hit[3] != cur.cuda_stream:
+            cur.wait_event(hit[2])             # (readers of the old contents on the packing stream are ordered before the overwrite)
         call("agl_conv2d_pack_weights", ptr(src.detach()), buf.data_ptr(), buf.numel(), pass_, Cin, Cout, ks, stride, CONV_FLAGS, stream())
+        ev = torch.cuda.Event()
+        ev.record(cur)
         PACK_STATS["packs"] += 1
-        cache[key] = (ver, buf)
+        cache[key] = (ver, buf, ev, cur.cuda_stream)
         return buf
 
 

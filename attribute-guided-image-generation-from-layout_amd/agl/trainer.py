@@ -91,10 +91,17 @@ class Trainer:
         # its gradient slots have one writer chain).  Every convolution launch ends in a partial round of workgroups and the
         # deep layers have small grids; concurrent chains fill those holes.  AGL_D_STREAMS=0: everything on one stream.
         self.d_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if os.environ.get("AGL_D_STREAMS", "1") != "0" else None
+        # ... and so do the generator's `rand` and `shift` branches behind the ConvLSTM (agl.generator.Generator.part_b)
+        self.g_streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if os.environ.get("AGL_G_STREAMS", "1") != "0" else None
+        if self.g_streams is not None:
+            netG.__dict__["branch_streams"] = self.g_streams
+            # the branches share their layers: each accumulates its parameter gradients into a private arena (no two streams
+            # read-modify-write one slot), folded into flat_g.g after the backward pass
+            netG.__dict__["branch_grad_arenas"] = [(self.flat_g, t) for t in self.flat_g.branch_arenas(2)]
         self._wgrad_map = None
         if self.wgrad_stream is not None:
             self._wgrad_map = {torch.cuda.current_stream(dev).cuda_stream: self.wgrad_stream}
-            for st in (self.d_streams or []):
+            for st in (self.d_streams or []) + (self.g_streams or []):
                 self._wgrad_map[st.cuda_stream] = torch.cuda.Stream(device=dev)
         self._in_step = False
         # With data parallelism step() returns while the G all-reduce + Adam still run on the side stream.  Readers of
@@ -180,7 +187,7 @@ class Trainer:
             torch.autograd.backward(heads, grads)
         finally:
             L.WGRAD_STREAMS = None
-        for st in (self.d_streams or []):                # the discriminator chains ran their backward on their own streams
+        for st in (self.d_streams or []) + (self.g_streams or []):      # the chains ran their backward on their own streams
             main.wait_stream(st)
         for st in (self._wgrad_map or {}).values():
             main.wait_stream(st)
@@ -225,11 +232,18 @@ class Trainer:
 
         # ---- pre-step attribute-estimate forward (train64.py:160-161); independent of G, so the previous
         #      iteration's G all-reduce/Adam (side stream) overlaps it
-        with torch.no_grad():
+        #      With the discriminator streams it runs on D_att's stream beside the generator's crop-encoder trunk; the generator
+        #      waits for the estimate where it first reads it (the event travels with the tensor).
+        pre = self._Chains(self.d_streams[2:3] if self.d_streams else None)
+        with torch.no_grad(), pre.on(0):
             crops_real = F.crop_boxes(b["imgs"], b["boxes"], o2i_dev, s)
             att_logits = self.netDa(crops_real)
             if self.estimate_attributes:
-                b = dict(b, attribute_est=L.attr_estimate(att_logits, b["attribute"]))
+                est = L.attr_estimate(att_logits, b["attribute"])
+                if self.d_streams:
+                    est._agl_ready = torch.cuda.Event()
+                    est._agl_ready.record(self.d_streams[2])
+                b = dict(b, attribute_est=est)
         self._wait(self._g_ready)
         self._g_ready = None
 
@@ -265,6 +279,13 @@ class Trainer:
         with ch.on(2):
             att = self.netDa(crops_input)
             term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
+        # The G step's generator evaluation (train64.py:280) reads the generator's weights and the batch only: with the discriminator
+        # chains on their own streams it is issued here, on the main stream, beside the D step's forward passes (the BatchNorm
+        # updates of the first evaluation are complete; the CPU draws are consumed in the reference's order)
+        out_g = None
+        if gen_state is not None and self.d_streams:
+            out_g = self._gen_second(gen_state, eps_g)
+            gen_state = None
         ch.join()
         self._backward(heads, grads)
         if self.on_d_backward is not None:
@@ -274,8 +295,8 @@ class Trainer:
         # ---- G step (train64.py:280-370)
         self.flat_d.set_requires_grad(False)
         try:
-            # (overlaps the D all-reduce + Adam on the side stream)
-            out = self._gen_second(gen_state, eps_g) if gen_state is not None else self._gen(b, eps_g)
+            # (without the discriminator streams: overlaps the D all-reduce + Adam on the side stream)
+            out = out_g if out_g is not None else (self._gen_second(gen_state, eps_g) if gen_state is not None else self._gen(b, eps_g))
             gen_state = None
             (crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift,
              mu, logvar, z_rand_rec, z_rand_shift) = out
@@ -307,6 +328,7 @@ class Trainer:
                     term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
             ch.join()
             self._backward(heads, grads)
+            self.flat_g.fold_branch_arenas()
             if self.on_g_backward is not None:
                 self.on_g_backward(self)
         finally:
