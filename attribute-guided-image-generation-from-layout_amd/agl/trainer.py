@@ -54,7 +54,7 @@ def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
 class Trainer:
     def __init__(self, netG, netD_image, netD_object, netD_att, pos_weight: torch.Tensor, *, lambdas: Optional[dict] = None,
                  group=None, estimate_attributes: bool = False, reuse_generator_pass: bool = True,
-                 conv_dtype: str = "f32"):
+                 conv_dtype: str = "f32", streams: bool = True):
         self.netG, self.netDi, self.netDo, self.netDa = netG, netD_image, netD_object, netD_att
         dev = next(netG.parameters()).device
         if dev.type != "cuda":
@@ -85,17 +85,23 @@ class Trainer:
         # products, AGL_CONV_SPLIT3) in the kernels that support it, exact fp32 MFMA elsewhere
         self.conv_flags = {"f32": 0, "fp32": 0, "f32x3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[conv_dtype]
         # weight gradients on their own stream beside the input-gradient chain (agl.lib.WGRAD_STREAM); AGL_WGRAD_STREAM=0: off
-        import os
-        self.wgrad_stream = torch.cuda.Stream(device=dev) if os.environ.get("AGL_WGRAD_STREAM", "1") != "0" else None
+        # `streams=False` (or the AGL_*_STREAMS=0 environment switches, for A/B runs): everything on the caller's stream, in
+        # program order — same kernels, same arithmetic; tests/test_model_gpu.py compares the two schedules.
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # (intended: see the chains below)
+        on = lambda name: streams and os.environ.get(name, "1") != "0"
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if on("AGL_WGRAD_STREAM") else None
         # The three discriminators are independent networks: their forward / backward chains run on three streams beside each
         # other (calls of ONE network stay in order on its stream, so its spectral-norm state advances exactly as before, and
         # its gradient slots have one writer chain).  Every convolution launch ends in a partial round of workgroups and the
         # deep layers have small grids; concurrent chains fill those holes.  AGL_D_STREAMS=0: everything on one stream.
-        self.d_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if os.environ.get("AGL_D_STREAMS", "1") != "0" else None
+        self.d_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if on("AGL_D_STREAMS") else None
         # ... and so do the generator's `rand` and `shift` branches behind the ConvLSTM (agl.generator.Generator.part_b)
         #     (streams 0, 1), and the reconstruction branch of the G step's evaluation (stream 2: its forward runs beside the D step,
         #     its backward — a ConvLSTM recurrence of small kernels — beside the other branches' backward)
-        self.g_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if os.environ.get("AGL_G_STREAMS", "1") != "0" else None
+        self.g_streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if on("AGL_G_STREAMS") else None
+        netG.__dict__.pop("branch_streams", None)
+        netG.__dict__.pop("branch_grad_arenas", None)
         if self.g_streams is not None:
             netG.__dict__["branch_streams"] = self.g_streams
             # the branches share their layers: each accumulates its parameter gradients into a private arena (no two streams

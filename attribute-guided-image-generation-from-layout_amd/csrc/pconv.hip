@@ -631,6 +631,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // the 128-pixel tiles, and writes one slab; the slabs are added in a fixed order (agl_launch_slab_reduce: deterministic).
 struct WArgs {
   const float* dy; const float* x; float* slabs;
+  float* direct;          // single split: the result goes (is added, when accumulate) straight to dw — no slab, no reduction launch
+  int accumulate;
   float* bias_slabs;      // optional [split][Cout]: per-channel sums of dy (the bias gradient), by the workgroups of input-channel block 0
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
   int tiles, tiles_per_split;
@@ -860,7 +862,8 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     if (tid < BMCO && co0 + tid < p.Cout) p.bias_slabs[(long)blockIdx.x * p.Cout + co0 + tid] = lbias[tid];
   }
   // ---- slab: C tile col = lane&15 (input channel), row = 4*(lane>>4) + reg (output channel)
-  float* out = p.slabs + (long)blockIdx.x * p.Cout * p.Cin * KK;
+  float* out = p.direct ? p.direct : p.slabs + (long)blockIdx.x * p.Cout * p.Cin * KK;
+  const bool acc_out = p.direct != nullptr && p.accumulate;
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
             if (tap0 + t >= KK) break;
             float v = acc[0][i][j][t][r];
             if constexpr (NSPL == 3) v += acc[1][i][j][t][r];
-            o[tap0 + t] = v;
+            o[tap0 + t] = acc_out ? o[tap0 + t] + v : v;
           }
         }
       }
@@ -1254,6 +1257,7 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   const long zcap = std::max(4L, operand_bytes / slab_bytes);
   long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
   long z = std::min((768 + blocks - 1) / blocks, zcap);       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
+  if (blocks >= 384) z = 1;      // the channel blocks alone fill the chip: one split writes dw directly (no slab pass over a large tensor)
   if (blocks * z < 256 && (*rt > 1 || *ct > 1)) {
     *rt = 1; *ct = 1;
     blocks = (long)agl_cdiv(a.Cout, 64) * (a.Cin / 16) * npass;
@@ -1288,10 +1292,12 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   int splits, tps, rt, ct, half, oh, ow; long tiles;
   if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return -1;
   const long n = (long)a.Cout * a.Cin * a.ks * a.ks;
-  if (!ws || ws_bytes < (long)splits * n * 4) return -1;
+  const bool direct = splits == 1;
+  if (!direct && (!ws || ws_bytes < (long)splits * n * 4)) return -1;
   WArgs p;
+  p.direct = direct ? a.dw : nullptr; p.accumulate = a.accumulate;
   // bias gradient alongside (a.dbias): its slabs follow the weight slabs when the workspace has room for them
-  const bool with_bias = a.dbias != nullptr && ws_bytes >= (long)splits * n * 4 + (long)splits * a.Cout * 4;
+  const bool with_bias = a.dbias != nullptr && ws && ws_bytes >= (long)splits * n * 4 + (long)splits * a.Cout * 4;
   p.bias_slabs = with_bias ? (float*)ws + (long)splits * n : nullptr;
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
@@ -1333,5 +1339,6 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     AGL_CHECK_LAUNCH(name);
     if (a.dbias_done) *a.dbias_done = 1;
   }
+  if (direct) return AGL_OK;
   return agl_launch_slab_reduce((const float*)ws, a.dw, n, splits, a.accumulate, st, name);
 }

@@ -709,6 +709,73 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
         assert bad.size == 0, (k, [(names[i], float(norms[k][i]), float(ref_norms[k][i])) for i in bad[:5]])
 
 
+def test_concurrent_schedule_equals_sequential_schedule():
+    """The training iteration with its concurrent schedule — discriminators on three streams, weight gradients on side streams,
+    the generator's rand / shift branches on two streams with private gradient arenas and deferred BatchNorm updates, the G step's
+    generator pass beside the D step — against the same iteration issued on ONE stream in program order (Trainer(streams=False)).
+    Same kernels and arithmetic; only the order in which the generator's gradient arenas are added differs.  Two iterations each
+    (the second runs on updated weights and re-packed weight caches).  Checked: the losses of both iterations (2e-5), every
+    gradient tensor of the first iteration (relative L2 <= 1e-4; the crop backward's atomicAdd is the only unordered sum), the
+    BatchNorm running statistics and spectral-norm vectors after the first iteration (1e-5; 5e-3 after the second, whose weights
+    already differ by Adam's sign flips), and every parameter to within the two
+    Adam steps' reach (|diff| <= 4 lr: an element whose gradient is rounding noise may step +-lr either way in each iteration)."""
+    from agl import synth
+    from agl.trainer import Trainer, batch_to_device, LR
+    pw = torch.from_numpy(synth.make_pos_weight())
+    bn = synth.make_batch(6, 64, seed=31)
+    O = bn["objs"].shape[0]
+    gen = torch.Generator().manual_seed(4)
+    eps = [[torch.randn(O, 64, generator=gen) for _ in range(6)] for _ in range(2)]
+    results = []
+    for streams in (True, False):
+        nets = build_nets(False)
+        tr = Trainer(*nets, pw, conv_dtype="f32x3", streams=streams)
+        assert (tr.d_streams is not None) == streams and (tr.g_streams is not None) == streams
+        grads = {}
+
+        def grab(tag, which):
+            def f(t):
+                if tag not in grads:
+                    grads[tag] = [q.grad.detach().cpu().clone() for n in which for q in n.parameters()]
+            return f
+
+        tr.on_d_backward, tr.on_g_backward = grab("D", nets[1:]), grab("G", nets[:1])
+        losses = []
+        for it in range(2):
+            tr.step(batch_to_device(bn, DEV), eps[it][:3], eps[it][3:])
+            tr.finish()
+            torch.cuda.synchronize()
+            losses.append(tr.loss_dict())
+            if it == 0:
+                first = [{k: v.detach().cpu().clone() for k, v in n.state_dict().items()} for n in nets]
+        state = [{k: v.detach().cpu().clone() for k, v in n.state_dict().items()} for n in nets]
+        names = [[k for k, _ in n.named_parameters()] for n in nets]
+        results.append((losses, state, grads, names, first))
+    (la, sa, ga, names, fa), (lb, sb, gb, _, fb) = results
+    for it in range(2):
+        for k in la[it]:
+            assert abs(la[it][k] - lb[it][k]) <= 2e-5 * max(1.0, abs(lb[it][k])), (it, k, la[it][k], lb[it][k])
+    for tag in ("D", "G"):
+        big = max(float(g.double().norm()) for g in gb[tag])
+        for i, (a, b) in enumerate(zip(ga[tag], gb[tag])):
+            nb = float(b.double().norm())
+            if nb > 1e-4 * big:
+                rel = float((a.double() - b.double()).norm()) / nb
+                assert rel <= 1e-4, (tag, i, rel)
+    for na, nb, pn in zip(sa, sb, names):
+        for k in na:
+            if not na[k].is_floating_point():
+                assert torch.equal(na[k], nb[k]), k
+            elif k in pn:
+                assert float((na[k] - nb[k]).abs().max()) <= 4.0 * LR * 1.01, (k, float((na[k] - nb[k]).abs().max()))
+            else:      # (second iteration: the weights already differ by Adam's sign flips)
+                close(na[k], nb[k], 5e-3, "buffer after two iterations " + k)
+    for na, nb, pn in zip(fa, fb, names):      # after the FIRST iteration the buffers saw identical weights: tight
+        for k in na:
+            if na[k].is_floating_point() and k not in pn:
+                close(na[k], nb[k], 1e-5, "buffer after one iteration " + k)
+
+
 def test_hinge_losses_vs_torch():
     """loss_hinge_dis / loss_hinge_gen (models/spade/networks/loss.py:65-76; off the reference's train path) against the
     torch-CPU arithmetic of GANLoss('hinge'): values and gradients <= 1e-6."""

@@ -664,7 +664,8 @@ def test_modules_vs_reference_op_fixtures(golden_dir):
 PCONV_CASES = [  # N, Cin, H, Cout, ks  (stride 1, "same" padding): the tile geometries of csrc/pconv.hip; 3x3, 5x5 and 1x1
     (4, 64, 32, 128, 3), (3, 32, 16, 64, 3), (2, 48, 64, 80, 3), (5, 64, 8, 128, 3), (7, 32, 8, 200, 3), (9, 64, 4, 128, 3),
     (17, 32, 4, 64, 3), (2, 32, 16, 128, 5), (6, 48, 8, 64, 5), (3, 16, 32, 48, 5), (9, 64, 24, 128, 3), (7, 32, 40, 64, 3),
-    (3, 64, 32, 128, 1), (5, 32, 16, 64, 1), (7, 48, 8, 200, 1), (19, 64, 4, 256, 1), (2, 16, 24, 48, 1)]
+    (3, 64, 32, 128, 1), (5, 32, 16, 64, 1), (7, 48, 8, 200, 1), (19, 64, 4, 256, 1), (2, 16, 24, 48, 1),
+    (9, 512, 4, 768, 3)]      # (last: 384 channel blocks — the weight gradient is written straight to dw by a single split)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
