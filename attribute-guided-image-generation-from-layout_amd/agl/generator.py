@@ -420,7 +420,36 @@ class Generator(nn.Module):
         return img_rec, crops_input_rec
 
     @_with_conv_stats.__func__
-    def part_b(self, sh):
+    def part_rec_nograd_beside_b(self, sh, eps0, tape_b):
+        """part_rec WITHOUT a graph (the D step's reconstruction branch, train64.py:195) evaluated beside part_b: its layout-encoder
+        front runs first on the caller's stream (the CondBN layers of the fronts update their running statistics in place, and the
+        reference's order is rec, rand, shift); its ConvLSTM, residual blocks, decoder and crop then run on the third branch stream
+        while part_b proceeds, with their BatchNorm updates deferred and applied before part_b's (rec, rand, shift again).
+        tape_b: the BatchNorm tape part_b's layers are recorded on.  Returns part_rec's outputs."""
+        streams = self.__dict__["branch_streams"]
+        main, g2 = torch.cuda.current_stream(), streams[2]
+        with torch.no_grad():
+            z_rec = self.crop_encoder.sample(sh["mu"], sh["logvar"], eps0)
+            f_rec = self.layout_encoder.front(sh["objs_att_est"], sh["masks"], z_rec, sh["objs"])
+            g2.wait_stream(main)
+            lst, prev = [], F.BN_DEFER
+            F.BN_DEFER = lst
+            try:
+                with torch.cuda.stream(g2):
+                    h = self.layout_encoder.residual(self.layout_encoder.clstm(f_rec, sh["obj_to_img"], plan=sh["plan"]))
+                    img_rec = self.decoder(h, self.global_encoder(h))
+                    crops_rec = F.crop_boxes(img_rec, sh["boxes"], sh["o2i_dev"], self.obj_size)
+            finally:
+                F.BN_DEFER = prev
+        F.BN_TAPE = tape_b
+        try:
+            self.part_b(sh, before_deferred=lambda: (main.wait_stream(g2), F.bn_apply_deferred(lst)))
+        finally:
+            F.BN_TAPE = None
+        return img_rec, crops_rec
+
+    @_with_conv_stats.__func__
+    def part_b(self, sh, before_deferred=None):
         objs, o2i = sh["objs"], sh["obj_to_img"]
         calls = [(sh["objs_att"], sh["masks"], sh["z_rand"]), (sh["objs_att"], sh["masks_shift"], sh["z_rand"])]
         streams = self.__dict__.get("branch_streams")
@@ -451,9 +480,12 @@ class Generator(nn.Module):
                 deferred.append(lst)
             for st in streams[:2]:
                 main.wait_stream(st)
+            if before_deferred is not None:
+                before_deferred()
             for lst in deferred:
                 F.bn_apply_deferred(lst)
             return sh
+        assert before_deferred is None, "part_rec_nograd_beside_b needs the concurrent schedule"
         if self.batch_clstm:
             h_rand, h_shift = self.layout_encoder.forward_many(calls, o2i, objs)
         else:

@@ -125,6 +125,27 @@ class Trainer:
         self.on_g_backward = None
 
     # ------------------------------------------------------------------ helpers
+    def serial(self):
+        """Context manager: the iterations inside run on ONE stream in program order (as Trainer(streams=False) does) — used by
+        bench.py's instrumented step, where every launch is timed alone, not beside the kernels of the other chains."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            saved = (self.wgrad_stream, self.d_streams, self.g_streams, self._wgrad_map,
+                     self.netG.__dict__.pop("branch_streams", None), self.netG.__dict__.pop("branch_grad_arenas", None))
+            self.finish()
+            torch.cuda.synchronize()
+            self.wgrad_stream = self.d_streams = self.g_streams = self._wgrad_map = None
+            try:
+                yield self
+            finally:
+                torch.cuda.synchronize()
+                self.wgrad_stream, self.d_streams, self.g_streams, self._wgrad_map, bs, ba = saved
+                if bs is not None:
+                    self.netG.__dict__["branch_streams"], self.netG.__dict__["branch_grad_arenas"] = bs, ba
+        return cm()
+
     def _slot(self, name):
         i = IDX[name]
         return self.raw[i:i + 1]
@@ -144,10 +165,14 @@ class Trainer:
                           b["masks_shift"], b["boxes_shift"], b["attribute_est"])
             F.BN_TAPE = None
             e = G.draw_eps(sh, eps)
-            with torch.no_grad():
-                rec = G.part_rec(sh, e[0])
-            F.BN_TAPE = tape_b
-            G.part_b(sh)
+            bs = G.__dict__.get("branch_streams")
+            if bs is not None and len(bs) >= 3 and G.batch_clstm and G.training and os.environ.get("AGL_G_REC_BESIDE_B", "1") != "0":
+                rec = G.part_rec_nograd_beside_b(sh, e[0], tape_b)      # the graph-less reconstruction branch beside part_b
+            else:
+                with torch.no_grad():
+                    rec = G.part_rec(sh, e[0])
+                F.BN_TAPE = tape_b
+                G.part_b(sh)
         finally:
             F.BN_TAPE = None
         with torch.no_grad():

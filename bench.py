@@ -216,10 +216,14 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         # one extra, instrumented step (outside the timed region; EVERY rank runs it, the gradient all-reduce is
         # collective): HIP events around every convolution launch (>99.9 % of the FLOPs) and every normalisation-family
         # launch (the dominant HBM-bound kernels) on the stream they are launched on; rank 0 reports.
+        # The timed steps run the discriminator / generator-branch / weight-gradient chains on several streams; here every launch
+        # is timed on its own — one stream, program order (Trainer.serial) — so that a launch's duration is the kernel's, not the
+        # kernel's share of a GPU it divides with two other chains.
         L.EVENT_LOG = [] if rank == 0 else None
         packs0 = L.PACK_STATS["packs"]
-        one_step()
-        tr.finish()
+        with tr.serial():
+            one_step()
+            tr.finish()
         fence()
         log, L.EVENT_LOG = L.EVENT_LOG, None
     if not a.no_roofline and rank == 0:
@@ -298,6 +302,9 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                                    f"and reused every step (no H2D in the timed region)",
                        "global_batch": per_gpu * world, "objects_per_rank": objs, "parallelism": f"dp{world}",
                        "generator_schedule": "two full passes" if a.two_generator_passes else "draw-independent parts evaluated once",
+                       "streams": "3 discriminator chains + 2-3 generator branches + weight-gradient side streams (one HIP stream each; "
+                                  "AGL_D_STREAMS / AGL_G_STREAMS / AGL_WGRAD_STREAM=0 for the single-stream schedule); roofline launches "
+                                  "are timed on one stream",
                        "abi_calls_per_step": round(abi_calls),
                        # host time to enqueue the K steps; the HIP queue throttles the host to the GPU's pace, so this is an upper
                        # bound of the host cost (measured un-throttled at batch 2: 60 ms per iteration, tools/host_profile.py)

@@ -29,6 +29,19 @@ def test_plain_multi_gpu_invocation_self_launches_its_ranks():
     assert out["max_rank_seconds"] >= 0.02          # MAX over ranks: rank 1 sleeps 20 ms
 
 
+def test_four_rank_rehearsal_over_gloo():
+    """the launcher path at world size 4 (rendezvous on 127.0.0.1, barrier, MAX-over-ranks timing, one JSON
+    line from rank 0) rehearsed on CPU over gloo — the closest this pipeline gets to the 4- and 8-rank runs without the node."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "dp4"
+    assert out["max_rank_seconds"] >= 0.04          # MAX over ranks: rank 3 sleeps 40 ms
+
+
 def test_single_rank_dry_run_prints_one_line():
     r = subprocess.run([sys.executable, BENCH, "--dry-run"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

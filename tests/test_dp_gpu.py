@@ -67,6 +67,24 @@ def _worker(rank, world, port, q):
     torch.cuda.synchronize()
     for k, v in tr.netG.state_dict().items():
         assert torch.equal(sd[k], v), ("state_dict taken right after step() is stale", k)
+    # the all-reduce + Adam of an arena run on the side stream; the gradients other code may read (test probes,
+    # gradient clipping a user adds) must be the LOCAL ones until that hand-off, and the main stream must not touch the weights
+    # before the event step() leaves in _g_ready / _d_ready.  Probe: the local gradient arena seen in on_g_backward (main stream,
+    # before the exchange) equals a copy taken there; after step() returns, _g_ready is set (work still pending on the side
+    # stream) and finish() makes the main stream wait for it.
+    tr, b, eps = _make(seed_offset=rank)
+    seen = {}
+    tr.on_g_backward = lambda t: seen.setdefault("g", t.flat_g.g.detach().clone())
+    p_before = tr.flat_g.p.detach().clone()
+    tr.step(b, eps[:3], eps[3:])
+    assert tr._g_ready is not None, "step() must leave the G exchange pending on the side stream"
+    tr.finish()
+    assert tr._g_ready is None
+    torch.cuda.synchronize()
+    assert float(seen["g"].abs().sum()) > 0 and not torch.equal(tr.flat_g.p, p_before)
+    summed = seen["g"].clone()
+    dist.all_reduce(summed)                    # what the side stream exchanged: SUM over ranks of the local arenas
+    assert torch.allclose(tr.flat_g.g, summed, rtol=0, atol=0), "the arena must hold exactly the all-reduced gradients after finish()"
     tr, b, eps = _make(seed_offset=rank)
     losses, pg, pd = _run(tr, b, eps)
     same = []
