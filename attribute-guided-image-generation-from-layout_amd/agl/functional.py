@@ -248,14 +248,17 @@ class _NormAct(torch.autograd.Function):
                 dp0, in_slots = s0, True
             else:
                 dp0 = torch.zeros_like(p0)
-        elif mode == 3:      # d(gamma|beta) at the map's full resolution (reduced to the class grid below when gathered)
-            dp0 = torch.empty((x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         gather = ctx.gather
+        # gathered gamma|beta on 64- / 128-wide maps: the row pass reduces d(gamma|beta) to the class grid itself
+        fused_reduce = gather is not None and mode == 3 and x.shape[-1] in (64, 128) and x.shape[-2] == x.shape[-1]
+        if mode == 3:        # d(gamma|beta): on the class grid when reduced in the kernel, else at the map's full resolution
+            dp0 = (torch.empty_like(p0) if fused_reduce else
+                   torch.empty((x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device))
         dx = L.norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, training, dp0, dp1, param_accumulate=in_slots,
-                        gb_map=gather[0] if gather is not None else None)
+                        gb_map=gather[0] if gather is not None else None, gb_lo=gather[1] if fused_reduce else None)
         if in_slots:
             dp0 = dp1 = None
-        if gather is not None:
+        if gather is not None and not fused_reduce:
             lo, h = gather[1], p0.shape[-1]
             dsrc = torch.empty_like(p0)
             L.call("agl_grid_gather_bwd", L.ptr(dp0), L.ptr(lo, torch.int32), L.ptr(lo, torch.int32), L.ptr(dsrc), dp0.shape[0] * dp0.shape[1],

@@ -45,7 +45,7 @@ SIGNATURES = {
     "agl_conv2d_fwd_stats": (_I, [_P] * 7 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
-    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _L, _P]),
+    "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
@@ -501,7 +501,8 @@ def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu, gb_map=N
     return y
 
 
-def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False, gb_map=None):
+def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False, gb_map=None,
+             gb_lo=None):
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
     dx = torch.empty_like(x)
@@ -509,7 +510,8 @@ def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=
     ws = workspace(nb, x.device)
     call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
          ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
-         p0.shape[0] if mode == 2 else 0, int(param_accumulate), ptr(gb_map, torch.int32), x.shape[-1] if gb_map is not None else 0,
+         p0.shape[0] if mode == 2 else 0, int(param_accumulate), ptr(gb_map, torch.int32), ptr(gb_lo, torch.int32),
+         x.shape[-1] if gb_map is not None else 0,
          p0.shape[-1] if gb_map is not None else 0, ws.data_ptr(), ws.numel(), stream())
     return dx
 

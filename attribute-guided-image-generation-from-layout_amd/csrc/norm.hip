@@ -242,6 +242,56 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
   }
 }
 
+// K1g (mode 3 with a gathered gamma|beta): the same row sums, and d(gamma|beta) reduced to the class grid in the same pass — a
+// (n, c) plane per workgroup of W threads (one per pixel column).  Image row by image row: every thread leaves its pixel's
+// (g*xhat, g) in LDS; the threads that own a class column add up their column range and keep running sums for the current class
+// row, flushed to the cell when the class row ends.  Every cell has one owner and a fixed order (deterministic), the activation
+// reads are coalesced, and neither the full-resolution d(gamma|beta) nor agl_grid_gather_bwd's pass over it exists.
+// lo[]: range starts of the map's inverse (src_w + 1 entries, lo[src_w] = W).
+__global__ __launch_bounds__(128) void norm_bwd_rows_gathered(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const int* __restrict__ lo, float* __restrict__ rowsum,
+                                                              float* __restrict__ dgb) {
+  __shared__ float ra[128], rb[128], red[4];
+  const int row = blockIdx.x, n = row / a.C, c = row - n * a.C, W = a.W, sw = a.src_w, tid = threadIdx.x;
+  const float mu = a.mean[c], rs = a.rstd[c];
+  const long base = (long)row * a.HW, gp = (long)sw * sw;
+  const float* gam = a.p0 + ((long)n * 2 * a.C + c) * gp;
+  float* dgam = dgb + ((long)n * 2 * a.C + c) * gp;
+  float* dbet = dgb + ((long)n * 2 * a.C + a.C + c) * gp;
+  const bool owner = tid < sw;
+  const int x0 = owner ? lo[tid] : 0, x1 = owner ? lo[tid + 1] : 0;
+  float ca = 0.f, cb = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int iy = 0; iy < W; ++iy) {
+    const long i = base + (long)iy * W + tid;
+    float g = dy[i];
+    if (a.relu && !(y[i] > 0.f)) g = 0.f;
+    const float xh = (a.x[i] - mu) * rs;
+    ra[tid] = g * xh; rb[tid] = g;
+    __syncthreads();
+    const int cy = a.map[iy];
+    const bool last = iy == W - 1 || a.map[iy + 1] != cy;      // (uniform)
+    if (owner) {
+      for (int xx = x0; xx < x1; ++xx) { ca += ra[xx]; cb += rb[xx]; }
+      if (last) {
+        const long cell = (long)cy * sw + tid;
+        dgam[cell] = ca; dbet[cell] = cb;
+        const float ge = 1.f + gam[cell];
+        s1 += ge * cb; s2 += ge * ca;
+        ca = 0.f; cb = 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  // block sums of s1, s2 (W = 64 or 128 threads)
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s1; red[(tid >> 6) * 2 + 1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    rowsum[2 * (long)row] = W > 64 ? red[0] + red[2] : red[0];
+    rowsum[2 * (long)row + 1] = W > 64 ? red[1] + red[3] : red[1];
+  }
+}
+
 // K2b (mode 2): gradient of the class table: thread (v, c) scans the objects in increasing n and adds the rows whose
 // label is v — every cell has one owner and a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void norm_bwd_table(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ dtable) {
@@ -439,8 +489,8 @@ long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2
 //          Either may be NULL to skip parameter gradients (not mode 3).
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, int W,
-                 int src_w, void* ws, long ws_bytes, void* stream) {
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                 int W, int src_w, void* ws, long ws_bytes, void* stream) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
   if (rc) return rc;
@@ -455,7 +505,12 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
   float* rowsum = (float*)ws;
   float* chansum = rowsum + (long)N * C * 2;
   hipStream_t st = (hipStream_t)stream;
-  AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
+  if (gb_lo) {      // d(gamma|beta) reduced to the class grid in the row pass
+    AGL_REQUIRE(gb_map && mode == 3 && (W == 64 || W == 128) && src_w <= W, "agl_norm_bwd: gb_lo needs mode 3, gb_map and a 64- or 128-wide map");
+    hipLaunchKernelGGL(norm_bwd_rows_gathered, dim3(N * C), dim3(W), 0, st, a, dy, y, gb_lo, rowsum, dp0);
+  } else {
+    AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
+  }
   AGL_CHECK_LAUNCH("agl_norm_bwd(rows)");
   hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 4)), dim3(256), 0, st, a, (const float*)rowsum, chansum,
                      mode == 3 ? nullptr : dp0, dp1, param_accumulate);

@@ -966,7 +966,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 }
 
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
-long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64); }
+long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
 
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   PConvPlan pl;
@@ -990,7 +990,10 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = 0; p.ow2 = 0;
   if (pl.splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, pl.splits); }
   // eight-wave workgroups (see pconv_k): the split-mode stride-1 3x3 / 5x5 kernels on tiles of >= 128 pixels
-  const bool w8 = a.w8 && a.nsplit == 3 && !s2 && (a.ks == 3 || a.ks == 5) && geo != 2 && geo != 3;
+  // (measured, tools/conv_bench.py: no change on grids that fill the chip; -8..-14 % on the small ones — ConvLSTM recurrence steps,
+  //  the decoder's 8x8 stem — where more waves per SIMD hide the staging latency nothing else covers: automatic below 512 workgroups)
+  const bool small_grid = ptiles * agl_cdiv(a.Cout, bm) * (pl.splits > 1 ? pl.splits : 1) < 512;
+  const bool w8 = (a.w8 || small_grid) && a.nsplit == 3 && !s2 && (a.ks == 3 || a.ks == 5) && geo != 2 && geo != 3;
   const int wcols = w8 ? 4 : 2;                 // wave columns = statistic rows per pixel tile
   if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 2 <= a.stats_floats) {
     p.stats = a.stats;

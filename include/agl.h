@@ -141,11 +141,13 @@ int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int
 long agl_norm_bwd_ws_bytes(int N, int C);
 /* dp0 / dp1: parameter gradients.  mode 1: dgamma[C], dbeta[C], overwritten — or added to when param_accumulate (gradient
  * accumulated in place, like autograd's AccumulateGrad); mode 2: dtable[V][2C], always added to; mode 3: dp0 = d(gb), overwritten —
- * at the FULL resolution (N, 2C, HW) also when gamma|beta are read through gb_map (reduce it with agl_grid_gather_bwd). */
+ * at the FULL resolution (N, 2C, HW) also when gamma|beta are read through gb_map (reduce it with agl_grid_gather_bwd) — unless
+ * gb_lo is given as well (the range starts of the map's inverse, src_w + 1 device ints; W = 64 or 128): then dp0 is
+ * (N, 2C, src_w, src_w), reduced to the class grid inside the row pass. */
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
-                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, int W,
-                 int src_w, void* ws, long ws_bytes, void* stream);
+                 float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                 int W, int src_w, void* ws, long ws_bytes, void* stream);
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;
