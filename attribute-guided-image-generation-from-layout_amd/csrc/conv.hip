@@ -1545,6 +1545,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
     if (pn > need) need = pn;
   }
   need = std::max(need, pconv_ws_bytes_split(Cin, Cout, ks, 3, (long)N * Cout * OH * OW));
+  if (Cout <= 4 && stride == 1 && up_log2 == 0) need = std::max(need, pconv_vert_ws_bytes(N, Cin, H, W, Cout, ks, 3));
   return need;
 }
 
@@ -1587,6 +1588,12 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
+  if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH == H && OW == W && w && co.patch && (co.prec == 1 || co.split3)) {
+    // few output channels, 7x7: vertical convolution on the matrix cores + diagonal sum (pconv.hip)
+    PVertArgs v{x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, co.prec == 1 ? 1 : 3};
+    const int vrc = pconv_vert_try(v, ws, ws_bytes, st, "agl_conv2d_fwd(vertical + diagonal)");
+    if (vrc >= 0) { g_last_pipe = v.nsplit; return vrc; }
+  }
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64 && (long)H * W * 8 < (1L << 18) && w)   // (linear layers, HW = 1, stay on the GEMM; 18-bit patch table)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
@@ -1674,6 +1681,7 @@ long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int 
   }
   if (stride == 1) need = std::max(need, pconv_ws_bytes_split(Cout, Cin, ks, 3, (long)N * Cin * IH * IW));
   if (stride == 2 && ks == 4) need = std::max(need, pconvT_ws_bytes_split(Cout, Cin, 3, (long)N * Cin * IH * IW));
+  if (Cin <= 4 && stride == 1) need = std::max(need, pconv_vert_ws_bytes(N, Cout, OH, OW, Cin, ks, 3));
   return need;
 }
 
@@ -1692,6 +1700,11 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
+  if (Cin <= 4 && stride == 1 && IH == OH && IW == OW && w && co.patch && (co.prec == 1 || co.split3)) {
+    PVertArgs v{dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu, accumulate, co.prec == 1 ? 1 : 3};
+    const int vrc = pconv_vert_try(v, ws, ws_bytes, st, "agl_conv2d_bwd_data(vertical + diagonal)");
+    if (vrc >= 0) { g_last_pipe = v.nsplit; return vrc; }
+  }
   if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18) && w)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");

@@ -40,6 +40,16 @@ long pconvT_ws_bytes(int Cred, int Crow, int nsplit);
 long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel);
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
 
+// Few channels on one side (CO <= 4), ks x ks window, stride 1, "same" size: vertical ks x 1 convolution on the matrix cores + a
+// diagonal sum (pconv.hip).  x: (N, Cred, H, W); y: (N, CO, H, W); w element (o, c, kh, kw) = w[o*w_so + c*w_sc + kh*ks + kw]
+// (flip: taps reversed — the input-gradient form).
+struct PVertArgs {
+  const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
+  int N, Cred, H, W, CO, ks, pad, w_so, w_sc, flip, relu, accumulate, nsplit;
+};
+long pconv_vert_ws_bytes(int N, int Cred, int H, int W, int CO, int ks, int nsplit);
+int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
+
 struct PBwwArgs {
   const float* dy; const float* x; float* dw;
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up)

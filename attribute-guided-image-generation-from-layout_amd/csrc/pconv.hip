@@ -129,8 +129,12 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // ABL (diagnostic builds only, results are wrong), a bit mask: 1 no MFMAs, 2 no operand conversion (one rounding, the other planes
 // are copies), 4 no LDS fragment reads inside the tap loop (tap 0's fragments for every tap), 8 no global loads after the first
 // stage, 16 no LDS stores after the first stage
-template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false, int NTH = 256, int ABL = 0>
+// VERT: a KS x 1 window (vertical taps only, no horizontal padding): the first half of the few-channel 7x7 layers (pconv_vert_try)
+template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false, int NTH = 256, int ABL = 0,
+          bool VERT = false>
 __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
+  constexpr int KSW = VERT ? 1 : KS;           // window columns
+  static_assert(!VERT || (S == 1 && !PHS && TG == KS), "vertical window");
   constexpr int NT = NTH;                      // (shadows the file-level 256)
   constexpr int WNW = NTH / 128;               // wave columns (pixel direction); 2 wave rows (channel direction)
   static_assert(!PHS || (KS == 2 && S == 1 && TG == 4), "phase mode");
@@ -139,9 +143,9 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // 4-byte stores from two workgroups (which also made every output line a partial write: 1.85x the bytes at the HBM)
   constexpr bool PAIR = PHS && TW >= 4;
   constexpr int NPW = PAIR ? 2 : 1, TGA = PAIR ? 2 * TG : TG;      // column phases per workgroup; taps staged per stage
-  constexpr int BN = TI * TH * TW, KK = KS * KS, NTG = PHS ? 1 : KK / TG, KKW = PHS ? 16 : KK;
+  constexpr int BN = TI * TH * TW, KK = KS * KSW, NTG = PHS ? 1 : KK / TG, KKW = PHS ? 16 : KK;
   static_assert((BN == 64 || BN == 128 || BN == 256) && (TG == KK || TG == KS) && (S == 1 || S == 2), "pconv geometry");
-  constexpr int KSX = PAIR ? 3 : KS;           // patch columns per output column
+  constexpr int KSX = PAIR ? 3 : KSW;          // patch columns per output column
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KSX;
   using PitchT = typename PitchSel<S, TW, KSX, NSPL>::type;
   constexpr int PWP = PitchT::PWP;             // row pitch (of a parity plane when S == 2)
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   constexpr int NZP = PHS ? (PAIR ? 2 : 4) : 1;                  // phase values carried by blockIdx.z (the reduction split index is above)
   const int zsplit = (int)blockIdx.z / NZP, zph = (int)blockIdx.z - zsplit * NZP;
   const int phase = PHS ? (PAIR ? 2 * zph : zph) : 0, ph_y = phase >> 1, ph_x = phase & 1;
-  const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? (PAIR ? 1 : 1 - ph_x) : p.pad;
+  const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? (PAIR ? 1 : 1 - ph_x) : (VERT ? 0 : p.pad);
 
   // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
   // the stage term is wave-uniform and travels in the scalar offset of the loads: no per-load vector arithmetic)
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     for (int t = 0; t < TGA; ++t) {
       int toff;                                  // LDS piece offset of tap (kh, kw)
       const int pw = PAIR ? t / TG : 0, tt = PAIR ? t % TG : t;      // (PAIR: taps 0..3 belong to column phase 0, 4..7 to phase 1)
-      if constexpr (TG == KK) toff = (tt / KS) * PWP + (S == 2 ? ((tt % KS) & 1) * PAR + ((tt % KS) >> 1) : (tt % KS)) + pw;
+      if constexpr (TG == KK) toff = (tt / KSW) * PWP + (S == 2 ? ((tt % KSW) & 1) * PAR + ((tt % KSW) >> 1) : (tt % KSW)) + pw;
       else toff = tg * PWP + (S == 2 ? (t & 1) * PAR + (t >> 1) : t);
       (void)tg;
       bf16x8 fa[NSPL][WTM], fb[NSPL][WTN];
@@ -1121,6 +1125,108 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
   const long per_plane = (long)nch * 2 * KK * mpad;
   hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
                      flip, mpad, nch, nsplit, phase4);
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
+
+// ---- few channels on one side, many on the other, ks x ks window (decoder c4 / c7: 64|128 -> 3, 7x7; the input gradients of the
+// 3-channel first layers CropEncoder.c1 / Decoder.c5) -------------------------------------------------------------------------
+// A matrix tile wants >= 32 rows; three output channels fill 3.  Decomposition: y[o][y][x] = sum_kw P[(kw,o)][y][x + kw - pad] with
+// P[(kw,o)][y][x'] = sum_{c,kh} x[c][y + kh - pad][x'] * w[o][c][kh][kw] — a ks x 1 (vertical) convolution with ks*CO <= 28 output
+// "channels" on the matrix cores (pconv_k<.., VERT>: reduction Cred*ks, one tile row of 64 channels), followed by a diagonal sum of
+// ks shifted planes (vert_diag_sum_k: P is ks*CO/Cred of the input's size).  Replaces small_cout_conv (fp32 VALU, ~27 TFLOP/s) in
+// the bf16 / split modes.
+namespace {
+// wp[plane][cc][h][kh][m][j] = term_plane(w[o*w_so + (16cc+8h+j)*w_sc + kh'*ks + kw']), m = kw*CO + o (zero rows for m >= ks*CO)
+__global__ void pack_vert_k(const float* __restrict__ w, u32x4* __restrict__ wp, int CO, int Cred, int ks, int w_so, int w_sc, int flip,
+                            int mpad, int nch, int nsplit) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_plane = (long)nch * 2 * ks * mpad;
+  if (i >= per_plane) return;
+  const int m = (int)(i % mpad);
+  long r = i / mpad;
+  const int kh = (int)(r % ks); r /= ks;
+  const int h = (int)(r & 1), cc = (int)(r >> 1);
+  const int kw = m / CO, o = m - kw * CO;
+  const int st = flip ? (ks - 1 - kh) * ks + (ks - 1 - kw) : kh * ks + kw;
+  bf16x8 t0, t1, t2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 16 * cc + 8 * h + j;
+    const float v = (m < ks * CO && c < Cred) ? w[(long)o * w_so + (long)c * w_sc + st] : 0.f;
+    if (nsplit == 1) { t0[j] = (__bf16)v; }
+    else { __bf16 a, b, d; split3(v, a, b, d); t0[j] = a; t1[j] = b; t2[j] = d; }
+  }
+  wp[i] = __builtin_bit_cast(u32x4, t0);
+  if (nsplit == 3) {
+    wp[per_plane + i] = __builtin_bit_cast(u32x4, t1);
+    wp[2 * per_plane + i] = __builtin_bit_cast(u32x4, t2);
+  }
+}
+
+// y[n][o][yy][x] = epilogue( sum_kw P[n][kw*CO + o][yy][x + kw - pad] + bias[o] ); columns outside the map contribute nothing
+__global__ void vert_diag_sum_k(const float* __restrict__ P, const float* __restrict__ bias, const float* __restrict__ pos_mask,
+                                float* __restrict__ y, long total, int CO, int HW, int W, int ks, int pad, int relu, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long plane = i / HW;                       // n*CO + o
+  const int o = (int)(plane % CO);
+  const long n = plane / CO;
+  const long pix = i - plane * HW;
+  const float* Pn = P + (n * ks * CO) * HW + pix;
+  float v = 0.f;
+  for (int kw = 0; kw < ks; ++kw) {
+    const int xs = x + kw - pad;
+    if (xs >= 0 && xs < W) v += Pn[(long)(kw * CO + o) * HW + (kw - pad)];
+  }
+  if (bias) v += bias[o];
+  if (pos_mask && !(pos_mask[i] > 0.f)) v = 0.f;
+  if (accumulate) v += y[i];
+  if (relu) v = fmaxf(v, 0.f);
+  y[i] = v;
+}
+}  // namespace
+
+static bool pconv_vert_ok(int N, int Cred, int H, int W, int CO, int ks, int nsplit) {
+  return ks == 7 && CO >= 1 && CO <= 4 && Cred % 16 == 0 && Cred >= 32 && W % 32 == 0 && H % 8 == 0 && (nsplit == 1 || nsplit == 3) &&
+         (long)N * Cred * H * W < (1L << 29);
+}
+long pconv_vert_ws_bytes(int N, int Cred, int H, int W, int CO, int ks, int nsplit) {
+  if (!pconv_vert_ok(N, Cred, H, W, CO, ks, nsplit)) return 0;
+  const long packed = (long)nsplit * (Cred / 16) * 2 * ks * 128 * 16;
+  return packed + (long)N * ks * CO * H * W * 4;
+}
+int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
+  if (!pconv_vert_ok(a.N, a.Cred, a.H, a.W, a.CO, a.ks, a.nsplit)) return -1;
+  const long need = pconv_vert_ws_bytes(a.N, a.Cred, a.H, a.W, a.CO, a.ks, a.nsplit);
+  if (!ws || ws_bytes < need) return -1;
+  const int nch = a.Cred / 16, mpad = 128, M = a.ks * a.CO;
+  const long packed = (long)a.nsplit * nch * 2 * a.ks * mpad * 16;
+  u32x4* wp = (u32x4*)ws;
+  float* P = (float*)((char*)ws + packed);
+  const long per_plane = (long)nch * 2 * a.ks * mpad;
+  hipLaunchKernelGGL(pack_vert_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, a.w, wp, a.CO, a.Cred, a.ks, a.w_so, a.w_sc,
+                     a.flip, mpad, nch, a.nsplit);
+  AGL_CHECK_LAUNCH(name);
+  PArgs p;
+  p.odiv = nullptr; p.prio = 0; p.oh2 = 0; p.ow2 = 0;
+  p.x = a.x; p.wp = wp; p.bias = nullptr; p.pos_mask = nullptr; p.y = P;
+  p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
+  p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
+  p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
+  p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * 4);
+  if (a.nsplit == 1) {
+    dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
+    hipLaunchKernelGGL((pconv_k<7, 1, 32, 8, 1, 64, 1, 7, false, false, 256, 0, true>), g, dim3(256), 0, st, p);
+  } else {
+    dim3 g((unsigned)((long)a.N * (a.H / 4) * (a.W / 32)), 1, 1);
+    hipLaunchKernelGGL((pconv_k<7, 1, 32, 4, 1, 64, 3, 7, false, false, 256, 0, true>), g, dim3(256), 0, st, p);
+  }
+  AGL_CHECK_LAUNCH(name);
+  const long total = (long)a.N * a.CO * a.H * a.W;
+  hipLaunchKernelGGL(vert_diag_sum_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)P, a.bias, a.pos_mask, a.y, total,
+                     a.CO, a.H * a.W, a.W, a.ks, a.pad, a.relu, a.accumulate);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }

@@ -992,3 +992,42 @@ def test_pconv_stride2_input_gradient_odd_sized_input(case, mode):
     close(dx[:, :, -1], ref[:, :, -1], tol, "last row")
     close(dx[:, :, :, -1], ref[:, :, :, -1], tol, "last column")
     close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", [(3, 64, 32, 32, 3), (2, 128, 64, 64, 3), (5, 48, 16, 32, 1), (2, 32, 8, 64, 4)])
+def test_few_channel_7x7_as_vertical_conv_plus_diagonal_sum(case, mode):
+    """Decoder c4 / c7 (64|128 -> 3, 7x7, generator_obj_att.py:544, generator_obj_att128.py:557) and the input gradients of the
+    3-channel first layers (CropEncoder.c1 :374, Decoder.c5): in the matrix-core modes they run as a 7x1 vertical convolution with
+    7*CO output planes on the bf16 matrix cores followed by a diagonal sum of shifted planes (csrc/pconv.hip pconv_vert_try).
+    Forward with bias / ReLU / accumulate and the input-gradient form with a ReLU mask, against torch (operands rounded to bf16 in
+    bf16 mode); in split mode also the fp64 accuracy class (<= 2x the exact fp32 kernel's error)."""
+    from agl import lib as L
+    N, C, H, W, CO = case
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    x, w, b = rn(N, C, H, W), rn(CO, C, 7, 7, seed=1) * (1.0 / (C * 49) ** 0.5), rn(CO, seed=2)
+    flags = L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    ref = TF.conv2d(r(x), r(w), b, padding=3)
+    with L.conv_flags(flags):
+        y = L.conv2d_fwd(xd, wd, bd, 1, 3)
+        assert L.load().agl_conv2d_last_pipe() == (1 if mode == "bf16" else 3), "the call must run on the matrix cores"
+        close(y, ref, 2e-5, "few-output-channel 7x7 forward")
+        close(L.conv2d_fwd(xd, wd, bd, 1, 3, relu=True), torch.relu(ref), 2e-5, "with ReLU")
+        base = rn(N, CO, H, W, seed=4)
+        close(L.conv2d_fwd(xd, wd, None, 1, 3, out=dev(base).clone(), accumulate=True), base + TF.conv2d(r(x), r(w), None, padding=3), 2e-5,
+              "accumulating")
+        # input gradient of a CO -> C layer (weights (C, CO, 7, 7)): dx has CO channels
+        w2 = rn(C, CO, 7, 7, seed=5) * (1.0 / (C * 49) ** 0.5)
+        dy = rn(N, C, H, W, seed=6)
+        xg = torch.zeros(N, CO, H, W, requires_grad=True)
+        TF.conv2d(xg, r(w2), None, padding=3).backward(r(dy))
+        mask = rn(N, CO, H, W, seed=7)
+        dx = L.conv2d_bwd_data(dev(dy), dev(w2), (H, W), 1, 3, pos_mask=dev(mask))
+        assert L.load().agl_conv2d_last_pipe() == (1 if mode == "bf16" else 3)
+        close(dx, xg.grad * (mask > 0), 5e-5, "few-input-channel 7x7 input gradient with ReLU mask")
+    if mode == "split3":
+        y64 = TF.conv2d(x.double(), w.double(), b.double(), padding=3)
+        y_exact = L.conv2d_fwd(xd, wd, bd, 1, 3)
+        e_split, e_exact = float((y.cpu().double() - y64).abs().max()), float((y_exact.cpu().double() - y64).abs().max())
+        assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
