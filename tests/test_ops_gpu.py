@@ -1031,3 +1031,28 @@ def test_few_channel_7x7_as_vertical_conv_plus_diagonal_sum(case, mode):
         y_exact = L.conv2d_fwd(xd, wd, bd, 1, 3)
         e_split, e_exact = float((y.cpu().double() - y64).abs().max()), float((y_exact.cpu().double() - y64).abs().max())
         assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
+
+
+def test_conv_batchnorm_partials_with_a_large_channel_offset():
+    """the convolution epilogue accumulates (sum, sum of squares) per lane in fp32 before the rows are added in double, and
+    the variance is E[x^2] - mean^2; for a channel with |mean| >> std the cancellation costs ~1e-7 * mean^2 / var relative to the
+    variance.  The generator's convolutions in front of a BatchNorm have no bias and near-zero means (measured mean/std <= ~1 on the
+    path), so the fused form is used there; this test pins the behaviour OUTSIDE that regime: with mean/std = 100 (a bias of 100 on
+    unit-variance outputs) the fused statistics must still agree with agl_bn_stats (double accumulation of the squares) to 1e-2 in
+    rstd and 1e-5 in the mean — and to 1e-5 / 1e-4 at mean/std = 3."""
+    from agl import lib as L
+    N, Cin, H, Cout = 8, 32, 16, 64
+    x, w = rn(N, Cin, H, H), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5)
+    for offset, tol_rstd in ((100.0, 1e-2), (3.0, 1e-4)):
+        b = torch.full((Cout,), offset)
+        with L.conv_flags(L.CONV_SPLIT3 | L.CONV_ANY_GRID):
+            y, part, rows = L.conv2d_fwd_stats(dev(x), dev(w), dev(b), 1, 1)
+        assert part is not None and rows > 0
+        cnt = y.numel() // Cout
+        m1, r1 = L.bn_stats_from_partials(part, rows, Cout, cnt, 1e-5, 0.1)
+        m2, r2 = L.bn_stats(y, 1e-5, 0.1)
+        std = float((1.0 / r2).mean())
+        assert abs(float(m2.mean()) / std) > 0.5 * offset / 1.2, "the case must have the intended mean / std ratio"
+        close(m1, m2, 1e-5, f"mean at offset {offset}")
+        rel = float(((r1 - r2).abs() / r2).max())
+        assert rel <= tol_rstd, (offset, rel)
