@@ -113,8 +113,10 @@ class ImageDiscriminator(_Discriminator):
                                   ResidualBlock(c * 8, c * 16, downsample=True))
         self.classifier = A.Linear(c * 16, 1, bias=False)
 
-    def forward(self, x):
-        W = self._weights()
+    def forward(self, x, W=None):
+        """W: the normalised weights of THIS call when the caller computed them ahead (`net._weights()`, in call order — the
+        spectral-norm state advances there); the convolutions may then run on another stream than the network's earlier calls."""
+        W = self._weights() if W is None else W
         f = self._trunk(x, W)
         return self.classifier(f, weight=_w(W, self.classifier)).view(-1)
 
@@ -130,8 +132,8 @@ class ObjectDiscriminator(_Discriminator):
         self.classifier_src = A.Linear(c * 16, 1)
         self.classifier_cls = A.Linear(c * 16, n_class)
 
-    def forward(self, x, y=None):
-        W = self._weights()
+    def forward(self, x, y=None, W=None):
+        W = self._weights() if W is None else W
         f = self._trunk(x, W)
         src = self.classifier_src(f, weight=_w(W, self.classifier_src)).view(-1)
         return src, self.classifier_cls(f, weight=_w(W, self.classifier_cls))

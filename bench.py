@@ -152,7 +152,7 @@ def cpu_baseline(max_seconds=30.0):
 def hbm_traffic(tag):
     """HBM bytes per launch of the normalisation family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     corrected as MI355X_MICROARCH.md §HBM prescribes; tools/hbm_table.py writes the file).  None if not collected."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
     try:
         with open(path) as f:
             return json.load(f).get(tag)

@@ -63,7 +63,8 @@ def main():
         print(f"{k.replace('(anonymous namespace)::', '')[:70]:70s} n={n:5d} {us:8.1f} us  fetch {fb/1e6:8.2f} MB write {wb/1e6:8.2f} MB  raw {raw:7.1f}  x2 {cor:7.1f} GB/s")
     if len(sys.argv) > 6:
         out_json, tag, iters = sys.argv[5], sys.argv[6], int(sys.argv[7])
-        fam = ("bn_stats_partial", "bn_stats_final", "bn_stats_from_rows", "norm_apply_fwd", "norm_bwd_rows", "norm_bwd_channels", "norm_bwd_apply")
+        fam = ("bn_stats_partial", "bn_stats_final", "bn_stats_single", "bn_stats_from_rows", "bn_running_update", "norm_apply_fwd", "norm_bwd_rows",
+               "norm_bwd_channels", "norm_bwd_apply", "norm_bwd_table")
         tot_b = tot_n = 0.0
         for secs, k, n, us, fb, wb, raw, cor in rows:
             if any(x in k for x in fam):
