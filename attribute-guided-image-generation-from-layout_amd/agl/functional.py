@@ -134,11 +134,12 @@ class _Conv2d(torch.autograd.Function):
                 fuse_b = want_b and bslot is not None
                 L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True,
                                                               dbias=bslot if fuse_b else None), g, x)
-            else:
-                fuse_b = want_b and bslot is None
-                if fuse_b:
+            else:      # (dw to a fresh tensor — e.g. a spectrally normalised weight; the bias may still have its arena slot)
+                fuse_b = want_b
+                if fuse_b and bslot is None:
                     db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device)
-                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, dbias=db if fuse_b else None)
+                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, dbias=(bslot if bslot is not None else db) if fuse_b else None,
+                                         dbias_accumulate=bslot is not None)
             want_b = want_b and not fuse_b
         if want_b:
             if bslot is not None:
@@ -563,10 +564,11 @@ class _Conv3x3AvgPool(torch.autograd.Function):
                 L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(dy, xb, 3, 2, 0, out=wslot, accumulate=True, dbias=bslot if fuse_b else None),
                                   dy, xb)
             else:
-                fuse_b = want_b and bslot is None
-                if fuse_b:
+                fuse_b = want_b
+                if fuse_b and bslot is None:
                     db = torch.empty(w3.shape[0], dtype=torch.float32, device=dy.device)
-                dw = L.conv2d_bwd_weight(dy, xb, 3, 2, 0, dbias=db if fuse_b else None)
+                dw = L.conv2d_bwd_weight(dy, xb, 3, 2, 0, dbias=(bslot if bslot is not None else db) if fuse_b else None,
+                                         dbias_accumulate=bslot is not None)
             want_b = want_b and not fuse_b
         if want_b:
             if bslot is not None:

@@ -32,7 +32,7 @@ SIGNATURES = {
     "agl_conv2d_pack_weights": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
     "agl_conv2d_last_pipe": (_I, []),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
-    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 14 + [_P]),
+    "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 14 + [_P]),
     "agl_conv2d_fwd_flops": (C.c_double, [_I] * 10),
     "agl_conv2d_bwd_data_flops": (C.c_double, [_I] * 11),
     "agl_conv2d_bwd_weight_flops": (C.c_double, [_I] * 13),
@@ -187,7 +187,7 @@ def work_of(name, args) -> float:
     if name == "agl_conv2d_bwd_data":
         return lib.agl_conv2d_bwd_data_flops(*args[9:19], args[21])
     if name == "agl_conv2d_bwd_weight":
-        return lib.agl_conv2d_bwd_weight_flops(*args[7:19], args[20])
+        return lib.agl_conv2d_bwd_weight_flops(*args[8:20], args[21])
     if name == "agl_bn_stats":                       # one read of x (4*N*C*HW)
         return 4.0 * args[1] * args[2] * args[3]
     if name == "agl_bn_stats_from_partials":         # the statistics read of x the fused form avoids: algorithmic bytes 0
@@ -440,9 +440,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     return out
 
 
-def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False, dbias=None):
-    """dw (+)= weight gradient.  dbias (optional, (Cout,) tensor): also (+)= the bias gradient sum_{n,oh,ow} dy — by the weight-gradient
-    kernel itself where it stages dy anyway, else by agl_channel_sum (same `accumulate` as dw)."""
+def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False, dbias=None, dbias_accumulate=None):
+    """dw (+)= weight gradient.  dbias (optional, (Cout,) tensor): also the bias gradient sum_{n,oh,ow} dy — by the weight-gradient
+    kernel itself where it stages dy anyway, else by agl_channel_sum; added in place when dbias_accumulate (default: like dw)."""
+    if dbias_accumulate is None:
+        dbias_accumulate = accumulate
     N, Cout, OH, OW = dy.shape
     _, Cin, H, W = x.shape
     if out is None:
@@ -453,11 +455,11 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
         need = max(need, Cout * Cin * ks * ks * 4)
     ws = workspace(need, dy.device) if need else None
     done = C.c_int(0)
-    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ptr(dbias), C.addressof(done) if dbias is not None else None,
+    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ptr(dbias), int(dbias_accumulate), C.addressof(done) if dbias is not None else None,
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up,
          int(in_relu), int(accumulate), CONV_FLAGS, stream())
     if dbias is not None and not done.value:
-        channel_sum(dy, out=dbias, accumulate=accumulate)
+        channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
     return out
 
 

@@ -1934,9 +1934,9 @@ static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW) {
 }
 
 // dw[Cout,Cin,ks,ks] (+)= sum_{n,oh,ow} dy * im2col(x).  ws: agl_conv2d_bwd_weight_ws_bytes() bytes (may be null if 0).
-int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int* dbias_done, void* ws, long ws_bytes, int N,
-                          int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
-                          int accumulate, int flags, void* stream) {
+int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws,
+                          long ws_bytes, int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2,
+                          int in_relu, int accumulate, int flags, void* stream) {
   AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
   AGL_REQUIRE(!dbias || dbias_done, "agl_conv2d_bwd_weight: dbias needs dbias_done");
   if (dbias_done) *dbias_done = 0;
@@ -1959,7 +1959,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
     PBwwArgs a{};
     a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
     a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = co.prec == 1 ? 1 : 3;
-    a.dbias = dbias; a.dbias_done = dbias_done;
+    a.dbias = dbias; a.dbias_accumulate = dbias_accumulate; a.dbias_done = dbias_done;
     const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
@@ -1978,7 +1978,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
       return AGL_ERR_WORKSPACE;
     }
     float* tmp = (float*)((char*)ws + inner);
-    int rc = agl_conv2d_bwd_weight(x, dy, tmp, nullptr, nullptr, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, flags, stream);
+    int rc = agl_conv2d_bwd_weight(x, dy, tmp, nullptr, 0, nullptr, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, flags, stream);
     if (rc != AGL_OK) return rc;
     const long n = (long)Cout * Cin * ks * ks;
     hipLaunchKernelGGL(flip_transpose_w, dim3(agl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dw, Cout, Cin, ks,

@@ -54,7 +54,7 @@ struct PBwwArgs {
   const float* dy; const float* x; float* dw;
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up)
   int ks, stride, pad, up, in_relu, accumulate, nsplit;
-  float* dbias; int* dbias_done;    // optional: also (+)= the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
+  float* dbias; int dbias_accumulate; int* dbias_done;    // optional: also (+= when dbias_accumulate) the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
 };
 long pbww_ws_bytes(const PBwwArgs& a);
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);

@@ -1444,7 +1444,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   AGL_CHECK_LAUNCH(name);
   if (with_bias) {
     hipLaunchKernelGGL(bias_slab_reduce, dim3(agl_cdiv(a.Cout, 256)), dim3(256), 0, st, (const float*)p.bias_slabs, a.dbias, a.Cout, splits,
-                       a.accumulate);
+                       a.dbias_accumulate);
     AGL_CHECK_LAUNCH(name);
     if (a.dbias_done) *a.dbias_done = 1;
   }

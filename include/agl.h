@@ -96,12 +96,13 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
                         const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
                         int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
-/* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] (+)= sum over (n, oh, ow) of dy — the
- * `accumulate` flag applies to it too.  The matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway;
- * *dbias_done (host int) is 1 when the call did so and 0 when the kernel that ran does not (the caller then uses agl_channel_sum). */
-int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int* dbias_done, void* ws, long ws_bytes, int N,
-                          int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2, int in_relu,
-                          int accumulate, int flags, void* stream);
+/* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] = sum over (n, oh, ow) of dy, added to dbias
+ * when dbias_accumulate (its own flag: a spectrally normalised layer returns dw fresh but accumulates db in place).  The
+ * matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway; *dbias_done (host int) is 1 when the call did so
+ * and 0 when the kernel that ran does not (the caller then uses agl_channel_sum). */
+int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws,
+                          long ws_bytes, int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2,
+                          int in_relu, int accumulate, int flags, void* stream);
 /* Executed FLOPs (2*MAC) of the launches one such call issues (dense count minus the padded taps the position-major
  * path skips) — what bench.py's roofline leg divides by the measured launch time. */
 double agl_conv2d_fwd_flops(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags);
