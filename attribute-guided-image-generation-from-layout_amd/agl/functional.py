@@ -578,7 +578,7 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         return dx, dw, db, None
 
 
-BOX_FORM = True     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
+BOX_FORM = os.environ.get("AGL_BOX_FORM", "1") != "0"     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
 BOX_BWD = os.environ.get("AGL_BOX_BWD", "0") == "1"   # input gradient through the 3x3/stride-2 phases + box transpose
 BOX_BWD_MIN = int(os.environ.get("AGL_BOX_BWD_MIN", "16"))   # ... used from this map size up (measured: 0.24 vs 0.34 ms at
                                                              # 32x32 and 16x16, but 0.48 vs 0.30 ms at 8x8)
