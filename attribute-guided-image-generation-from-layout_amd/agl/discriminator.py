@@ -10,6 +10,8 @@ batched spectral-norm kernel sequence per forward call.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -32,6 +34,17 @@ def _w(W, mod):
     return None if W is None else W.get(id(mod))
 
 
+def _fork(x, c1, w1, in_relu):
+    """First convolution of a down-sampling block and the pooled shortcut input, from the block input x."""
+    w = c1.weight if w1 is None else w1
+    if FORK:
+        return F.conv2d_and_avg_pool2(x, w, c1.bias, c1.padding[0], in_relu=in_relu, relu=True, relu_grad_by_consumer=True)
+    return c1(x, in_relu=in_relu, relu=True, relu_grad_by_consumer=True, weight=w1), F.avg_pool2(x, in_relu=in_relu)
+
+
+FORK = os.environ.get("AGL_D_FORK", "1") != "0"      # A/B switch: 0 = two graph nodes, autograd adds their input gradients
+
+
 class OptimizedBlock(nn.Module):
     def __init__(self, dim_in, dim_out, downsample=False):
         super().__init__()
@@ -45,15 +58,16 @@ class OptimizedBlock(nn.Module):
 
     def forward(self, x, W=None):
         # h feeds exactly one convolution, which masks its input gradient by h > 0 (no separate ReLU-backward pass)
-        h = self.resi[0](x, relu=True, relu_grad_by_consumer=True, weight=_w(W, self.resi[0]))
-        c2 = self.resi[2]
-        w2 = _w(W, c2)
-        s = x
+        c1, c2 = self.resi[0], self.resi[2]
+        w1, w2 = _w(W, c1), _w(W, c2)
         if self.downsample:            # conv3x3 + avg-pool == one 4x4 stride-2 conv (2.25x fewer MACs)
+            # (x feeds the first convolution and the pooled shortcut: one graph node, its input gradient is accumulated in place)
+            h, s = _fork(x, c1, w1, False)
             h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias, x_relu=True)
-            s = F.avg_pool2(x)
         else:
+            h = c1(x, relu=True, relu_grad_by_consumer=True, weight=w1)
             h = c2(h, x_relu=True, weight=w2)
+            s = x
         return self.sc(s, addend=h, weight=_w(W, self.sc))
 
 
@@ -72,12 +86,13 @@ class ResidualBlock(nn.Module):
     def forward(self, x, W=None):
         if not self.learnable_sc:
             raise NotImplementedError("identity-shortcut blocks are not on the reference path")
-        h = self.resi[1](x, in_relu=True, relu=True, relu_grad_by_consumer=True, weight=_w(W, self.resi[1]))
-        c2 = self.resi[3]
-        w2 = _w(W, c2)
+        c1, c2 = self.resi[1], self.resi[3]
+        w1, w2 = _w(W, c1), _w(W, c2)
         if self.downsample:
+            h, s = _fork(x, c1, w1, True)
             h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias, x_relu=True)
-            return self.sc(F.avg_pool2(x, in_relu=True), addend=h, weight=_w(W, self.sc))
+            return self.sc(s, addend=h, weight=_w(W, self.sc))
+        h = c1(x, in_relu=True, relu=True, relu_grad_by_consumer=True, weight=w1)
         h = c2(h, x_relu=True, weight=w2)
         return self.sc(x, in_relu=True, addend=h, weight=_w(W, self.sc))
 

@@ -84,6 +84,34 @@ def _take_stats(x):
 
 
 # --------------------------------------------------------------------------- convolution
+def _conv_param_grads(slots, want_w, want_b, g, x, w, stride, pad, up, in_relu):
+    """Weight and bias gradient of a convolution (shared by _Conv2d and _ConvPoolFork): into the arena slots of the parameters
+    when they have them (returns None for those), on the chain's weight-gradient stream."""
+    wslot, bslot = slots
+    ks = w.shape[2]
+    dw = db = None
+    if want_w:
+        # the bias gradient rides on the weight-gradient kernel (it stages dy anyway) when both go the same way
+        # (both into their arena slots, or both into fresh tensors)
+        if wslot is not None:
+            fuse_b = want_b and bslot is not None
+            L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True,
+                                                          dbias=bslot if fuse_b else None), g, x)
+        else:      # (dw to a fresh tensor — e.g. a spectrally normalised weight; the bias may still have its arena slot)
+            fuse_b = want_b
+            if fuse_b and bslot is None:
+                db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device)
+            dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, dbias=(bslot if bslot is not None else db) if fuse_b else None,
+                                     dbias_accumulate=bslot is not None)
+        want_b = want_b and not fuse_b
+    if want_b:
+        if bslot is not None:
+            L.channel_sum(g, out=bslot, accumulate=True)
+        else:
+            db = L.channel_sum(g)
+    return dw, db
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, addend, stride, pad, up, in_relu, relu, relu_grad_by_consumer, x_relu):
@@ -125,27 +153,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dx = L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), stride, pad, pos_mask=x if (in_relu or x_relu) else None,
                                        wsrc=ctx.wsrc)
-        wslot, bslot = ctx.slots
-        want_b = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            # the bias gradient rides on the weight-gradient kernel (it stages dy anyway) when both go the same way
-            # (both into their arena slots, or both into fresh tensors)
-            if wslot is not None:
-                fuse_b = want_b and bslot is not None
-                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, out=wslot, accumulate=True,
-                                                              dbias=bslot if fuse_b else None), g, x)
-            else:      # (dw to a fresh tensor — e.g. a spectrally normalised weight; the bias may still have its arena slot)
-                fuse_b = want_b
-                if fuse_b and bslot is None:
-                    db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device)
-                dw = L.conv2d_bwd_weight(g, x, ks, stride, pad, up, in_relu, dbias=(bslot if bslot is not None else db) if fuse_b else None,
-                                         dbias_accumulate=bslot is not None)
-            want_b = want_b and not fuse_b
-        if want_b:
-            if bslot is not None:
-                L.channel_sum(g, out=bslot, accumulate=True)
-            else:
-                db = L.channel_sum(g)
+        dw, db = _conv_param_grads(ctx.slots, ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2], g, x, w, stride, pad, up, in_relu)
         dadd = dy if (has_add and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dadd, None, None, None, None, None, None, None
 
@@ -160,6 +168,46 @@ def conv2d(x, w, bias=None, stride=1, padding=0, up=0, in_relu=False, relu=False
     the gradient it returns by x > 0 in its input-gradient epilogue."""
     assert not (x_relu and up), "x_relu with folded up-sampling is not supported"
     return _Conv2d.apply(x, w, bias, addend, stride, padding, up, in_relu, relu, relu_grad_by_consumer, x_relu)
+
+
+class _ConvPoolFork(torch.autograd.Function):
+    """The two consumers of a down-sampling residual block's input (reference discriminator.py:46-60, 84-99) as ONE graph node:
+    y = conv(x) (3x3, stride 1, optional fused input / output ReLU) and s = avg_pool2d(x, 2) (of relu(x) with in_relu: the block's
+    in-place ReLU aliases the shortcut's input).  Same kernels as conv2d + avg_pool2 forward; backward: the pooled gradient is
+    written to dx and the convolution's input-gradient epilogue accumulates onto it — autograd's separate add of two x-sized
+    tensors (3 passes over them) disappears."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, pad, in_relu, relu, relu_grad_by_consumer):
+        global _LAST_STATS
+        _LAST_STATS = None
+        ctx.slots = (_slot(w), _slot(bias))
+        ctx.wsrc = wsrc = getattr(w, "_agl_wsrc", None)
+        x, w = _c(x), _c(w)
+        y = L.conv2d_fwd(x, w, bias, 1, pad, 0, in_relu, relu, wsrc=wsrc)
+        s = L.avgpool2_fwd(x, in_relu)
+        ctx.cfg = (pad, in_relu, relu, bias is not None, relu_grad_by_consumer)
+        ctx.save_for_backward(x, w, y if (relu and not relu_grad_by_consumer) else None)
+        return y, s
+
+    @staticmethod
+    def backward(ctx, dy, ds):
+        pad, in_relu, relu, has_bias, by_consumer = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        g = L.relu_bwd(dy, y) if (relu and not by_consumer) else dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = L.avgpool2_bwd(_c(ds), x if in_relu else tuple(x.shape), in_relu)
+            L.conv2d_bwd_data(g, w, (x.shape[2], x.shape[3]), 1, pad, pos_mask=x if in_relu else None, out=dx, accumulate=True,
+                              wsrc=ctx.wsrc)
+        dw, db = _conv_param_grads(ctx.slots, ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2], g, x, w, 1, pad, 0, in_relu)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d_and_avg_pool2(x, w, bias=None, padding=1, in_relu=False, relu=False, relu_grad_by_consumer=False):
+    """(conv2d(x, w, bias, stride 1, padding), avg_pool2(x)) — see _ConvPoolFork."""
+    return _ConvPoolFork.apply(x, w, bias, padding, in_relu, relu, relu_grad_by_consumer)
 
 
 def linear(x, w, bias=None, relu=False):

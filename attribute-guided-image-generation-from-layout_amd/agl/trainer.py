@@ -123,6 +123,7 @@ class Trainer:
         self._g_ready = None
         self.on_d_backward = None        # optional test probes, called after backward and before Adam
         self.on_g_backward = None
+        self.marks = None                # tools/phase_times.py: a list collects (label, event) pairs along the iteration
 
     # ------------------------------------------------------------------ helpers
     def serial(self):
@@ -149,6 +150,12 @@ class Trainer:
     def _slot(self, name):
         i = IDX[name]
         return self.raw[i:i + 1]
+
+    def _mark(self, label, stream=None):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.marks.append((label, ev))
 
     def _gen(self, b, eps):
         return self.netG(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],
@@ -268,6 +275,7 @@ class Trainer:
         #      iteration's G all-reduce/Adam (side stream) overlaps it
         #      With the discriminator streams it runs on D_att's stream beside the generator's crop-encoder trunk; the generator
         #      waits for the estimate where it first reads it (the event travels with the tensor).
+        self._mark("start")
         pre = self._Chains(self.d_streams[2:3] if self.d_streams else None)
         with torch.no_grad(), pre.on(0):
             crops_real = F.crop_boxes(b["imgs"], b["boxes"], o2i_dev, s)
@@ -278,6 +286,7 @@ class Trainer:
                     est._agl_ready = torch.cuda.Event()
                     est._agl_ready.record(self.d_streams[2])
                 b = dict(b, attribute_est=est)
+            self._mark("pre-step estimate done (its stream)")
         self._wait(self._g_ready)
         self._g_ready = None
 
@@ -289,6 +298,7 @@ class Trainer:
             with torch.no_grad():
                 out = self._gen(b, eps_d)
         crops_input, crops_rec, crops_rand, crops_shift, img_rec, img_rand, img_shift = out[:7]
+        self._mark("generator pass 1 done")
         self.flat_d.zero_grad()
         heads, grads = [], []
 
@@ -303,6 +313,7 @@ class Trainer:
                 term(lg, LS.bce_const(lg, 0.0, lam["img_adv"] * w, self._slot(name)))
             lg = self.netDi(b["imgs"])
             term(lg, LS.bce_const(lg, 1.0, lam["img_adv"], self._slot("d_img_real")))
+            self._mark("D step: D_img forward done (its stream)")
         with ch.on(1):
             for name, x, w in (("d_obj_rec", crops_rec, MIX[0]), ("d_obj_rand", crops_rand, MIX[1]), ("d_obj_shift", crops_shift, MIX[2])):
                 src, _ = self.netDo(x, objs)
@@ -310,9 +321,11 @@ class Trainer:
             src, cls = self.netDo(crops_input, objs)
             term(src, LS.bce_const(src, 1.0, lam["obj_adv"], self._slot("d_obj_real")))
             term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
+            self._mark("D step: D_obj forward done (its stream)")
         with ch.on(2):
             att = self.netDa(crops_input)
             term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
+            self._mark("D step: D_att forward done (its stream)")
         # The G step's generator evaluation (train64.py:280) reads the generator's weights and the batch only: with the discriminator
         # chains on their own streams it is issued here, on the main stream, beside the D step's forward passes (the BatchNorm
         # updates of the first evaluation are complete; the CPU draws are consumed in the reference's order)
@@ -332,11 +345,15 @@ class Trainer:
             else:
                 out_g = self._gen_second(gen_state, eps_g)
             gen_state = None
+            self._mark("generator pass 2 done (main stream)")
         ch.join()
+        self._mark("D step: forward joined")
         self._backward(heads, grads)
+        self._mark("D step: backward joined")
         if self.on_d_backward is not None:
             self.on_d_backward(self)
         self._d_ready = self._reduce_and_step(self.flat_d)
+        self._mark("D step: Adam done")
 
         # ---- G step (train64.py:280-370)
         self.flat_d.set_requires_grad(False)
@@ -365,23 +382,29 @@ class Trainer:
                 for tag, x, w in (("rec", img_rec, MIX[0]), ("rand", img_rand, MIX[1]), ("shift", img_shift, MIX[2])):
                     lg = self.netDi(x)
                     term(lg, LS.bce_const(lg, 1.0, lam["img_adv"] * w, self._slot("g_img_adv_" + tag)))
+                self._mark("G step: D_img forward done (its stream)")
             with ch.on(1):
                 for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
                     src, cls = self.netDo(x, objs)
                     term(src, LS.bce_const(src, 1.0, lam["obj_adv"] * w, self._slot("g_obj_adv_" + tag)))
                     term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
+                self._mark("G step: D_obj forward done (its stream)")
             with ch.on(2):
                 for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
                     att = self.netDa(x)
                     term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))
+                self._mark("G step: D_att forward done (its stream)")
             ch.join()
+            self._mark("G step: forward joined")
             self._backward(heads, grads)
+            self._mark("G step: backward joined")
             self.flat_g.fold_branch_arenas()
             if self.on_g_backward is not None:
                 self.on_g_backward(self)
         finally:
             self.flat_d.set_requires_grad(True)
         self._g_ready = self._reduce_and_step(self.flat_g)
+        self._mark("G step: Adam done")
         self.last_outputs = out
         return self.raw
 

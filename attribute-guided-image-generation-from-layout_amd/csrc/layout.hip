@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void l1_pixels_k(const float* __restrict__ WB,
   }
 }
 
-// GB[o,co,t] = sum_p dy[o,co,p] I_t(p), GD[o,co,t] = sum_p dy[o,co,p] m_t(p).  Block: one object x 32 output channels.
-// The tap bits of every output pixel are computed once per block into LDS (the mask is read once per 32 channels, not
+// GB[o,co,t] = sum_p dy[o,co,p] I_t(p), GD[o,co,t] = sum_p dy[o,co,p] m_t(p).  Block: one object x 8 output channels.
+// The tap bits of every output pixel are computed once per block into LDS (the mask is read once per 8 channels, not
 // once per channel); wave g then owns channels g, g+4, ... and reduces its 32 tap sums with shuffles (fixed order).
-constexpr int TAPSUM_CH = 32;
+constexpr int TAPSUM_CH = 8;
 __global__ __launch_bounds__(256) void l1_tapsum_k(const float* __restrict__ dy, const float* __restrict__ mask, float* __restrict__ GB,
                                                    float* __restrict__ GD, int O, int Co, int R, int OH) {
   extern __shared__ unsigned l1_bits[];       // [OH*OH]: in_img | in_mask << 16

@@ -37,6 +37,7 @@ struct PArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu, relu, accumulate;
   int nch, mpad;
   unsigned x_bytes;
+  int xgy, xchunk, xitems;   // XCD-aware workgroup order (xchunk > 0): the grid is 1-D, see pconv_k
   float* stats;      // optional: per-channel (sum, sum of squares) of the stored outputs, one row per (pixel tile, wave column)
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
   int cps;           // (each slab is shaped like y; splitk_epilogue of conv.hip adds them and applies the epilogue)
@@ -177,16 +178,27 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave / WNW, wn = wave % WNW;
   const int Hl = p.H << p.up, Wl = p.W << p.up;
+  // Workgroup -> (pixel tile bx, channel tile by).  Workgroups are dealt round-robin over the 8 XCDs (linear ids L and L + 8 share an
+  // XCD and its L2).  With the plain grid, vertically adjacent pixel tiles (which share two of their ten patch rows) and the channel
+  // tiles of one pixel tile (which read the same patch) land on different XCDs, and every one of them fetches the shared rows from
+  // memory again.  XCD-aware order (p.xchunk > 0, 1-D grid of 8 * xchunk): XCD k takes the contiguous run of items
+  // [k * xchunk, (k + 1) * xchunk), item = pixel tile * gy + channel tile — neighbours in space are neighbours in time on one L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.xchunk > 0) {
+    const int item = (int)(blockIdx.x & 7) * p.xchunk + (int)(blockIdx.x >> 3);
+    if (item >= p.xitems) return;
+    bx = item / p.xgy; by = item - bx * p.xgy;
+  }
   int img0, ty0, tx0;
   if constexpr (TI == 1) {
     const int tpr = p.OW / TW, tpi = (p.OH / TH) * tpr;
-    img0 = blockIdx.x / tpi;
-    const int t = blockIdx.x - img0 * tpi;
+    img0 = bx / tpi;
+    const int t = bx - img0 * tpi;
     ty0 = (t / tpr) * TH; tx0 = (t % tpr) * TW;
   } else {
-    img0 = blockIdx.x * TI; ty0 = 0; tx0 = 0;
+    img0 = bx * TI; ty0 = 0; tx0 = 0;
   }
-  const int bm0 = blockIdx.y * BM;
+  const int bm0 = by * BM;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   constexpr int NZP = PHS ? (PAIR ? 2 : 4) : 1;                  // phase values carried by blockIdx.z (the reduction split index is above)
   const int zsplit = (int)blockIdx.z / NZP, zph = (int)blockIdx.z - zsplit * NZP;
@@ -539,7 +551,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   }
   if constexpr (!PHS) {
     if (p.stats) {      // the 8 lanes of a channel row hold its pixels: butterfly within the octet, lane 0 of it writes the partial
-      float* const row = p.stats + ((long)blockIdx.x * WNW + wn) * p.Cout * 2;
+      float* const row = p.stats + ((long)bx * WNW + wn) * p.Cout * 2;
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -641,6 +653,7 @@ struct WArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
   int tiles, tiles_per_split;
   unsigned x_bytes, dy_bytes;
+  int xgyz, xchunk, xitems, xgy;      // XCD-aware workgroup order (xchunk > 0): 1-D grid, see pbww_k
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -666,11 +679,24 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   __shared__ float lbias[BMCO];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int pass = NPASS == 1 ? 0 : (int)blockIdx.y % NPASS, tap0 = pass * TSUB;
-  const bool do_bias = p.bias_slabs != nullptr && blockIdx.y == 0;
+  // Workgroup -> (pixel split bx, input-channel block by, output-channel block bz).  The workgroups of one pixel split read the
+  // same dy tiles (every by) and the same x patches (every bz), in the same order; dealt round-robin over the 8 XCDs by their linear
+  // id they sit on different L2s and each fetches them from memory (measured: 2.8x the operand bytes).  XCD-aware order
+  // (p.xchunk > 0, 1-D grid of 8 * xchunk): XCD k takes the items [k * xchunk, (k + 1) * xchunk), item = (bx * gz + bz) * gy + by —
+  // the channel blocks of one split run side by side on one L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xchunk > 0) {
+    const int item = (int)(blockIdx.x & 7) * p.xchunk + (int)(blockIdx.x >> 3);
+    if (item >= p.xitems) return;
+    bx = item / p.xgyz;
+    const int r = item - bx * p.xgyz;
+    bz = r / p.xgy; by = r - bz * p.xgy;
+  }
+  const int pass = NPASS == 1 ? 0 : by % NPASS, tap0 = pass * TSUB;
+  const bool do_bias = p.bias_slabs != nullptr && by == 0;
   if (do_bias && tid < BMCO) lbias[tid] = 0.f;      // (ordered before the first update by the barrier at the top of the tile loop)
-  const int c0 = ((int)blockIdx.y / NPASS) * BC, co0 = blockIdx.z * BMCO;
-  const int t_beg = blockIdx.x * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
+  const int c0 = (by / NPASS) * BC, co0 = bz * BMCO;
+  const int t_beg = bx * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
   const int Hl = p.H << p.up, Wl = p.W << p.up;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
@@ -863,10 +889,10 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
 
   if (do_bias) {
     __syncthreads();
-    if (tid < BMCO && co0 + tid < p.Cout) p.bias_slabs[(long)blockIdx.x * p.Cout + co0 + tid] = lbias[tid];
+    if (tid < BMCO && co0 + tid < p.Cout) p.bias_slabs[(long)bx * p.Cout + co0 + tid] = lbias[tid];
   }
   // ---- slab: C tile col = lane&15 (input channel), row = 4*(lane>>4) + reg (output channel)
-  float* out = p.direct ? p.direct : p.slabs + (long)blockIdx.x * p.Cout * p.Cin * KK;
+  float* out = p.direct ? p.direct : p.slabs + (long)bx * p.Cout * p.Cin * KK;
   const bool acc_out = p.direct != nullptr && p.accumulate;
 #pragma unroll
   for (int i = 0; i < RT; ++i)
@@ -972,6 +998,18 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
 long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
 
+#ifndef AGL_PCONV_XCD
+#define AGL_PCONV_XCD 1
+#endif
+// XCD-aware workgroup order of pconv_k (see there): (gx, gy, gz) -> (8 * ceil(gx * gy / 8), 1, gz) once the grid spans the XCDs
+static void pconv_xcd_order(PArgs& p, dim3& g) {
+  p.xgy = 1; p.xchunk = 0; p.xitems = 0;
+  const long items = (long)g.x * g.y;
+  if (!AGL_PCONV_XCD || items < 64 || items > (1L << 28)) return;
+  p.xgy = (int)g.y; p.xitems = (int)items; p.xchunk = (int)((items + 7) / 8);
+  g.x = 8u * (unsigned)p.xchunk; g.y = 1;
+}
+
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   PConvPlan pl;
   if (pconv_plan(a, pl) != 0) return -1;
@@ -1005,6 +1043,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
+  pconv_xcd_order(p, g);
   if (!a.packed) {
     const int prc = pconv_pack(a.w, wp, a.Cout, a.Cin, a.ks, a.w_sm, a.w_sc, a.flip, a.nsplit, 0, st, name);
     if (prc != AGL_OK) return prc;
@@ -1218,9 +1257,11 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * 4);
   if (a.nsplit == 1) {
     dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
+    pconv_xcd_order(p, g);
     hipLaunchKernelGGL((pconv_k<7, 1, 32, 8, 1, 64, 1, 7, false, false, 256, 0, true>), g, dim3(256), 0, st, p);
   } else {
     dim3 g((unsigned)((long)a.N * (a.H / 4) * (a.W / 32)), 1, 1);
+    pconv_xcd_order(p, g);
     hipLaunchKernelGGL((pconv_k<7, 1, 32, 4, 1, 64, 3, 7, false, false, 256, 0, true>), g, dim3(256), 0, st, p);
   }
   AGL_CHECK_LAUNCH(name);
@@ -1294,6 +1335,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
+  pconv_xcd_order(p, g);
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
 #define PT_GEO(BM_, NS_)                                          \
   do {                                                            \
@@ -1414,6 +1456,12 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
+  p.xgyz = 1; p.xchunk = 0; p.xitems = 0; p.xgy = 1;
+  if (AGL_PCONV_XCD && (long)g.x * g.y * g.z >= 64 && g.y * g.z > 1) {
+    const long items = (long)g.x * g.y * g.z;
+    p.xgy = (int)g.y; p.xgyz = (int)(g.y * g.z); p.xitems = (int)items; p.xchunk = (int)((items + 7) / 8);
+    g = dim3(8u * (unsigned)p.xchunk, 1, 1);
+  }
 #define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
     if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);           \

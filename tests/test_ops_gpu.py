@@ -467,6 +467,39 @@ def test_conv3x3_avgpool_box_form(shape):
     close(outs[0], outs[1], 2e-5, "box form vs pooled-filter form")
 
 
+@pytest.mark.parametrize("mode", ["f32", "split3", "bf16"])
+@pytest.mark.parametrize("case", [(3, 64, 32, 64, True), (2, 3, 16, 32, False), (5, 128, 8, 128, True), (2, 48, 64, 80, True), (70, 64, 4, 64, True)])
+def test_conv_and_pool_fork_of_a_block_input(case, mode):
+    """x -> (conv3x3(x), avg_pool2(x)) as one graph node (agl.functional.conv2d_and_avg_pool2: the input of the discriminators'
+    down-sampling blocks): values and every gradient equal the two separate functions' — the same kernels run, the input gradient
+    is accumulated in the convolution's epilogue instead of by a separate addition, the same two fp32 terms either way."""
+    from agl import functional as F, lib as L
+    N, C, H, Co, in_relu = case
+    flags = {"f32": 0, "split3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[mode]
+    x, w, b = rn(N, C, H, H), rn(Co, C, 3, 3, seed=1) * (1.0 / (C * 9) ** 0.5), rn(Co, seed=2)
+    gy, gs = rn(N, Co, H, H, seed=3), rn(N, C, H // 2, H // 2, seed=4)
+    res = []
+    with L.conv_flags(flags):
+        for fork in (True, False):
+            xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+            if fork:
+                y, s = F.conv2d_and_avg_pool2(xg, wg, bg, 1, in_relu=in_relu, relu=True, relu_grad_by_consumer=False)
+            else:
+                y = F.conv2d(xg, wg, bg, 1, 1, in_relu=in_relu, relu=True)
+                s = F.avg_pool2(xg, in_relu=in_relu)
+            torch.autograd.backward([y, s], [dev(gy), dev(gs)])
+            res.append((y.detach(), s.detach(), xg.grad, wg.grad, bg.grad))
+    for a_, b_, what in zip(res[0], res[1], ("y", "s", "dx", "dw", "db")):
+        assert torch.equal(a_, b_), f"{what} differs from the separate functions ({mode})"
+    if mode == "f32":
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        xin = torch.relu(xr) if in_relu else xr
+        yr, sr = torch.relu(TF.conv2d(xin, wr, br, padding=1)), TF.avg_pool2d(xin, 2)
+        torch.autograd.backward([yr, sr], [gy, gs])
+        close(res[0][0], yr, 3e-5, "y")
+        close(res[0][2], xr.grad, 1e-4, "dx")
+
+
 @pytest.mark.parametrize("case", [(4, 64, 32, 128, 4, 1), (5, 32, 16, 64, 4, 1), (9, 16, 8, 96, 4, 1), (4, 64, 33, 128, 3, 0), (6, 32, 17, 64, 3, 0),
                                   (10, 24, 9, 72, 3, 0), (2, 128, 64, 64, 4, 1)])
 def test_patch_conv_stride2_forward(case):
