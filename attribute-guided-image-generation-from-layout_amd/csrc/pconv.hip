@@ -183,10 +183,15 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // tiles of one pixel tile (which read the same patch) land on different XCDs, and every one of them fetches the shared rows from
   // memory again.  XCD-aware order (p.xchunk > 0, 1-D grid of 8 * xchunk): XCD k takes the contiguous run of items
   // [k * xchunk, (k + 1) * xchunk), item = pixel tile * gy + channel tile — neighbours in space are neighbours in time on one L2.
+  // Phase kernels: the two / four phases of a pixel tile read the same dy patch and join the item index (fastest), the
+  // reduction split stays in blockIdx.z.
+  constexpr int NZP = PHS ? (PAIR ? 2 : 4) : 1;                  // phase values carried by blockIdx.z (the reduction split index is above)
   int bx = blockIdx.x, by = blockIdx.y;
+  int zsplit = (int)blockIdx.z / NZP, zph = (int)blockIdx.z - zsplit * NZP;
   if (p.xchunk > 0) {
-    const int item = (int)(blockIdx.x & 7) * p.xchunk + (int)(blockIdx.x >> 3);
+    int item = (int)(blockIdx.x & 7) * p.xchunk + (int)(blockIdx.x >> 3);
     if (item >= p.xitems) return;
+    if constexpr (NZP > 1) { zsplit = blockIdx.z; zph = item % NZP; item /= NZP; }
     bx = item / p.xgy; by = item - bx * p.xgy;
   }
   int img0, ty0, tx0;
@@ -200,8 +205,6 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   }
   const int bm0 = by * BM;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  constexpr int NZP = PHS ? (PAIR ? 2 : 4) : 1;                  // phase values carried by blockIdx.z (the reduction split index is above)
-  const int zsplit = (int)blockIdx.z / NZP, zph = (int)blockIdx.z - zsplit * NZP;
   const int phase = PHS ? (PAIR ? 2 * zph : zph) : 0, ph_y = phase >> 1, ph_x = phase & 1;
   const int pad_y = PHS ? 1 - ph_y : p.pad, pad_x = PHS ? (PAIR ? 1 : 1 - ph_x) : (VERT ? 0 : p.pad);
 
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   float pb[BR][8];
   u32x4 pa[AR];
   auto gload_b = [&](int c0) {
-    if ((ABL & 8) && c0 != 16 * (p.slabs ? (int)(blockIdx.z / (PHS ? (PAIR ? 2 : 4) : 1)) * p.cps : 0)) return;
+    if ((ABL & 8) && c0 != 16 * (p.slabs ? zsplit * p.cps : 0)) return;
 #pragma unroll
     for (int r = 0; r < BR; ++r)
 #pragma unroll
@@ -1001,13 +1004,16 @@ long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * O
 #ifndef AGL_PCONV_XCD
 #define AGL_PCONV_XCD 1
 #endif
+#ifndef AGL_PBWW_ROWS32
+#define AGL_PBWW_ROWS32 1
+#endif
 // XCD-aware workgroup order of pconv_k (see there): (gx, gy, gz) -> (8 * ceil(gx * gy / 8), 1, gz) once the grid spans the XCDs
-static void pconv_xcd_order(PArgs& p, dim3& g) {
+static void pconv_xcd_order(PArgs& p, dim3& g, int nzp = 1) {      // nzp: phases per pixel tile in g.z (phase kernels), else 1
   p.xgy = 1; p.xchunk = 0; p.xitems = 0;
-  const long items = (long)g.x * g.y;
+  const long items = (long)g.x * g.y * nzp;
   if (!AGL_PCONV_XCD || items < 64 || items > (1L << 28)) return;
   p.xgy = (int)g.y; p.xitems = (int)items; p.xchunk = (int)((items + 7) / 8);
-  g.x = 8u * (unsigned)p.xchunk; g.y = 1;
+  g.x = 8u * (unsigned)p.xchunk; g.y = 1; g.z /= nzp;
 }
 
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
@@ -1335,7 +1341,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
-  pconv_xcd_order(p, g);
+  pconv_xcd_order(p, g, geo == 3 ? 4 : 2);
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
 #define PT_GEO(BM_, NS_)                                          \
   do {                                                            \
@@ -1386,8 +1392,13 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   const bool half = s2 && a.nsplit == 3;       // 64-pixel tiles: the stride-2 patch of a 128-pixel tile does not fit three planes
   long tiles;
   int shape;           // pixel tile: 0 = 8 x 16, 1 = two 8 x 8 images, 2 = 4 x 16 (64 pixels), 3 = 8 x 8 of one image (64 pixels),
-                       // 4 = four whole 4 x 4 images (64 pixels)
-  if (a.OW % 16 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1); shape = half ? 2 : 0; }
+                       // 4 = four whole 4 x 4 images (64 pixels), 5 = 4 x 32
+  // (5: rows of 32 pixels are whole 128-byte lines of dy and x — with 16-pixel rows two tiles share every line, and at three
+  //  workgroups per CU the second one comes after the line has left the L2: measured 2.8x the operand bytes on 64 -> 64 at 64 x 64.
+  //  Only where the layer is memory-bound — bf16 mode, <= 64 output channels: 245 -> 211 us there, 178 -> 155 us at 128 x 128; the
+  //  wider patch (34 x 6 against 18 x 10 pixels to stage and convert) costs 6 % on 128-channel layers and 45 % in split mode.)
+  if (AGL_PBWW_ROWS32 && !s2 && a.ks == 3 && a.nsplit == 1 && a.Cout <= 64 && a.OW % 32 == 0 && a.OH % 4 == 0) { tiles = (long)a.N * (a.OH / 4) * (a.OW / 32); shape = 5; }
+  else if (a.OW % 16 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 16) * (half ? 2 : 1); shape = half ? 2 : 0; }
   else if (a.OW == 8 && a.OH == 8) { tiles = half ? a.N : agl_cdiv(a.N, 2); shape = half ? 3 : 1; }
   else if (a.OW % 8 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 8); shape = 3; }
   else if (a.OW == 4 && a.OH == 4 && a.ks != 5) { tiles = agl_cdiv(a.N, 4); shape = 4; }
@@ -1428,17 +1439,6 @@ long pbww_ws_bytes(const PBwwArgs& a) {
   return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4 + (long)s * a.Cout * 4;      // weight slabs + bias-gradient slabs
 }
 
-namespace {
-// db[c] (+)= sum over the splits' partial sums, in split order
-__global__ void bias_slab_reduce(const float* __restrict__ slabs, float* __restrict__ db, int C, int splits, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slabs[(long)z * C + c];
-  db[c] = accumulate ? db[c] + s : s;
-}
-}  // namespace
-
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int splits, tps, rt, ct, half, oh, ow; long tiles;
   if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return -1;
@@ -1470,6 +1470,11 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);     \
     else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                    \
   } while (0)
+#define PW_LAUNCH1(KS_, RT_, CT_, NS_)      /* 3x3, bf16 mode, <= 64 output channels: the 4 x 32 tile (shape 5) */              \
+  do {                                                                                                              \
+    if (half == 5) hipLaunchKernelGGL((pbww_k<KS_, 1, 32, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);            \
+    else PW_LAUNCH(KS_, 1, RT_, CT_, NS_);                                                                          \
+  } while (0)
   if (a.stride == 2) {
     if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
     else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 2, 1, 1);
@@ -1480,7 +1485,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 1); else PW_LAUNCH(1, 1, 1, 1, 1);
   } else if (a.ks == 3 && a.nsplit == 1) {
     if (rt == 2 && ct == 2) PW_LAUNCH(3, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 1, 2, 1, 1);
-    else if (ct == 2) PW_LAUNCH(3, 1, 1, 2, 1); else PW_LAUNCH(3, 1, 1, 1, 1);
+    else if (ct == 2) PW_LAUNCH1(3, 1, 2, 1); else PW_LAUNCH1(3, 1, 1, 1);
   } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
   else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
   else {
@@ -1488,11 +1493,14 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
   }
+#undef PW_LAUNCH1
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
   if (with_bias) {
-    hipLaunchKernelGGL(bias_slab_reduce, dim3(agl_cdiv(a.Cout, 256)), dim3(256), 0, st, (const float*)p.bias_slabs, a.dbias, a.Cout, splits,
-                       a.dbias_accumulate);
+    // (agl_launch_slab_reduce: 16 thread rows walk the splits of 16 consecutive channels — one thread per channel was a chain of up
+    //  to 384 dependent loads, 27 us per launch, 150 launches per iteration)
+    const int brc = agl_launch_slab_reduce((const float*)p.bias_slabs, a.dbias, a.Cout, splits, a.dbias_accumulate, st, name);
+    if (brc != AGL_OK) return brc;
     AGL_CHECK_LAUNCH(name);
     if (a.dbias_done) *a.dbias_done = 1;
   }
