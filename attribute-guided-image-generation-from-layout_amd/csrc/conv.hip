@@ -1597,6 +1597,11 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH * OW >= 64 && (long)H * W * 8 < (1L << 18) && w)   // (linear layers, HW = 1, stay on the GEMM; 18-bit patch table)
     return launch_small_cout(x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, st,
                              "agl_conv2d_fwd(small Cout)");
+  if (Cin <= 4 && Cout >= 16 && stride == 1 && up_log2 == 0 && OH == H && OW == W && w && co.patch) {
+    // few input channels, 1x1 / 3x3: a stream over the output (few.hip; exact fp32 on the vector units in every arithmetic mode)
+    const int frc = few_cin_fwd_try(x, w, bias, y, N, Cin, H, W, Cout, ks, in_relu, relu, accumulate, st, "agl_conv2d_fwd(few input channels)");
+    if (frc >= 0) return frc;
+  }
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;

@@ -6,6 +6,11 @@
 //               generator_obj_att.py:367 CropEncoder c1 3->64 k7) — and, through the role swap of conv.hip, with <= 4 OUTPUT
 //               channels (decoder c4 64->3 k7, generator_obj_att.py:516).  GEMM: rows = output channels (64 per workgroup),
 //               columns = (input channel, tap) <= 160, reduction = pixels, on v_mfma_f32_32x32x2_f32.
+//   few_cin_fwd_k   forward with <= 4 INPUT channels, 1x1 / 3x3, stride 1, "same" (OptimizedBlock c1 3->64 and its 1x1 shortcut
+//               accumulated onto the residual branch, discriminator.py:36-60): a stream over the output — a thread owns four
+//               consecutive pixels and walks all output channels with 16-byte stores (and 16-byte reads of the tensor it
+//               accumulates onto); the 64 x 27 weights sit in LDS and are read as broadcasts.
+#include <cstdint>
 #include "agl_internal.h"
 #include "few.h"
 
@@ -160,6 +165,66 @@ __global__ __launch_bounds__(NT_, 2) void few_bww_k(FewBwwArgs p) {
   }
 }
 
+
+struct FewCinArgs {
+  const float* x; const float* w; const float* bias; float* y;
+  int N, Cin, H, W, Cout, in_relu, relu, accumulate;
+};
+
+template <int KS, int CIN>
+__global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
+  constexpr int KK = KS * KS, PADK = KS / 2, NW = CIN * KK;
+  extern __shared__ __attribute__((aligned(16))) float lw[];       // [Cout][NW] (+ bias [Cout])
+  for (int i = threadIdx.x; i < p.Cout * NW; i += 256) lw[i] = p.w[i];
+  float* const lb = lw + p.Cout * NW;
+  for (int i = threadIdx.x; i < p.Cout; i += 256) lb[i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+  const int QW = p.W / 4;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (long)p.N * p.H * QW) return;
+  const int qx = (int)(q % QW), t = (int)(q / QW), iy = t % p.H, n = t / p.H, ix0 = 4 * qx;
+  const long HW = (long)p.H * p.W;
+  // the input window: CIN channels x KS rows x (4 + KS - 1) columns, zero outside the map
+  float xin[CIN][KS][4 + KS - 1];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+      const int yy = iy - PADK + r;
+      const bool rok = (unsigned)yy < (unsigned)p.H;
+      const float* row = p.x + ((long)n * CIN + c) * HW + (long)(rok ? yy : 0) * p.W + ix0;
+      float4 mid = rok ? *reinterpret_cast<const float4*>(row) : float4{0.f, 0.f, 0.f, 0.f};
+      if (p.in_relu) { mid.x = fmaxf(mid.x, 0.f); mid.y = fmaxf(mid.y, 0.f); mid.z = fmaxf(mid.z, 0.f); mid.w = fmaxf(mid.w, 0.f); }
+      xin[c][r][PADK + 0] = mid.x; xin[c][r][PADK + 1] = mid.y; xin[c][r][PADK + 2] = mid.z; xin[c][r][PADK + 3] = mid.w;
+      if constexpr (KS == 3) {
+        float l = (rok && ix0 > 0) ? row[-1] : 0.f, rr = (rok && ix0 + 4 < p.W) ? row[4] : 0.f;
+        if (p.in_relu) { l = fmaxf(l, 0.f); rr = fmaxf(rr, 0.f); }
+        xin[c][r][0] = l; xin[c][r][5] = rr;
+      }
+    }
+  float* const yb = p.y + (long)n * p.Cout * HW + (long)iy * p.W + ix0;
+  for (int co = 0; co < p.Cout; ++co) {
+    const float* wc = lw + co * NW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float wv = wc[(c * KS + r) * KS + k];
+          a0 = fmaf(wv, xin[c][r][k + 0], a0); a1 = fmaf(wv, xin[c][r][k + 1], a1);
+          a2 = fmaf(wv, xin[c][r][k + 2], a2); a3 = fmaf(wv, xin[c][r][k + 3], a3);
+        }
+    const float bb = lb[co];
+    float4 v = {a0 + bb, a1 + bb, a2 + bb, a3 + bb};
+    float4* dst = reinterpret_cast<float4*>(yb + (long)co * HW);
+    if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *dst = v;
+  }
+}
+
 }  // namespace
 
 static int few_bww_plan(const FewBwwShape& a, int* ntl, int* splits, int* tps, int* tiles) {
@@ -205,5 +270,22 @@ int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws,
 #undef FEW_LAUNCH
   AGL_CHECK_LAUNCH(name);
   *splits_out = splits;
+  return AGL_OK;
+}
+
+// Forward with <= 4 input channels (see few_cin_fwd_k).  -1: shape not taken.
+int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int ks, int in_relu,
+                    int relu, int accumulate, hipStream_t st, const char* name) {
+  if (!(ks == 1 || ks == 3) || Cin < 1 || Cin > 4 || W % 4 != 0 || (relu && accumulate)) return -1;
+  const long lds = ((long)Cout * Cin * ks * ks + Cout) * 4;
+  if (lds > 48 * 1024) return -1;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
+  FewCinArgs p{x, w, bias, y, N, Cin, H, W, Cout, in_relu, relu, accumulate};
+  const dim3 g((unsigned)agl_cdiv((long)N * H * (W / 4), 256));
+#define FC_LAUNCH(KS_, C_) hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_>), g, dim3(256), (size_t)lds, st, p)
+  if (ks == 1) { if (Cin == 1) FC_LAUNCH(1, 1); else if (Cin == 2) FC_LAUNCH(1, 2); else if (Cin == 3) FC_LAUNCH(1, 3); else FC_LAUNCH(1, 4); }
+  else { if (Cin == 1) FC_LAUNCH(3, 1); else if (Cin == 2) FC_LAUNCH(3, 2); else if (Cin == 3) FC_LAUNCH(3, 3); else FC_LAUNCH(3, 4); }
+#undef FC_LAUNCH
+  AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }

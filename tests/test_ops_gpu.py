@@ -467,6 +467,32 @@ def test_conv3x3_avgpool_box_form(shape):
     close(outs[0], outs[1], 2e-5, "box form vs pooled-filter form")
 
 
+@pytest.mark.parametrize("case", [(5, 3, 32, 32, 64, 3), (5, 3, 32, 32, 64, 1), (2, 3, 64, 64, 64, 3), (3, 4, 16, 24, 48, 3), (9, 1, 8, 64, 16, 1),
+                                  (2, 2, 40, 28, 130, 3)])
+def test_few_input_channel_forward_stream(case):
+    """Forward with <= 4 input channels, 1x1 / 3x3 (csrc/few.hip few_cin_fwd_k: the discriminators' first convolution and the 1x1
+    shortcut accumulated onto the residual branch): bias, fused input ReLU, output ReLU and accumulation, borders included, against
+    torch fp32 — exact fp32 arithmetic in every mode, so the same 2e-5 in all three."""
+    from agl import lib as L
+    N, Cin, H, W, Cout, ks = case
+    x, w, b = rn(N, Cin, H, W), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2)
+    old = rn(N, Cout, H, W, seed=5)
+    for flags in (0, L.CONV_SPLIT3, L.CONV_BF16):
+        with L.conv_flags(flags):
+            for in_relu, relu, acc in ((False, False, False), (True, True, False), (False, False, True), (True, False, True)):
+                xin = torch.relu(x) if in_relu else x
+                ref = TF.conv2d(xin, w, b, padding=ks // 2)
+                if acc:
+                    ref = ref + old
+                if relu:
+                    ref = torch.relu(ref)
+                out = dev(old).clone() if acc else None
+                y = L.conv2d_fwd(dev(x), dev(w), dev(b), 1, ks // 2, 0, in_relu, relu, out=out, accumulate=acc)
+                close(y, ref, 2e-5, f"y flags={flags} in_relu={in_relu} relu={relu} acc={acc}")
+    y = L.conv2d_fwd(dev(x), dev(w), None, 1, ks // 2)
+    close(y, TF.conv2d(x, w, None, padding=ks // 2), 2e-5, "no bias")
+
+
 @pytest.mark.parametrize("mode", ["f32", "split3", "bf16"])
 @pytest.mark.parametrize("case", [(3, 64, 32, 64, True), (2, 3, 16, 32, False), (5, 128, 8, 128, True), (2, 48, 64, 80, True), (70, 64, 4, 64, True)])
 def test_conv_and_pool_fork_of_a_block_input(case, mode):
