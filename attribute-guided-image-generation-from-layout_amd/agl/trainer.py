@@ -18,6 +18,7 @@ builder's job (agl.synth); the batch carries attribute / attribute_gt / attribut
 from __future__ import annotations
 
 import math
+import time
 import os
 from typing import Dict, Optional, Sequence
 
@@ -155,7 +156,7 @@ class Trainer:
         if self.marks is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream if stream is not None else torch.cuda.current_stream())
-            self.marks.append((label, ev))
+            self.marks.append((label, ev, time.perf_counter()))
 
     def _gen(self, b, eps):
         return self.netG(b["imgs"], b["objs"], b["boxes"], b["masks"], b["obj_to_img"], b["z"], b["attribute"],

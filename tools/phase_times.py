@@ -4,6 +4,7 @@ every discriminator chain, on the chain's stream); this prints when each was rea
 import argparse
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -77,14 +78,16 @@ for it in range(a.steps):
     end = torch.cuda.Event(enable_timing=True)
     end.record()
     torch.cuda.synchronize()
-    m, tr.marks = tr.marks + [("end (Adam of G joined)", end)], None
-    t0 = m[0][1]
-    for label, ev in m:
+    m, tr.marks = tr.marks + [("end (Adam of G joined)", end, time.perf_counter())], None
+    t0, h0 = m[0][1], m[0][2]
+    for label, ev, th in m:
         if label not in acc:
-            acc[label] = 0.0
+            acc[label] = [0.0, 0.0]
             order.append(label)
-        acc[label] += t0.elapsed_time(ev) / a.steps
+        acc[label][0] += t0.elapsed_time(ev) / a.steps
+        acc[label][1] += 1e3 * (th - h0) / a.steps
 print(f"{a.res} px, {dtype}, batch {per_gpu}, O = {O}: event reached at (ms after the start of the iteration; mean of {a.steps}; the host runs "
       f"ahead, so consecutive iterations overlap at the edges)")
+print("       GPU      host (ms after the host entered the iteration: when the mark was ISSUED; the last line includes the final synchronize)")
 for label in order:
-    print(f"  {acc[label]:8.2f}  {label}")
+    print(f"  {acc[label][0]:8.2f}  {acc[label][1]:8.2f}  {label}")
