@@ -29,8 +29,19 @@ BN_TAPE = None
 
 
 def bn_tape_replay(tape):
-    for fn in tape:
-        fn()
+    """Entries: ("bn", moments, running_mean, running_var, nbt) — a running-statistics update, replayed from its saved moments;
+    runs of them go out as one launch — or a callable."""
+    run = []
+    for e in tape:
+        if isinstance(e, tuple):
+            run.append(e[1:])
+            continue
+        if run:
+            L.bn_running_update_many(run, BN_MOMENTUM)
+            run = []
+        e()
+    if run:
+        L.bn_running_update_many(run, BN_MOMENTUM)
 
 
 # Deferred running-statistics updates (agl.generator's concurrent branches): while BN_DEFER is a list, a training-mode statistics
@@ -41,8 +52,8 @@ BN_DEFER = None
 
 
 def bn_apply_deferred(entries):
-    for mom, rmean, rvar, nbt in entries:
-        L.bn_running_update(mom, BN_MOMENTUM, rmean, rvar, nbt)
+    if entries:
+        L.bn_running_update_many(list(entries), BN_MOMENTUM)
 
 
 def _slot(p):
@@ -270,7 +281,7 @@ class _NormAct(torch.autograd.Function):
             if defer:
                 BN_DEFER.append((mom, rmean, rvar, nbt))
             if taped:
-                BN_TAPE.append(lambda: L.bn_running_update(mom, BN_MOMENTUM, rmean, rvar, nbt))
+                BN_TAPE.append(("bn", mom, rmean, rvar, nbt))
         else:
             mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
         p0c = _c(p0) if p0 is not None else None

@@ -39,6 +39,7 @@ SIGNATURES = {
     "agl_bn_stats_ws_bytes": (_L, [_I] * 3),
     "agl_bn_stats": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "agl_bn_running_update": (_I, [_P, _I, _F, _P, _P, _P, _P]),
+    "agl_bn_running_update_multi": (_I, [_P, _I, _P]),
     "agl_bn_stats_eval": (_I, [_P, _P, _I, _F, _P, _P, _P]),
     "agl_bn_stats_from_partials": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "agl_conv2d_fwd_stats_floats": (_L, [_I] * 4),
@@ -109,7 +110,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 2     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 3     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -403,6 +404,27 @@ def bn_running_update(moments, momentum, running_mean, running_var, nbt=None):
     """Re-apply the running-statistics update of the statistics call that wrote `moments` (bit-identical to recomputing it)."""
     call("agl_bn_running_update", ptr(moments, torch.float64), running_mean.numel(), momentum, ptr(running_mean), ptr(running_var),
          ptr(nbt, torch.int64), stream())
+
+
+class BnUpdate(C.Structure):
+    """AglBnUpdate of include/agl.h."""
+    _fields_ = [("moments", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("C", C.c_int), ("momentum", C.c_float)]
+
+
+BN_UPDATE_MAX = 24
+
+
+def bn_running_update_many(entries, momentum):
+    """bn_running_update for a list of (moments, running_mean, running_var, nbt) in as few launches as possible (array order kept)."""
+    for i in range(0, len(entries), BN_UPDATE_MAX):
+        chunk = entries[i:i + BN_UPDATE_MAX]
+        arr = (BnUpdate * len(chunk))()
+        for k, (mom, rm, rv, nbt) in enumerate(chunk):
+            arr[k].moments, arr[k].running_mean, arr[k].running_var = ptr(mom, torch.float64), ptr(rm), ptr(rv)
+            arr[k].num_batches_tracked = ptr(nbt, torch.int64)
+            arr[k].C, arr[k].momentum = rm.numel(), momentum
+        call("agl_bn_running_update_multi", C.addressof(arr), len(chunk), stream())
 
 
 def bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad):

@@ -31,7 +31,8 @@ void agl_set_error(const char* fmt, ...);
 static inline int agl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // out[i] (+)= sum over `splits` slabs of n floats (conv.hip); deterministic for a given slab count
-int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name);
+int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name,
+                           const float* slabs_b = nullptr, float* out_b = nullptr, long nb = 0, int accumulate_b = 0);
 // out[o] = epilogue(sum over slabs) with bias[(o / HW) % C], ReLU mask, accumulate, ReLU (conv.hip)
 // (out_div: optional device scalar, the slab sum is divided by it first)
 int agl_launch_splitk_epilogue(const float* slabs, float* out, long n, int splits, int HW, int C, const float* bias, const float* pos_mask,

@@ -855,42 +855,55 @@ __global__ __launch_bounds__(NT, (BM * BN > 128 * 128) ? 2 : 4) void igemm_f32(P
   }
 }
 
-__global__ void slab_reduce(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// A launch may reduce a second, smaller set of slabs with the same slab count behind the first (the bias-gradient sums beside the
+// weight-gradient slabs of csrc/pconv.hip: one launch instead of two): workgroups >= blocks_a work on (slabs_b, out_b, nb).
+struct SlabPair { const float* slabs; float* out; long n; int accumulate; };
+
+__global__ void slab_reduce(SlabPair a, SlabPair b, int blocks_a, int splits) {
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const SlabPair q = second ? b : a;
+  const long i = (long)(blockIdx.x - (second ? blocks_a : 0)) * blockDim.x + threadIdx.x;
+  if (i >= q.n) return;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+  for (int z = 0; z < splits; ++z) s += q.slabs[(long)z * q.n + i];
+  q.out[i] = q.accumulate ? q.out[i] + s : s;
 }
 
 // Many slabs of few elements (few.hip: 512 slabs of 64 x 27): one thread per element would walk all slabs serially on a handful
 // of workgroups.  Here a workgroup owns 16 consecutive elements and its 16 thread rows take every 16th slab each; the 16
 // partial sums are added in row order (deterministic for a given slab count).
-__global__ __launch_bounds__(256) void slab_reduce_wide(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits,
-                                                        int accumulate) {
+__global__ __launch_bounds__(256) void slab_reduce_wide(SlabPair a, SlabPair b, int blocks_a, int splits) {
   __shared__ float part[16][17];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const SlabPair q = second ? b : a;
   const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
-  const long i = (long)blockIdx.x * 16 + o;
+  const long i = (long)(blockIdx.x - (second ? blocks_a : 0)) * 16 + o;
   float s = 0.f;
-  if (i < n)
-    for (int z = zl; z < splits; z += 16) s += slabs[(long)z * n + i];
+  if (i < q.n)
+    for (int z = zl; z < splits; z += 16) s += q.slabs[(long)z * q.n + i];
   part[zl][o] = s;
   __syncthreads();
-  if (zl == 0 && i < n) {
+  if (zl == 0 && i < q.n) {
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += part[r][o];
-    out[i] = accumulate ? out[i] + t : t;
+    q.out[i] = q.accumulate ? q.out[i] + t : t;
   }
 }
 
 }  // namespace
-// out[i] (+)= sum over slabs, in slab order (row-interleaved order in the wide form): shared by the weight-gradient paths
-int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name) {
-  if (splits >= 8 && n < (1L << 18))
-    hipLaunchKernelGGL(slab_reduce_wide, dim3(agl_cdiv(n, 16)), dim3(256), 0, st, slabs, out, n, splits, accumulate);
-  else
-    hipLaunchKernelGGL(slab_reduce, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, accumulate);
+// out[i] (+)= sum over slabs, in slab order (row-interleaved order in the wide form): shared by the weight-gradient paths.
+// slabs_b (optional): a second set of `splits` slabs of nb elements reduced by the same launch.
+int agl_launch_slab_reduce(const float* slabs, float* out, long n, int splits, int accumulate, hipStream_t st, const char* name,
+                           const float* slabs_b, float* out_b, long nb, int accumulate_b) {
+  const SlabPair a{slabs, out, n, accumulate}, b{slabs_b, out_b, slabs_b ? nb : 0, accumulate_b};
+  if (splits >= 8 && n < (1L << 18)) {
+    const int ba = agl_cdiv(n, 16);
+    hipLaunchKernelGGL(slab_reduce_wide, dim3(ba + agl_cdiv(b.n, 16)), dim3(256), 0, st, a, b, ba, splits);
+  } else {
+    const int ba = agl_cdiv(n, 256);
+    hipLaunchKernelGGL(slab_reduce, dim3(ba + agl_cdiv(b.n, 256)), dim3(256), 0, st, a, b, ba, splits);
+  }
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }

@@ -9,6 +9,10 @@
 #include "agl_internal.h"
 #include <algorithm>
 
+// (AglBnUpdate / AGL_BN_UPDATE_MAX: include/agl.h — the sources do not include the public header, tests/test_abi.py keeps them in step)
+#define AGL_BN_UPDATE_MAX 24
+struct AglBnUpdate { const double* moments; float* running_mean; float* running_var; long long* num_batches_tracked; int C; float momentum; };
+
 namespace {
 
 template <int LPR>
@@ -149,6 +153,20 @@ __global__ void bn_running_update_k(const double* __restrict__ moments, int C, f
   const double mu = moments[2 * c], unb = moments[2 * c + 1];
   rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
   rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+}
+
+// ... for up to AGL_BN_UPDATE_MAX layers in one launch: thread c applies the items in array order to channel c of each
+struct BnUpdateBatch { AglBnUpdate it[AGL_BN_UPDATE_MAX]; int n; };
+__global__ void bn_running_update_multi_k(BnUpdateBatch b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int e = 0; e < b.n; ++e) {
+    const AglBnUpdate& u = b.it[e];
+    if (c == 0 && u.num_batches_tracked) *u.num_batches_tracked += 1;
+    if (c >= u.C) continue;
+    const double mu = u.moments[2 * c], unb = u.moments[2 * c + 1];
+    u.running_mean[c] = (float)((1.0 - u.momentum) * u.running_mean[c] + u.momentum * mu);
+    u.running_var[c] = (float)((1.0 - u.momentum) * u.running_var[c] + u.momentum * unb);
+  }
 }
 
 // Eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
@@ -363,45 +381,46 @@ __global__ __launch_bounds__(256) void norm_bwd_table(NormArgs a, const float* _
   }
 }
 
-// K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; affine parameter grads (mode 1).  One wave per channel.
-__global__ __launch_bounds__(256) void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
-                                                         float* __restrict__ dp0, float* __restrict__ dp1, int param_accumulate) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= a.C) return;
-  double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
-  for (int n = lane; n < a.N; n += 64) {
-    const float a1 = rowsum[2 * ((long)n * a.C + c)], a2 = rowsum[2 * ((long)n * a.C + c) + 1];
-    float g = 1.f;
-    if (a.mode == 2) g = a.p0[(long)a.labels[n] * 2 * a.C + c];
-    S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
-  }
-  S1 = wave_sum(S1); S2 = wave_sum(S2); A1 = wave_sum(A1); A2 = wave_sum(A2);
-  if (lane == 0) {
-    if (a.mode == 1) {
-      if (dp0) {
-        if (param_accumulate) { dp0[c] += (float)A2; dp1[c] += (float)A1; }
-        else { dp0[c] = (float)A2; dp1[c] = (float)A1; }
-      }
-      S1 *= a.p0[c]; S2 *= a.p0[c];
-    }
-    chansum[2 * c] = (float)S1;
-    chansum[2 * c + 1] = (float)S2;
-  }
-}
-
-// K3: dx = rstd * (ge*g - S1/M - xhat*S2/M)
+// K2 + K3 in one launch.  Per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 over the row sums of K1 (ge = 1, gamma[c] or the
+// class-table entry; doubles) — every group of lanes that owns a row (n, c) adds the N row sums of its channel itself, in the same
+// order as every other group of that channel (identical totals in all of them; N <= a few hundred values from L2, nothing beside the
+// HW-long row it then walks) — the separate per-channel launch between the row pass and this one is gone.  The groups of image 0
+// also leave the affine parameter gradients (mode 1).  Then dx = rstd * (ge*g - S1/M - xhat*S2/M).
 template <int LPR>
 __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
-                                                      const float* __restrict__ chansum, float inv_m, int batch_stats,
-                                                      float* __restrict__ dx) {
+                                                      const float* __restrict__ rowsum, float inv_m, int batch_stats,
+                                                      float* __restrict__ dx, float* __restrict__ dp0, float* __restrict__ dp1,
+                                                      int param_accumulate) {
+  constexpr int G = LPR >= 64 ? 64 : LPR;          // lanes that add the channel's row sums together (a wave, or the row's lane group)
   const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-  if (row >= a.N * a.C) return;
-  const int n = row / a.C, c = row - n * a.C;
+  const bool live = row < a.N * a.C;
+  const int rr = live ? row : 0;
+  const int n = rr / a.C, c = rr - n * a.C;
+  const bool want_p = a.mode == 1 && dp0 != nullptr;
+  float m1 = 0.f, m2 = 0.f;
+  if (batch_stats || want_p) {                      // (wave-uniform)
+    double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
+    for (int k = threadIdx.x % G; k < a.N; k += G) {
+      const float a1 = rowsum[2 * ((long)k * a.C + c)], a2 = rowsum[2 * ((long)k * a.C + c) + 1];
+      float g = 1.f;
+      if (a.mode == 2) g = a.p0[(long)a.labels[k] * 2 * a.C + c];
+      S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+      S1 += __shfl_xor(S1, o); S2 += __shfl_xor(S2, o); A1 += __shfl_xor(A1, o); A2 += __shfl_xor(A2, o);
+    }
+    if (want_p && live && n == 0 && threadIdx.x % LPR == 0) {
+      if (param_accumulate) { dp0[c] += (float)A2; dp1[c] += (float)A1; }
+      else { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+    }
+    if (a.mode == 1) { S1 *= a.p0[c]; S2 *= a.p0[c]; }
+    if (batch_stats) { m1 = (float)S1 * inv_m; m2 = (float)S2 * inv_m; }
+  }
+  if (!live) return;
   const float mu = a.mean[c], rs = a.rstd[c];
   float ge, b;
   row_affine(a, n, c, ge, b);
-  const float m1 = batch_stats ? chansum[2 * c] * inv_m : 0.f, m2 = batch_stats ? chansum[2 * c + 1] * inv_m : 0.f;
   const long base = (long)row * a.HW;
   const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
@@ -458,6 +477,21 @@ int agl_bn_running_update(const double* moments, int C, float momentum, float* r
   hipLaunchKernelGGL(bn_running_update_k, dim3(agl_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, moments, C, momentum, running_mean,
                      running_var, num_batches_tracked);
   AGL_CHECK_LAUNCH("agl_bn_running_update");
+  return AGL_OK;
+}
+
+int agl_bn_running_update_multi(const AglBnUpdate* items, int n, void* stream) {
+  AGL_REQUIRE(items && n > 0 && n <= AGL_BN_UPDATE_MAX, "agl_bn_running_update_multi: 1..%d items", AGL_BN_UPDATE_MAX);
+  BnUpdateBatch b;
+  b.n = n;
+  int cmax = 0;
+  for (int e = 0; e < n; ++e) {
+    AGL_REQUIRE(items[e].moments && items[e].running_mean && items[e].running_var && items[e].C > 0, "agl_bn_running_update_multi: bad item %d", e);
+    b.it[e] = items[e];
+    cmax = std::max(cmax, items[e].C);
+  }
+  hipLaunchKernelGGL(bn_running_update_multi_k, dim3(agl_cdiv(cmax, 128)), dim3(128), 0, (hipStream_t)stream, b);
+  AGL_CHECK_LAUNCH("agl_bn_running_update_multi");
   return AGL_OK;
 }
 
@@ -558,7 +592,6 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
     return AGL_ERR_WORKSPACE;
   }
   float* rowsum = (float*)ws;
-  float* chansum = rowsum + (long)N * C * 2;
   hipStream_t st = (hipStream_t)stream;
   if (gb_lo) {      // d(gamma|beta) reduced to the class grid in the row pass
     AGL_REQUIRE(gb_map && mode == 3 && (W == 64 || W == 128) && src_w <= W, "agl_norm_bwd: gb_lo needs mode 3, gb_map and a 64- or 128-wide map");
@@ -567,16 +600,13 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
     AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
   }
   AGL_CHECK_LAUNCH("agl_norm_bwd(rows)");
-  hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 4)), dim3(256), 0, st, a, (const float*)rowsum, chansum,
-                     mode == 3 ? nullptr : dp0, dp1, param_accumulate);
-  AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
   if (mode == 2 && dp0) {
     AGL_REQUIRE(n_classes > 0, "agl_norm_bwd: mode 2 needs the number of table rows");
     hipLaunchKernelGGL(norm_bwd_table, dim3(agl_cdiv(C, 256), n_classes), dim3(256), 0, st, a, (const float*)rowsum, dp0);
     AGL_CHECK_LAUNCH("agl_norm_bwd(table)");
   }
   const float inv_m = 1.0f / (float)((long)N * HW);
-  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)chansum, inv_m, batch_stats, dx);
+  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)rowsum, inv_m, batch_stats, dx, mode == 3 ? nullptr : dp0, dp1, param_accumulate);
   AGL_CHECK_LAUNCH("agl_norm_bwd(apply)");
   return AGL_OK;
 }

@@ -1496,14 +1496,13 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
 #undef PW_LAUNCH1
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
-  if (with_bias) {
-    // (agl_launch_slab_reduce: 16 thread rows walk the splits of 16 consecutive channels — one thread per channel was a chain of up
-    //  to 384 dependent loads, 27 us per launch, 150 launches per iteration)
-    const int brc = agl_launch_slab_reduce((const float*)p.bias_slabs, a.dbias, a.Cout, splits, a.dbias_accumulate, st, name);
-    if (brc != AGL_OK) return brc;
-    AGL_CHECK_LAUNCH(name);
-    if (a.dbias_done) *a.dbias_done = 1;
-  }
-  if (direct) return AGL_OK;
-  return agl_launch_slab_reduce((const float*)ws, a.dw, n, splits, a.accumulate, st, name);
+  if (with_bias && a.dbias_done) *a.dbias_done = 1;
+  // the bias-gradient sums ride on the reduction launch of the weight slabs (one launch for both; when the single split wrote dw
+  // directly there are no weight slabs and the bias sums are one slab: their own small launch).
+  // (agl_launch_slab_reduce: 16 thread rows walk the splits of 16 consecutive elements — one thread per channel was a chain of up
+  //  to 384 dependent loads, 27 us per launch)
+  if (direct)
+    return with_bias ? agl_launch_slab_reduce((const float*)p.bias_slabs, a.dbias, a.Cout, splits, a.dbias_accumulate, st, name) : AGL_OK;
+  return agl_launch_slab_reduce((const float*)ws, a.dw, n, splits, a.accumulate, st, name, with_bias ? (const float*)p.bias_slabs : nullptr,
+                                a.dbias, a.Cout, a.dbias_accumulate);
 }

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 2
+#define AGL_ABI_VERSION 3
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -123,6 +123,14 @@ int agl_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum
                  void* stream);
 int agl_bn_running_update(const double* moments, int C, float momentum, float* running_mean, float* running_var,
                           long long* num_batches_tracked, void* stream);
+/* The same for n layers in ONE launch (n <= AGL_BN_UPDATE_MAX): the replay of a whole evaluation's tape.  Items are applied in
+ * array order per channel, so a layer may appear more than once (its updates then chain as they would in separate calls). */
+#define AGL_BN_UPDATE_MAX 24
+typedef struct {
+  const double* moments; float* running_mean; float* running_var; long long* num_batches_tracked; /* may be NULL */
+  int C; float momentum;
+} AglBnUpdate;
+int agl_bn_running_update_multi(const AglBnUpdate* items, int n, void* stream);
 int agl_bn_stats_eval(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
                       void* stream);
 /* agl_bn_stats from the partial rows of agl_conv2d_fwd_stats (count = N*HW elements per channel); rows are added in

@@ -1145,3 +1145,42 @@ def test_conv_batchnorm_partials_with_a_large_channel_offset():
         close(m1, m2, 1e-5, f"mean at offset {offset}")
         rel = float(((r1 - r2).abs() / r2).max())
         assert rel <= tol_rstd, (offset, rel)
+
+
+def test_bn_running_update_replay_single_and_batched():
+    """A statistics call leaves its (mean, unbiased variance) in double; agl_bn_running_update re-applies the running-statistics update
+    from them bit-identically to the update the statistics call itself makes, and agl_bn_running_update_multi does the same for a
+    whole tape in one launch — including a layer that appears twice (its two updates chain in array order) and more items than one
+    launch holds."""
+    from agl import lib as L
+    layers = []
+    for k, (N, Cc, H) in enumerate([(6, 64, 8), (3, 130, 4), (5, 32, 16)] * 10):       # 30 items > AGL_BN_UPDATE_MAX
+        x = dev(rn(N, Cc, H, H, seed=k) * (1.0 + 0.1 * k) + 0.3 * k)
+        rm, rv = dev(rn(Cc, seed=100 + k)), dev(rn(Cc, seed=200 + k).abs() + 0.5)
+        nbt = torch.full((1,), 7 + k, dtype=torch.int64, device=DEV)
+        layers.append((x, rm, rv, nbt))
+    direct, entries, singles = [], [], []
+    for x, rm, rv, nbt in layers:
+        a = (rm.clone(), rv.clone(), nbt.clone())
+        L.bn_stats(x, 1e-5, 0.1, *a)                                    # the statistics call updates a's copies itself
+        direct.append(a)
+        mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=DEV)
+        L.bn_stats(x, 1e-5, 0.1, None, None, None, moments=mom)         # moments only
+        b, c = (rm.clone(), rv.clone(), nbt.clone()), (rm.clone(), rv.clone(), nbt.clone())
+        entries.append((mom, *b))
+        singles.append(c)
+        L.bn_running_update(mom, 0.1, *c)
+    L.bn_running_update_many(entries, 0.1)
+    for a, e, c in zip(direct, entries, singles):
+        for t_direct, t_many, t_single in zip(a, e[1:], c):
+            assert torch.equal(t_direct, t_many) and torch.equal(t_direct, t_single)
+    # one layer twice in one batch: the second update starts from the first one's result
+    x, rm, rv, nbt = layers[0]
+    mom = entries[0][0]
+    twice = (rm.clone(), rv.clone(), nbt.clone())
+    L.bn_running_update_many([(mom, *twice), (mom, *twice)], 0.1)
+    ref = (rm.clone(), rv.clone(), nbt.clone())
+    L.bn_running_update(mom, 0.1, *ref)
+    L.bn_running_update(mom, 0.1, *ref)
+    for t1, t2 in zip(twice, ref):
+        assert torch.equal(t1, t2)
