@@ -381,16 +381,43 @@ __global__ __launch_bounds__(256) void norm_bwd_table(NormArgs a, const float* _
   }
 }
 
-// K2 + K3 in one launch.  Per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 over the row sums of K1 (ge = 1, gamma[c] or the
-// class-table entry; doubles) — every group of lanes that owns a row (n, c) adds the N row sums of its channel itself, in the same
-// order as every other group of that channel (identical totals in all of them; N <= a few hundred values from L2, nothing beside the
-// HW-long row it then walks) — the separate per-channel launch between the row pass and this one is gone.  The groups of image 0
-// also leave the affine parameter gradients (mode 1).  Then dx = rstd * (ge*g - S1/M - xhat*S2/M).
+// K2: per channel: S1 = sum_n ge(n,c)*a1, S2 = sum_n ge(n,c)*a2 ; affine parameter grads (mode 1).  One wave per channel.
+__global__ __launch_bounds__(256) void norm_bwd_channels(NormArgs a, const float* __restrict__ rowsum, float* __restrict__ chansum,
+                                                         float* __restrict__ dp0, float* __restrict__ dp1, int param_accumulate) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= a.C) return;
+  double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
+  for (int n = lane; n < a.N; n += 64) {
+    const float a1 = rowsum[2 * ((long)n * a.C + c)], a2 = rowsum[2 * ((long)n * a.C + c) + 1];
+    float g = 1.f;
+    if (a.mode == 2) g = a.p0[(long)a.labels[n] * 2 * a.C + c];
+    S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
+  }
+  S1 = wave_sum(S1); S2 = wave_sum(S2); A1 = wave_sum(A1); A2 = wave_sum(A2);
+  if (lane == 0) {
+    if (a.mode == 1) {
+      if (dp0) {
+        if (param_accumulate) { dp0[c] += (float)A2; dp1[c] += (float)A1; }
+        else { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+      }
+      S1 *= a.p0[c]; S2 *= a.p0[c];
+    }
+    chansum[2 * c] = (float)S1;
+    chansum[2 * c + 1] = (float)S2;
+  }
+}
+
+// K3: dx = rstd * (ge*g - S1/M - xhat*S2/M).  chansum == nullptr (batches of <= 64 images: every layer of the decoders and the
+// residual blocks): K2 is folded in — every group of lanes that owns a row (n, c) adds the N row sums of its channel itself (one
+// load per lane, the same order in every group of that channel: identical totals), the groups of image 0 also leave the affine
+// parameter gradients, and the per-channel launch between the row pass and this one is gone.  (With hundreds of rows per channel —
+// the crop encoder's per-object batches — that prologue costs more than the rows' own work: 2.2 -> 9.9 ms per iteration; those keep K2.)
 template <int LPR>
 __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
-                                                      const float* __restrict__ rowsum, float inv_m, int batch_stats,
-                                                      float* __restrict__ dx, float* __restrict__ dp0, float* __restrict__ dp1,
-                                                      int param_accumulate) {
+                                                      const float* __restrict__ rowsum, const float* __restrict__ chansum, float inv_m,
+                                                      int batch_stats, float* __restrict__ dx, float* __restrict__ dp0,
+                                                      float* __restrict__ dp1, int param_accumulate) {
   constexpr int G = LPR >= 64 ? 64 : LPR;          // lanes that add the channel's row sums together (a wave, or the row's lane group)
   const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const bool live = row < a.N * a.C;
@@ -398,7 +425,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
   const int n = rr / a.C, c = rr - n * a.C;
   const bool want_p = a.mode == 1 && dp0 != nullptr;
   float m1 = 0.f, m2 = 0.f;
-  if (batch_stats || want_p) {                      // (wave-uniform)
+  if (chansum) {
+    if (batch_stats) { m1 = chansum[2 * c] * inv_m; m2 = chansum[2 * c + 1] * inv_m; }
+  } else if (batch_stats || want_p) {               // (wave-uniform)
     double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
     for (int k = threadIdx.x % G; k < a.N; k += G) {
       const float a1 = rowsum[2 * ((long)k * a.C + c)], a2 = rowsum[2 * ((long)k * a.C + c) + 1];
@@ -606,7 +635,16 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
     AGL_CHECK_LAUNCH("agl_norm_bwd(table)");
   }
   const float inv_m = 1.0f / (float)((long)N * HW);
-  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)rowsum, inv_m, batch_stats, dx, mode == 3 ? nullptr : dp0, dp1, param_accumulate);
+  const float* chansum = nullptr;
+  if (N > 64) {      // many rows per channel: the per-channel sums by their own launch (see norm_bwd_apply)
+    float* cs = rowsum + (long)N * C * 2;
+    hipLaunchKernelGGL(norm_bwd_channels, dim3(agl_cdiv(C, 4)), dim3(256), 0, st, a, (const float*)rowsum, cs, mode == 3 ? nullptr : dp0, dp1,
+                       param_accumulate);
+    AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
+    chansum = cs;
+  }
+  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)rowsum, chansum, inv_m, batch_stats, dx, mode == 3 ? nullptr : dp0, dp1,
+                   param_accumulate);
   AGL_CHECK_LAUNCH("agl_norm_bwd(apply)");
   return AGL_OK;
 }
