@@ -32,13 +32,24 @@ __device__ __forceinline__ float group_sum(float v, float* scratch4) {
 __device__ __forceinline__ void channel_moments(const float* __restrict__ x, int C, int HW, int c, long e0, long e1, double& a, double& b) {
   a = 0.0; b = 0.0;
   if ((HW & 3) == 0) {
-    const int Q = HW >> 2;
-    for (long g = (e0 >> 2) + threadIdx.x; g < (e1 >> 2); g += 256) {
-      const int n = (int)(g / Q), q = (int)(g - (long)n * Q);
-      const float4 v = *reinterpret_cast<const float4*>(x + ((long)n * C + c) * HW + 4 * q);
+    // (32-bit index arithmetic — the tensors hold < 2^30 elements — and two independent 16-byte loads in flight per thread: the
+    //  64-bit division per load of the first form held the kernel at 2.6 TB/s)
+    const unsigned Q = HW >> 2, g1 = (unsigned)(e1 >> 2);
+    auto piece = [&](unsigned g) {
+      const unsigned n = g / Q, q = g - n * Q;
+      return *reinterpret_cast<const float4*>(x + ((long)n * C + c) * HW + 4 * q);
+    };
+    auto add = [&](const float4& v) {
       a += (double)((v.x + v.y) + (v.z + v.w));
       b += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    };
+    unsigned g = (unsigned)(e0 >> 2) + threadIdx.x;
+    for (; g + 256 < g1; g += 512) {
+      const float4 v0 = piece(g), v1 = piece(g + 256);
+      add(v0);
+      add(v1);
     }
+    if (g < g1) add(piece(g));
   } else {
     for (long e = e0 + threadIdx.x; e < e1; e += 256) {
       const int n = (int)(e / HW), hw = (int)(e - (long)n * HW);
@@ -307,6 +318,56 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
   }
 }
 
+// K1 with 16-byte accesses: one row per workgroup, four consecutive pixels per thread and step (HW % 4 == 0, aligned tensors,
+// W % 4 == 0 for a gathered gamma|beta).
+__global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ rowsum, float* __restrict__ dgb) {
+  __shared__ float sc[4];
+  const int row = blockIdx.x;
+  const int n = row / a.C, c = row - n * a.C;
+  const float mu = a.mean[c], rs = a.rstd[c];
+  const long base = (long)row * a.HW;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
+  float4* dgam = a.mode == 3 ? reinterpret_cast<float4*>(dgb + ((long)n * 2 * a.C + c) * a.HW) : nullptr;
+  float4* dbet = a.mode == 3 ? reinterpret_cast<float4*>(dgb + ((long)n * 2 * a.C + a.C + c) * a.HW) : nullptr;
+  const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
+  const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
+  const float4* y4 = a.relu ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < a.HW / 4; i += 256) {
+    const float4 gv = dy4[i], xv = x4[i];
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+    if (a.relu) {
+      const float4 yv = y4[i];
+      if (!(yv.x > 0.f)) g[0] = 0.f;
+      if (!(yv.y > 0.f)) g[1] = 0.f;
+      if (!(yv.z > 0.f)) g[2] = 0.f;
+      if (!(yv.w > 0.f)) g[3] = 0.f;
+    }
+    if (a.mode == 3) {
+      dgam[i] = float4{g[0] * xh[0], g[1] * xh[1], g[2] * xh[2], g[3] * xh[3]};
+      dbet[i] = float4{g[0], g[1], g[2], g[3]};
+      if (a.map) {
+        const int iy = (4 * i) / a.W, ix0 = 4 * i - iy * a.W, ro = a.map[iy] * a.src_w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] *= 1.f + gam[ro + a.map[ix0 + k]];
+      } else {
+        const float4 g4 = reinterpret_cast<const float4*>(gam)[i];
+        g[0] *= 1.f + g4.x; g[1] *= 1.f + g4.y; g[2] *= 1.f + g4.z; g[3] *= 1.f + g4.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1 += g[k]; s2 += g[k] * xh[k]; }
+  }
+  s1 = group_sum<256>(s1, sc);
+  s2 = group_sum<256>(s2, sc);
+  if (threadIdx.x == 0) {
+    rowsum[2 * (long)row] = s1;
+    rowsum[2 * (long)row + 1] = s2;
+  }
+}
+
 // K1g (mode 3 with a gathered gamma|beta): the same row sums, and d(gamma|beta) reduced to the class grid in the same pass — a
 // (n, c) plane per workgroup of W threads (one per pixel column).  Image row by image row: every thread leaves its pixel's
 // (g*xhat, g) in LDS; the threads that own a class column add up their column range and keep running sums for the current class
@@ -458,6 +519,74 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
     float xh = (a.x[base + i] - mu) * rs;
     float gg = a.mode == 3 ? g * (1.f + gam[gb_index(a, i)]) : g * ge;
     dx[base + i] = rs * (gg - m1 - xh * m2);
+  }
+}
+
+// K3 with 16-byte accesses (one row per workgroup; per-channel sums from K2 or folded in, as in norm_bwd_apply<256>)
+__global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* __restrict__ dy, const float* __restrict__ y,
+                                                       const float* __restrict__ rowsum, const float* __restrict__ chansum, float inv_m,
+                                                       int batch_stats, float* __restrict__ dx, float* __restrict__ dp0,
+                                                       float* __restrict__ dp1, int param_accumulate) {
+  const int row = blockIdx.x;
+  const int n = row / a.C, c = row - n * a.C;
+  const bool want_p = a.mode == 1 && dp0 != nullptr;
+  float m1 = 0.f, m2 = 0.f;
+  if (chansum) {
+    if (batch_stats) { m1 = chansum[2 * c] * inv_m; m2 = chansum[2 * c + 1] * inv_m; }
+  } else if (batch_stats || want_p) {
+    double S1 = 0.0, S2 = 0.0, A1 = 0.0, A2 = 0.0;
+    for (int k = threadIdx.x % 64; k < a.N; k += 64) {
+      const float a1 = rowsum[2 * ((long)k * a.C + c)], a2 = rowsum[2 * ((long)k * a.C + c) + 1];
+      float g = 1.f;
+      if (a.mode == 2) g = a.p0[(long)a.labels[k] * 2 * a.C + c];
+      S1 += (double)g * a1; S2 += (double)g * a2; A1 += a1; A2 += a2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      S1 += __shfl_xor(S1, o); S2 += __shfl_xor(S2, o); A1 += __shfl_xor(A1, o); A2 += __shfl_xor(A2, o);
+    }
+    if (want_p && n == 0 && threadIdx.x == 0) {
+      if (param_accumulate) { dp0[c] += (float)A2; dp1[c] += (float)A1; }
+      else { dp0[c] = (float)A2; dp1[c] = (float)A1; }
+    }
+    if (a.mode == 1) { S1 *= a.p0[c]; S2 *= a.p0[c]; }
+    if (batch_stats) { m1 = (float)S1 * inv_m; m2 = (float)S2 * inv_m; }
+  }
+  const float mu = a.mean[c], rs = a.rstd[c];
+  float ge, b;
+  row_affine(a, n, c, ge, b);
+  const long base = (long)row * a.HW;
+  const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
+  const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
+  const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
+  const float4* y4 = a.relu ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  float4* dx4 = reinterpret_cast<float4*>(dx + base);
+  for (int i = threadIdx.x; i < a.HW / 4; i += 256) {
+    const float4 gv = dy4[i], xv = x4[i];
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+    if (a.relu) {
+      const float4 yv = y4[i];
+      if (!(yv.x > 0.f)) g[0] = 0.f;
+      if (!(yv.y > 0.f)) g[1] = 0.f;
+      if (!(yv.z > 0.f)) g[2] = 0.f;
+      if (!(yv.w > 0.f)) g[3] = 0.f;
+    }
+    float ge4[4] = {ge, ge, ge, ge};
+    if (a.mode == 3) {
+      if (a.map) {
+        const int iy = (4 * i) / a.W, ix0 = 4 * i - iy * a.W, ro = a.map[iy] * a.src_w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ge4[k] = 1.f + gam[ro + a.map[ix0 + k]];
+      } else {
+        const float4 g4 = reinterpret_cast<const float4*>(gam)[i];
+        ge4[0] = 1.f + g4.x; ge4[1] = 1.f + g4.y; ge4[2] = 1.f + g4.z; ge4[3] = 1.f + g4.w;
+      }
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = rs * (g[k] * ge4[k] - m1 - xh[k] * m2);
+    dx4[i] = float4{o[0], o[1], o[2], o[3]};
   }
 }
 
@@ -622,9 +751,15 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
   }
   float* rowsum = (float*)ws;
   hipStream_t st = (hipStream_t)stream;
+  // rows of >= 1024 pixels: 16-byte accesses (a workgroup per row either way)
+  const bool vec4 = HW >= 1024 && HW % 4 == 0 && (!gb_map || W % 4 == 0) &&
+                    (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)(mode == 3 ? dp0 : nullptr) |
+                      (uintptr_t)(mode == 3 && !gb_map ? p0 : nullptr)) & 15) == 0;
   if (gb_lo) {      // d(gamma|beta) reduced to the class grid in the row pass
     AGL_REQUIRE(gb_map && mode == 3 && (W == 64 || W == 128) && src_w <= W, "agl_norm_bwd: gb_lo needs mode 3, gb_map and a 64- or 128-wide map");
     hipLaunchKernelGGL(norm_bwd_rows_gathered, dim3(N * C), dim3(W), 0, st, a, dy, y, gb_lo, rowsum, dp0);
+  } else if (vec4) {
+    hipLaunchKernelGGL(norm_bwd_rows4, dim3(N * C), dim3(256), 0, st, a, dy, y, rowsum, dp0);
   } else {
     AGL_LPR_DISPATCH(norm_bwd_rows, a, dy, y, rowsum, dp0);
   }
@@ -643,8 +778,12 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
     AGL_CHECK_LAUNCH("agl_norm_bwd(channels)");
     chansum = cs;
   }
-  AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)rowsum, chansum, inv_m, batch_stats, dx, mode == 3 ? nullptr : dp0, dp1,
-                   param_accumulate);
+  if (vec4)
+    hipLaunchKernelGGL(norm_bwd_apply4, dim3(N * C), dim3(256), 0, st, a, dy, y, (const float*)rowsum, chansum, inv_m, batch_stats, dx,
+                       mode == 3 ? nullptr : dp0, dp1, param_accumulate);
+  else
+    AGL_LPR_DISPATCH(norm_bwd_apply, a, dy, y, (const float*)rowsum, chansum, inv_m, batch_stats, dx, mode == 3 ? nullptr : dp0, dp1,
+                     param_accumulate);
   AGL_CHECK_LAUNCH("agl_norm_bwd(apply)");
   return AGL_OK;
 }
