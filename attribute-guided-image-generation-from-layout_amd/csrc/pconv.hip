@@ -1416,7 +1416,13 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   // fragment block goes back to 64 x 16 channels (more, smaller workgroups instead of more slabs).
   const long slab_bytes = (long)a.Cout * a.Cin * a.ks * a.ks * 4;
   const long operand_bytes = ((long)a.N * a.Cout * a.OH * a.OW + (long)a.N * a.Cin * a.H * a.W) * 4;
-  const long zcap = std::max(4L, operand_bytes / slab_bytes);
+#ifndef AGL_PBWW_ZCAP_DIV_BF16
+#define AGL_PBWW_ZCAP_DIV_BF16 4
+#endif
+  // (bf16 mode — one product per multiply-add, the layer is memory-bound: the slabs may take a quarter of the operand bytes;
+  //  256 -> 256 at 16 x 16 x 210: 236 -> 156 us, 128 px step 261 -> 266 images/s.  In split mode the same cap costs 3 %: the
+  //  workgroups it removes were hiding the longer matrix segments.)
+  const long zcap = std::max(4L, operand_bytes / (slab_bytes * (a.nsplit == 1 ? AGL_PBWW_ZCAP_DIV_BF16 : 1)));
   long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
   long z = std::min((768 + blocks - 1) / blocks, zcap);       // ~3 workgroups per CU: enough to fill the chip without piling up slabs
   if (blocks >= 384) z = 1;      // the channel blocks alone fill the chip: one split writes dw directly (no slab pass over a large tensor)
