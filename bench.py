@@ -233,7 +233,10 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         if os.environ.get("AGL_DUMP_CONV"):
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            only = os.environ.get("AGL_DUMP_PIPE")             # e.g. 0: the launches that stayed on the exact-fp32 kernels
             for name, e0, e1, f, dims, _pipe in conv:
+                if only is not None and str(_pipe) != only:
+                    continue
                 k = (name.replace('agl_conv2d_', ''), dims)
                 agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
             by_ms = os.environ.get("AGL_DUMP_SORT") == "ms"
