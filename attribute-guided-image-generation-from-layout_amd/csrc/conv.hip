@@ -1718,6 +1718,8 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
   AGL_REQUIRE((long)N * Cin * IH * IW < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
+  if (ks == 1 && IH == 1 && IW == 1 && OH == 1 && OW == 1 && pad == 0 && w && !bias && !relu && co.patch)      // nn.Linear (few.hip)
+    return linear_bwd_data_launch(dy, w, pos_mask, dx, N, Cin, Cout, accumulate, st, "agl_conv2d_bwd_data(linear)");
   if (Cin <= 4 && stride == 1 && IH == OH && IW == OW && w && co.patch && (co.prec == 1 || co.split3)) {
     PVertArgs v{dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu, accumulate, co.prec == 1 ? 1 : 3};
     const int vrc = pconv_vert_try(v, ws, ws_bytes, st, "agl_conv2d_bwd_data(vertical + diagonal)");
@@ -1963,6 +1965,8 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (ks == 1 && H == 1 && W == 1 && OH == 1 && OW == 1 && pad == 0 && up_log2 == 0 && co.patch)      // nn.Linear (few.hip)
+    return linear_bww_launch(dy, x, dw, N, Cin, Cout, in_relu, accumulate, (hipStream_t)stream, "agl_conv2d_bwd_weight(linear)");
   if (Cin <= 4) {      // RGB-side layers: rows = output channels, columns = (input channel, tap), exact fp32 (few.hip)
     const FewBwwShape f{N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up_log2, in_relu};
     int fsplits = 0;

@@ -43,6 +43,8 @@ CONV_CASES = [
     (3, 40, 9, 7, 24, 1, 1, 0),       # 1x1
     (2, 16, 6, 6, 20, 1, 1, 1),       # 1x1 with padding (LayoutEncoder c0)
     (70, 170, 1, 1, 128, 1, 1, 0),    # Linear as 1x1
+    (37, 130, 1, 1, 1, 1, 1, 0),      # ... one output (the discriminators' real / fake heads); rows and features off the block sizes
+    (9, 64, 1, 1, 2048, 1, 1, 0),     # ... wide (crop encoder fc)
     (1, 3, 10, 12, 8, 3, 1, 1),       # first D conv, ragged
     (3, 64, 17, 17, 128, 3, 2, 0),    # 3x3 stride 2 (box form of conv3x3 + avg-pool): phases of 4:2:2:1 taps
     (40, 32, 5, 5, 64, 3, 2, 0),      # ... on a small map (tap-proportional splits)
