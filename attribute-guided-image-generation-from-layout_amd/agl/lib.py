@@ -58,6 +58,8 @@ SIGNATURES = {
     "agl_grid_gather_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_grid_gather_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_box2_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
+    "agl_box2_fwd_bf16": (_I, [_P, _P, _L, _I, _I, _P]),
+    "agl_conv2d_bwd_weight_takes_bf16_x": (_I, [_I] * 11),
     "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
@@ -110,7 +112,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 3     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 4     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -150,6 +152,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 # Python binding only — the C ABI has no process-wide switches.
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_W8, CONV_PRIO = 128, 256
+CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
 CONV_FLAGS = 0
 
 
@@ -366,9 +369,10 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up) if not (relu and accumulate) else (None, None)
-    call("agl_conv2d_fwd", ptr(x), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out),
-         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
-         int(in_relu), int(relu), int(accumulate), CONV_FLAGS, stream())
+    xb16 = x.dtype == torch.bfloat16      # a tensor its producer wrote in bf16 (box2_fwd(bf16=True)): matrix-core kernel only
+    call("agl_conv2d_fwd", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
+         ptr(out), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
+         int(in_relu), int(relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0), stream())
     return out
 
 
@@ -477,9 +481,11 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
         need = max(need, Cout * Cin * ks * ks * 4)
     ws = workspace(need, dy.device) if need else None
     done = C.c_int(0)
-    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x), ptr(out), ptr(dbias), int(dbias_accumulate), C.addressof(done) if dbias is not None else None,
+    xb16 = x.dtype == torch.bfloat16
+    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x, x.dtype if xb16 else torch.float32), ptr(out), ptr(dbias), int(dbias_accumulate),
+         C.addressof(done) if dbias is not None else None,
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up,
-         int(in_relu), int(accumulate), CONV_FLAGS, stream())
+         int(in_relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0), stream())
     if dbias is not None and not done.value:
         channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
     return out
@@ -584,11 +590,27 @@ def scatter_rows(src, rows, out):
     return out
 
 
-def box2_fwd(x):
+def box2_fwd(x, bf16=False):
+    """bf16=True: the filtered map as a torch.bfloat16 tensor, for convolutions called with it as x (CONV_X_BF16)."""
     N, Cc, H, W = x.shape
+    if bf16:
+        xb = torch.empty((N, Cc, H + 1, W + 1), dtype=torch.bfloat16, device=x.device)
+        call("agl_box2_fwd_bf16", ptr(x), ptr(xb, torch.bfloat16), N * Cc, H, W, stream())
+        return xb
     xb = torch.empty((N, Cc, H + 1, W + 1), dtype=torch.float32, device=x.device)
     call("agl_box2_fwd", ptr(x), ptr(xb), N * Cc, H, W, stream())
     return xb
+
+
+def box_input_as_bf16(N, Cin, H, W, Cout, need_bww):
+    """True when the 3x3 / stride-2 / unpadded convolution of an (N, Cin, H, W) box-filtered map (and, with need_bww, its weight
+    gradient) runs on the matrix-core kernels in bf16 arithmetic — the producer may then write the map in bf16 (identical results)."""
+    if not (CONV_FLAGS & CONV_BF16) or (CONV_FLAGS & CONV_NO_PATCH) or W % 4 != 1:
+        return False
+    OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    if not load().agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, 3, 2, 0, 0, CONV_FLAGS):
+        return False
+    return (not need_bww) or bool(load().agl_conv2d_bwd_weight_takes_bf16_x(N, Cin, H, W, Cout, OH, OW, 3, 2, 0, CONV_FLAGS))
 
 
 def box2_bwd(dxb, mask=None):

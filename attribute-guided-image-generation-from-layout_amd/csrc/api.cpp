@@ -14,5 +14,5 @@ void agl_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* agl_last_error(void) { return g_err; }
-int agl_version(void) { return 3; }   // = AGL_ABI_VERSION of include/agl.h (bumped with every signature change)
+int agl_version(void) { return 4; }   // = AGL_ABI_VERSION of include/agl.h (bumped with every signature change)
 }

@@ -986,6 +986,7 @@ struct ConvOpts {
   bool w8;           // eight-wave workgroups in the LDS-patch kernels that have that form
   int prio;          // start stagger of the co-resident workgroups of the LDS-patch kernels (0 off, 1..4: delay length)
   int ablate;        // diagnostic kernel builds (flags bits 9..11; results are wrong by construction)
+  bool x_bf16;       // AGL_CONV_X_BF16 (1 << 17): the input tensor x holds bf16 elements (bf16 arithmetic, matrix-core kernels only)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -1000,9 +1001,10 @@ static ConvOpts conv_opts(int flags) {
   o.w8 = (flags & 128) != 0;
   o.prio = (flags >> 14) & 7;
   o.ablate = (flags >> 9) & 31;
+  o.x_bf16 = (flags & (1 << 17)) != 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1601,6 +1603,19 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
+  if (co.x_bf16) {      // a bf16 input exists for the matrix-core patch kernel in bf16 arithmetic only (the caller asked agl_conv2d_fwd_packed_bytes)
+    AGL_REQUIRE(co.prec == 1 && co.patch && !(relu && accumulate), "agl_conv2d_fwd: AGL_CONV_X_BF16 needs AGL_CONV_BF16 and the patch kernel");
+    PConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
+    a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
+    a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1;
+    const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, bf16 input)");
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd: AGL_CONV_X_BF16 on a shape the patch kernel does not take");
+    g_last_pipe = 1;
+    return prc;
+  }
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH == H && OW == W && w && co.patch && (co.prec == 1 || co.split3)) {
     // few output channels, 7x7: vertical convolution on the matrix cores + diagonal sum (pconv.hip)
     PVertArgs v{x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, co.prec == 1 ? 1 : 3};
@@ -1900,6 +1915,16 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
 }
 
 static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW);
+// 1 when agl_conv2d_bwd_weight with AGL_CONV_BF16 runs these extents on the matrix-core kernel — the only one that reads a bf16 x
+// (AGL_CONV_X_BF16); a producer asks before it writes the tensor in bf16.
+int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch) return 0;
+  PBwwArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.nsplit = 1; a.x_bf16 = 1;
+  return pbww_ws_bytes(a) > 0 ? 1 : 0;
+}
+
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW) {
   long need = bww_ws_core(N, Cin, Cout, ks, OH, OW);
   PBwwArgs a{};    // bf16 / split kernels: the input extent is not an argument here, so cover the convolution forms the path has
@@ -1965,6 +1990,17 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (co.x_bf16) {
+    AGL_REQUIRE(co.prec == 1 && co.patch, "agl_conv2d_bwd_weight: AGL_CONV_X_BF16 needs AGL_CONV_BF16 and the matrix-core kernel");
+    PBwwArgs a{};
+    a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
+    a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = 1; a.x_bf16 = 1;
+    a.dbias = dbias; a.dbias_accumulate = dbias_accumulate; a.dbias_done = dbias_done;
+    const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww, bf16 input)");
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_weight: AGL_CONV_X_BF16 on a shape the matrix-core kernel does not take (ask agl_conv2d_bwd_weight_takes_bf16_x)");
+    g_last_pipe = 1;
+    return prc;
+  }
   if (ks == 1 && H == 1 && W == 1 && OH == 1 && OW == 1 && pad == 0 && up_log2 == 0 && co.patch)      // nn.Linear (few.hip)
     return linear_bww_launch(dy, x, dw, N, Cin, Cout, in_relu, accumulate, (hipStream_t)stream, "agl_conv2d_bwd_weight(linear)");
   if (Cin <= 4) {      // RGB-side layers: rows = output channels, columns = (input channel, tap), exact fp32 (few.hip)

@@ -16,6 +16,7 @@ struct PConvArgs {
   const void* packed;               // optional: the weights already in packed form (pconv_pack / pconvT_pack with the same nsplit) — no
                                     // per-call pack_weights_k launch; the packed tensor w0 may differ from w by a scalar: w = w0 / *out_div
   const float* out_div;             // optional device scalar: the accumulated products are divided by it before bias / mask / ReLU
+  int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
 };
 // Packed form of a weight tensor for pconv_try (forward: flip 0, w_sm = Cin*ks*ks, w_sc = ks*ks; "same" input gradient: flip 1, roles
 // swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
@@ -54,6 +55,7 @@ struct PBwwArgs {
   const float* dy; const float* x; float* dw;
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up)
   int ks, stride, pad, up, in_relu, accumulate, nsplit;
+  int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
   float* dbias; int dbias_accumulate; int* dbias_done;    // optional: also (+= when dbias_accumulate) the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
 };
 long pbww_ws_bytes(const PBwwArgs& a);

@@ -37,6 +37,7 @@ struct PArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu, relu, accumulate;
   int nch, mpad;
   unsigned x_bytes;
+  int x_bf16;                // the input tensor is stored as bf16 (2-byte elements: a tensor only convolutions read, written by its producer in bf16)
   int xgy, xchunk, xitems;   // XCD-aware workgroup order (xchunk > 0): the grid is 1-D, see pconv_k
   float* stats;      // optional: per-channel (sum, sum of squares) of the stored outputs, one row per (pixel tile, wave column)
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 
   // ---- per-thread constants of the two staging passes (everything that does not depend on the stage is computed once;
   // the stage term is wave-uniform and travels in the scalar offset of the loads: no per-load vector arithmetic)
+  const unsigned esz = p.x_bf16 ? 2u : 4u;      // bytes per stored input element
   unsigned bsrc[BR];   // patch item e = (half h, image ti, row yy, column xx): byte offset of channel 8h, or OOB31
   int bdst[BR];        // LDS piece index h*NQ + q, or -1
 #pragma unroll
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     const int img = img0 + ti, ly = S * ty0 - pad_y + yy, lx = S * tx0 - pad_x + xx;
     const bool in = e < NB;
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-    bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
+    bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
     bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
   }
-  const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
+  const unsigned cstride = (unsigned)(p.H * p.W) * esz;
   unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
@@ -237,6 +239,14 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   u32x4 pa[AR];
   auto gload_b = [&](int c0) {
     if ((ABL & 8) && c0 != 16 * (p.slabs ? zsplit * p.cps : 0)) return;
+    if (p.x_bf16) {      // (a bf16 value is the upper half of its fp32 form: the conversion at the LDS store is then exact)
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          pb[r][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, bsrc[r], (unsigned)(c0 + j) * cstride, 0) << 16);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < BR; ++r)
 #pragma unroll
@@ -656,6 +666,7 @@ struct WArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, up, in_relu;
   int tiles, tiles_per_split;
   unsigned x_bytes, dy_bytes;
+  int x_bf16;             // x is stored as bf16 (see PArgs)
   int xgyz, xchunk, xitems, xgy;      // XCD-aware workgroup order (xchunk > 0): 1-D grid, see pbww_k
 };
 
@@ -702,7 +713,8 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   const int t_beg = bx * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
   const int Hl = p.H << p.up, Wl = p.W << p.up;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const unsigned cstride = (unsigned)(p.H * p.W) * 4u;
+  const unsigned esz = p.x_bf16 ? 2u : 4u;
+  const unsigned cstride = (unsigned)(p.H * p.W) * esz;
   const int tpr = p.OW / TW, tpi = TI == 1 ? (p.OH / TH) * tpr : 1;
 
   f32x4 acc[NACC][RT][CT][TSUB];
@@ -765,10 +777,16 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int ti = q / IMGP, r2 = q - ti * IMGP, yy = r2 / PW, xx = r2 - yy * PW;
       const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
       const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-      const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * 4u : OOB31;
+      const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
+      if (p.x_bf16) {
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj)
-        px[sl][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, (unsigned)jj * cstride, 0));
+        for (int jj = 0; jj < 8; ++jj)
+          px[sl][jj] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, off, (unsigned)jj * cstride, 0) << 16);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          px[sl][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, off, (unsigned)jj * cstride, 0));
+      }
     }
   };
   auto sstore_dy = [&](int r, int sl) {
@@ -1047,7 +1065,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
   }
-  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
+  p.x_bf16 = a.x_bf16;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
   pconv_xcd_order(p, g);
   if (!a.packed) {
@@ -1260,6 +1279,7 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
+  p.x_bf16 = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * 4);
   if (a.nsplit == 1) {
     dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
@@ -1339,6 +1359,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
+  p.x_bf16 = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
   pconv_xcd_order(p, g, geo == 3 ? 4 : 2);
@@ -1459,7 +1480,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
-  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
+  p.x_bf16 = a.x_bf16;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4)); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
   p.xgyz = 1; p.xchunk = 0; p.xitems = 0; p.xgy = 1;

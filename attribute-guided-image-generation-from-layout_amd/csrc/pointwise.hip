@@ -615,7 +615,8 @@ __global__ void box2_fwd_any_k(const float* __restrict__ x, float* __restrict__ 
 // One thread per four consecutive outputs of a row (W % 4 == 0): two 16-byte loads + two scalars in, four coalesced stores out
 // (the one-output-per-thread form ran at 2.4 TB/s: 65-float rows, four scalar loads per store).  Same addition order as before:
 // ((top-left + top-right) + bottom-left) + bottom-right.
-__global__ void box2_fwd_k(const float* __restrict__ x, float* __restrict__ xb, long NC, int H, int W) {
+template <typename OutT>       // float, or __bf16 (round to nearest even: the rounding the bf16-mode convolution applies when it stages a tensor)
+__global__ void box2_fwd_k(const float* __restrict__ x, OutT* __restrict__ xb, long NC, int H, int W) {
   const unsigned HB = H + 1, WB = W + 1, G = W / 4 + 1;
   const unsigned i = blockIdx.x * TPB + threadIdx.x;
   if (i >= (unsigned)(NC * HB * G)) return;
@@ -633,10 +634,10 @@ __global__ void box2_fwd_k(const float* __restrict__ x, float* __restrict__ xb, 
     if (ix0 > 0) bot[0] = r[-1];
     if (ix0 < (unsigned)W) { const float4 v = *reinterpret_cast<const float4*>(r); bot[1] = v.x; bot[2] = v.y; bot[3] = v.z; bot[4] = v.w; }
   }
-  float* o = xb + ((long)nc * HB + iy) * WB + ix0;
+  OutT* o = xb + ((long)nc * HB + iy) * WB + ix0;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (ix0 + k < WB) o[k] = 0.25f * (((top[k] + top[k + 1]) + bot[k]) + bot[k + 1]);
+    if (ix0 + k < WB) o[k] = (OutT)(0.25f * (((top[k] + top[k + 1]) + bot[k]) + bot[k + 1]));
 }
 // dx[j][i] = (dxb[j][i] + dxb[j][i+1] + dxb[j+1][i] + dxb[j+1][i+1]) / 4, optionally masked by mask > 0 (ReLU backward)
 __global__ void box2_bwd_k(const float* __restrict__ dxb, const float* __restrict__ mask, float* __restrict__ dx, long NC, int H, int W) {
@@ -949,9 +950,18 @@ int agl_deprocess_u8(const float* x, unsigned char* out, int N, int C, int HW, i
 
 int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream) {
   AGL_REQUIRE(x && xb && NC > 0 && H > 0 && W > 0 && NC * (H + 1) * (W + 1) < (1L << 31), "agl_box2_fwd: bad argument");
-  if (W % 4 == 0) LAUNCH1D(box2_fwd_k, NC * (H + 1) * (W / 4 + 1), x, xb, NC, H, W);
+  if (W % 4 == 0) LAUNCH1D(box2_fwd_k<float>, NC * (H + 1) * (W / 4 + 1), x, xb, NC, H, W);
   else LAUNCH1D(box2_fwd_any_k, NC * (H + 1) * (W + 1), x, xb, NC, H, W);
   AGL_CHECK_LAUNCH("agl_box2_fwd");
+  return AGL_OK;
+}
+
+// The same box filter written as bf16 (W % 4 == 0): for a consumer that is a bf16-mode convolution reading it with AGL_CONV_X_BF16
+// — the values are those the convolution would have rounded the fp32 tensor to when staging it, so the results are identical.
+int agl_box2_fwd_bf16(const float* x, void* xb, long NC, int H, int W, void* stream) {
+  AGL_REQUIRE(x && xb && NC > 0 && H > 0 && W > 0 && W % 4 == 0 && NC * (H + 1) * (W + 1) < (1L << 31), "agl_box2_fwd_bf16: bad argument");
+  LAUNCH1D(box2_fwd_k<__bf16>, NC * (H + 1) * (W / 4 + 1), x, (__bf16*)xb, NC, H, W);
+  AGL_CHECK_LAUNCH("agl_box2_fwd_bf16");
   return AGL_OK;
 }
 

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 3
+#define AGL_ABI_VERSION 4
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -58,6 +58,11 @@ const char* agl_last_error(void);
 #define AGL_CONV_PRIO 256 /* wave priority 1 for the conversion / LDS-store bursts of the patch kernels (A/B switch) */
 #define AGL_CONV_W8 128   /* eight-wave (512-thread) workgroups in the split-mode stride-1 3x3 / 5x5 patch kernels: same tile and LDS
                            * footprint, twice the waves per SIMD (A/B switch; the host mirror sets it where it measured faster) */
+#define AGL_CONV_X_BF16 (1 << 17) /* agl_conv2d_fwd / agl_conv2d_bwd_weight: x points to bf16 elements (same extents; 2 bytes each).  For a
+                           * tensor that only bf16-mode convolutions read and whose producer wrote it in bf16 (agl_box2_fwd_bf16): they
+                           * would round the fp32 tensor to these very values when staging it, so results are identical and the tensor
+                           * costs half the HBM traffic.  Needs AGL_CONV_BF16 and a shape the matrix-core kernels take
+                           * (agl_conv2d_fwd_packed_bytes != 0 / agl_conv2d_bwd_weight_takes_bf16_x); otherwise the call is rejected. */
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
@@ -96,6 +101,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
                         const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
                         int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
+int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
 /* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] = sum over (n, oh, ow) of dy, added to dbias
  * when dbias_accumulate (its own flag: a spectrally normalised layer returns dw fresh but accumulates db in place).  The
  * matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway; *dbias_done (host int) is 1 when the call did so
@@ -184,6 +190,8 @@ int agl_scatter_rows(const float* src, const long long* rows, float* out, long R
 /* 2x2 stride-1 box filter over the zero-extended map ((H+1) x (W+1) outputs): avg_pool2(conv3x3(x, pad 1)) is the 3x3
  * stride-2 unpadded convolution of it (models/discriminator.py:25-26,90-97 down-sampling blocks) */
 int agl_box2_fwd(const float* x, float* xb, long NC, int H, int W, void* stream);
+/* the same, written as bf16 (round to nearest even; W % 4 == 0) for a consumer that reads it with AGL_CONV_X_BF16 */
+int agl_box2_fwd_bf16(const float* x, void* xb, long NC, int H, int W, void* stream);
 int agl_box2_bwd(const float* dxb, const float* mask, float* dx, long NC, int H, int W, void* stream);
 /* y[nc][Y][X] = x[nc][map_y[Y]][map_x[X]] for monotone non-decreasing index maps (device int arrays of H / W entries);
  * backward sums dy over each source cell's preimage: lo_y / lo_x hold h+1 / w+1 range starts (lo[h] = H).  Nearest

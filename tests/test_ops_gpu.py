@@ -1186,3 +1186,36 @@ def test_bn_running_update_replay_single_and_batched():
     L.bn_running_update(mom, 0.1, *ref)
     for t1, t2 in zip(twice, ref):
         assert torch.equal(t1, t2)
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 32, 128), (3, 128, 16, 256), (210, 64, 64, 128), (9, 32, 8, 64), (2, 48, 64, 80)])
+def test_box_filtered_map_stored_as_bf16_gives_identical_results(shape):
+    """bf16 arithmetic (config 3): the box-filtered map of a down-sampling block is read by one convolution and its weight gradient
+    only; written as bf16 (agl_box2_fwd_bf16) and read with AGL_CONV_X_BF16 it holds exactly the values those kernels round the fp32
+    map to when they stage it — output, weight gradient and bias gradient must be bit-identical to the fp32-stored path, and the
+    tensor must really be bf16 where the matrix-core kernels take the layer."""
+    from agl import functional as F, lib as L
+    N, Cin, H, Cout = shape
+    x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5), rn(Cout, seed=2)
+    gy = rn(N, Cout, H // 2, H // 2, seed=3)
+    res = []
+    with L.conv_flags(L.CONV_BF16):
+        took = L.box_input_as_bf16(N, Cin, H + 1, H + 1, Cout, True)
+        for as16 in (True, False):
+            F.BOX_BF16 = as16
+            try:
+                xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+                y = F.conv3x3_avgpool2(xg, wg, bg)
+                saved = [t for t in y.grad_fn.saved_tensors if t is not None and t.shape[-1] == H + 1]
+                y.backward(dev(gy))
+            finally:
+                F.BOX_BF16 = True
+            res.append((y.detach(), wg.grad, bg.grad, xg.grad, saved[0].dtype))
+    assert res[1][4] == torch.float32
+    assert res[0][4] == (torch.bfloat16 if took else torch.float32)
+    for a_, b_, what in zip(res[0][:4], res[1][:4], ("y", "dw", "db", "dx")):
+        assert torch.equal(a_, b_), f"{what} differs between the bf16-stored and the fp32-stored map"
+    if shape[0] <= 9:
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        xb = TF.avg_pool2d(TF.pad(x, (1, 1, 1, 1)), 2, stride=1)
+        close(res[0][0], TF.conv2d(r(xb), r(w), b, stride=2), 3e-5, "y vs an fp32 convolution of the bf16-rounded operands")
