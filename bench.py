@@ -240,9 +240,10 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 k = (name.replace('agl_conv2d_', ''), dims)
                 agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1); agg[k][2] += f
             by_ms = os.environ.get("AGL_DUMP_SORT") == "ms"
-            rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] if by_ms else kv[1][1] - kv[1][2] / 157.3e9))
+            ref = float(os.environ.get("AGL_DUMP_REF_TF", "157.3")) * 1e9      # "lost" = time above what the launch would take at this rate
+            rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] if by_ms else kv[1][1] - kv[1][2] / ref))
             for (nm, dims), (cnt, ms, fl) in rows[:int(os.environ.get("AGL_DUMP_CONV_ROWS", "40"))]:
-                print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/157.3e9:6.2f} ms  dims {dims}', file=sys.stderr)
+                print(f'{nm:11s} x{cnt:3d} {ms:7.2f} ms  {fl/ms/1e9 if ms else 0:6.1f} TF  lost {ms - fl/ref:6.2f} ms  dims {dims}', file=sys.stderr)
         c0, c1 = FLOPS_PER_IMAGE[res]
         flops_step = per_gpu * c0 + O * c1                      # algorithmic (reference graph), per GPU per step
         # Utilisation of the pipes actually used: every convolution launch is priced against the peak of the pipe its main kernel
