@@ -1734,7 +1734,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
               "agl_conv2d_bwd_data: tensor too large (< 2^30 elements per operand)");
   hipStream_t st = (hipStream_t)stream;
   if (ks == 1 && IH == 1 && IW == 1 && OH == 1 && OW == 1 && pad == 0 && w && !bias && !relu && co.patch)      // nn.Linear (few.hip)
-    return linear_bwd_data_launch(dy, w, pos_mask, dx, N, Cin, Cout, accumulate, st, "agl_conv2d_bwd_data(linear)");
+    return linear_bwd_data_launch(dy, w, pos_mask, dx, N, Cin, Cout, accumulate, co.prec == 1, st, "agl_conv2d_bwd_data(linear)");
   if (Cin <= 4 && stride == 1 && IH == OH && IW == OW && w && co.patch && (co.prec == 1 || co.split3)) {
     PVertArgs v{dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu, accumulate, co.prec == 1 ? 1 : 3};
     const int vrc = pconv_vert_try(v, ws, ws_bytes, st, "agl_conv2d_bwd_data(vertical + diagonal)");
@@ -2002,7 +2002,7 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
     return prc;
   }
   if (ks == 1 && H == 1 && W == 1 && OH == 1 && OW == 1 && pad == 0 && up_log2 == 0 && co.patch)      // nn.Linear (few.hip)
-    return linear_bww_launch(dy, x, dw, N, Cin, Cout, in_relu, accumulate, (hipStream_t)stream, "agl_conv2d_bwd_weight(linear)");
+    return linear_bww_launch(dy, x, dw, N, Cin, Cout, in_relu, accumulate, co.prec == 1, (hipStream_t)stream, "agl_conv2d_bwd_weight(linear)");
   if (Cin <= 4) {      // RGB-side layers: rows = output channels, columns = (input channel, tap), exact fp32 (few.hip)
     const FewBwwShape f{N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up_log2, in_relu};
     int fsplits = 0;

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
 // serially (75 us for the 393 x 64 -> 2048 weight gradient, 100 MFLOP).  Here: one output element per thread, the reduction index
 // innermost, the operand that varies along the wave read coalesced and the other one as a wave-uniform value.  Exact fp32, fixed order.
 // dw[co][ci] (+)= sum_n dy[n][co] * x[n][ci]
+// (rb: bf16 arithmetic mode — both operands are rounded to bf16 first, as every kernel of that mode does)
 __global__ __launch_bounds__(256) void linear_bww_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int N,
-                                                    int Cin, int Cout, int in_relu, int accumulate) {
+                                                    int Cin, int Cout, int in_relu, int accumulate, int rb) {
+  auto op = [&](float v) { return rb ? (float)(__bf16)v : v; };
   const int ci = blockIdx.x * 64 + (threadIdx.x & 63), co = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (co >= Cout) return;                         // (wave-uniform)
   const bool ok = ci < Cin;
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(256) void linear_bww_k(const float* __restrict__ dy
   for (; n + 4 <= N; n += 4) {
     float x0 = xp[(long)n * Cin], x1 = xp[(long)(n + 1) * Cin], x2 = xp[(long)(n + 2) * Cin], x3 = xp[(long)(n + 3) * Cin];
     if (in_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
-    a0 = fmaf(dp[(long)n * Cout], x0, a0); a1 = fmaf(dp[(long)(n + 1) * Cout], x1, a1);
-    a2 = fmaf(dp[(long)(n + 2) * Cout], x2, a2); a3 = fmaf(dp[(long)(n + 3) * Cout], x3, a3);
+    a0 = fmaf(op(dp[(long)n * Cout]), op(x0), a0); a1 = fmaf(op(dp[(long)(n + 1) * Cout]), op(x1), a1);
+    a2 = fmaf(op(dp[(long)(n + 2) * Cout]), op(x2), a2); a3 = fmaf(op(dp[(long)(n + 3) * Cout]), op(x3), a3);
   }
   for (; n < N; ++n) {
     float x0 = xp[(long)n * Cin];
     if (in_relu) x0 = fmaxf(x0, 0.f);
-    a0 = fmaf(dp[(long)n * Cout], x0, a0);
+    a0 = fmaf(op(dp[(long)n * Cout]), op(x0), a0);
   }
   if (!ok) return;
   const float v = (a0 + a1) + (a2 + a3);
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(256) void linear_bww_k(const float* __restrict__ dy
 
 // dx[n][ci] (+)= sum_co dy[n][co] * w[co][ci], zeroed where pos_mask <= 0
 __global__ __launch_bounds__(256) void linear_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ pos_mask,
-                                                         float* __restrict__ dx, int N, int Cin, int Cout, int accumulate) {
+                                                         float* __restrict__ dx, int N, int Cin, int Cout, int accumulate, int rb) {
+  auto op = [&](float v) { return rb ? (float)(__bf16)v : v; };
   const int ci = blockIdx.x * 64 + (threadIdx.x & 63), n = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (n >= N) return;                             // (wave-uniform)
   const bool ok = ci < Cin;
@@ -268,10 +271,10 @@ __global__ __launch_bounds__(256) void linear_bwd_data_k(const float* __restrict
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int co = 0;
   for (; co + 4 <= Cout; co += 4) {
-    a0 = fmaf(dp[co], wp[(long)co * Cin], a0); a1 = fmaf(dp[co + 1], wp[(long)(co + 1) * Cin], a1);
-    a2 = fmaf(dp[co + 2], wp[(long)(co + 2) * Cin], a2); a3 = fmaf(dp[co + 3], wp[(long)(co + 3) * Cin], a3);
+    a0 = fmaf(op(dp[co]), op(wp[(long)co * Cin]), a0); a1 = fmaf(op(dp[co + 1]), op(wp[(long)(co + 1) * Cin]), a1);
+    a2 = fmaf(op(dp[co + 2]), op(wp[(long)(co + 2) * Cin]), a2); a3 = fmaf(op(dp[co + 3]), op(wp[(long)(co + 3) * Cin]), a3);
   }
-  for (; co < Cout; ++co) a0 = fmaf(dp[co], wp[(long)co * Cin], a0);
+  for (; co < Cout; ++co) a0 = fmaf(op(dp[co]), op(wp[(long)co * Cin]), a0);
   if (!ok) return;
   float v = (a0 + a1) + (a2 + a3);
   const long o = (long)n * Cin + ci;
@@ -344,16 +347,18 @@ int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y,
   return AGL_OK;
 }
 
-int linear_bww_launch(const float* dy, const float* x, float* dw, int N, int Cin, int Cout, int in_relu, int accumulate, hipStream_t st,
-                      const char* name) {
-  hipLaunchKernelGGL(linear_bww_k, dim3(agl_cdiv(Cin, 64), agl_cdiv(Cout, 4)), dim3(256), 0, st, dy, x, dw, N, Cin, Cout, in_relu, accumulate);
+int linear_bww_launch(const float* dy, const float* x, float* dw, int N, int Cin, int Cout, int in_relu, int accumulate, int round_bf16,
+                      hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(linear_bww_k, dim3(agl_cdiv(Cin, 64), agl_cdiv(Cout, 4)), dim3(256), 0, st, dy, x, dw, N, Cin, Cout, in_relu, accumulate,
+                     round_bf16);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
 
 int linear_bwd_data_launch(const float* dy, const float* w, const float* pos_mask, float* dx, int N, int Cin, int Cout, int accumulate,
-                           hipStream_t st, const char* name) {
-  hipLaunchKernelGGL(linear_bwd_data_k, dim3(agl_cdiv(Cin, 64), agl_cdiv(N, 4)), dim3(256), 0, st, dy, w, pos_mask, dx, N, Cin, Cout, accumulate);
+                           int round_bf16, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(linear_bwd_data_k, dim3(agl_cdiv(Cin, 64), agl_cdiv(N, 4)), dim3(256), 0, st, dy, w, pos_mask, dx, N, Cin, Cout, accumulate,
+                     round_bf16);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
