@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
+from . import lib as L
 from . import nn as A
 
 
@@ -65,8 +66,16 @@ class OptimizedBlock(nn.Module):
             h, s = _fork(x, c1, w1, False)
             h = F.conv3x3_avgpool2(h, c2.weight if w2 is None else w2, c2.bias, x_relu=True)
         else:
-            h = c1(x, relu=True, relu_grad_by_consumer=True, weight=w1)
-            h = c2(h, x_relu=True, weight=w2)
+            # bf16 arithmetic: h = relu(c1(x)) feeds c2 only — the two convolutions as one graph node, h stored as bf16 inside it
+            # (F.conv_relu_conv3x3) where the kernels that run can write / read that form
+            N, C0, H, Wd = x.shape
+            wa, wb = (w1 if w1 is not None else c1.weight), (w2 if w2 is not None else c2.weight)
+            if F.H_BF16 and L.first_conv_output_as_bf16(N, C0, H, Wd, c1.out_channels, c2.out_channels, c1.kernel_size[0],
+                                                        need_bww=wb.requires_grad, need_bwd_data=True):
+                h = F.conv_relu_conv3x3(x, wa, c1.bias, wb, c2.bias, c1.padding[0], h_bf16=True)
+            else:
+                h = c1(x, relu=True, relu_grad_by_consumer=True, weight=w1)
+                h = c2(h, x_relu=True, weight=w2)
             s = x
         return self.sc(s, addend=h, weight=_w(W, self.sc))
 

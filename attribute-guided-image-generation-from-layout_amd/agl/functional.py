@@ -221,6 +221,50 @@ def conv2d_and_avg_pool2(x, w, bias=None, padding=1, in_relu=False, relu=False, 
     return _ConvPoolFork.apply(x, w, bias, padding, in_relu, relu, relu_grad_by_consumer)
 
 
+class _ConvReluConv(torch.autograd.Function):
+    """y = conv3x3(relu(conv_k(x, w1, b1)), w2, b2), both stride 1 / "same" (the residual branch of a discriminator block without
+    down-sampling, reference discriminator.py:36-40) as ONE graph node, so that the intermediate h = relu(conv_k(x)) never is an
+    autograd edge: in bf16 arithmetic it is then stored as bf16 (an edge of that dtype would have its gradient cast to bf16 by
+    autograd).  h is read by the second convolution only — forward, the x operand of its weight gradient, the ReLU mask of its input
+    gradient — which rounds it to bf16 when staging it anyway: identical results at half the traffic on that tensor.
+    The same launches as two conv2d nodes with relu_grad_by_consumer / x_relu otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, pad1, h_bf16):
+        global _LAST_STATS
+        _LAST_STATS = None
+        ctx.slots = (_slot(w1), _slot(b1), _slot(w2), _slot(b2))
+        ctx.wsrcs = (getattr(w1, "_agl_wsrc", None), getattr(w2, "_agl_wsrc", None))
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        h = L.conv2d_fwd(x, w1, b1, 1, pad1, 0, False, True, wsrc=ctx.wsrcs[0], out_bf16=h_bf16)
+        y = L.conv2d_fwd(h, w2, b2, 1, 1, wsrc=ctx.wsrcs[1])
+        ctx.cfg = (pad1, b1 is not None, b2 is not None)
+        ctx.save_for_backward(x, w1, w2, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pad1, has_b1, has_b2 = ctx.cfg
+        x, w1, w2, h = ctx.saved_tensors
+        dy = _c(dy)
+        need = ctx.needs_input_grad
+        dx = None
+        dh = None
+        if need[0] or need[1] or (has_b1 and need[2]):
+            dh = L.conv2d_bwd_data(dy, w2, (h.shape[2], h.shape[3]), 1, 1, pos_mask=h, wsrc=ctx.wsrcs[1])
+        dw2, db2 = _conv_param_grads(ctx.slots[2:], need[3], has_b2 and need[4], dy, h, w2, 1, 1, 0, False)
+        dw1 = db1 = None
+        if dh is not None:
+            if need[0]:
+                dx = L.conv2d_bwd_data(dh, w1, (x.shape[2], x.shape[3]), 1, pad1, wsrc=ctx.wsrcs[0])
+            dw1, db1 = _conv_param_grads(ctx.slots[:2], need[1], has_b1 and need[2], dh, x, w1, 1, pad1, 0, False)
+        return dx, dw1, db1, dw2, db2, None, None
+
+
+def conv_relu_conv3x3(x, w1, b1, w2, b2, pad1, h_bf16=False):
+    return _ConvReluConv.apply(x, w1, b1, w2, b2, pad1, h_bf16)
+
+
 def linear(x, w, bias=None, relu=False):
     """nn.Linear as a 1x1 convolution over (rows, features, 1, 1)."""
     y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), bias, relu=relu)
@@ -642,6 +686,7 @@ class _Conv3x3AvgPool(torch.autograd.Function):
 
 
 BOX_BF16 = os.environ.get("AGL_BOX_BF16", "1") != "0"      # A/B switch: 0 keeps the box-filtered maps in fp32 in bf16 mode
+H_BF16 = os.environ.get("AGL_H_BF16", "1") != "0"          # ... and the first-convolution output of a flat discriminator block
 BOX_FORM = os.environ.get("AGL_BOX_FORM", "1") != "0"     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
 BOX_BWD = os.environ.get("AGL_BOX_BWD", "0") == "1"   # input gradient through the 3x3/stride-2 phases + box transpose
 BOX_BWD_MIN = int(os.environ.get("AGL_BOX_BWD_MIN", "16"))   # ... used from this map size up (measured: 0.24 vs 0.34 ms at

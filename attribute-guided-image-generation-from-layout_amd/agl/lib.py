@@ -60,6 +60,7 @@ SIGNATURES = {
     "agl_box2_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
     "agl_box2_fwd_bf16": (_I, [_P, _P, _L, _I, _I, _P]),
     "agl_conv2d_bwd_weight_takes_bf16_x": (_I, [_I] * 11),
+    "agl_conv2d_bwd_data_takes_bf16_mask": (_I, [_I] * 11),
     "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
@@ -153,6 +154,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_W8, CONV_PRIO = 128, 256
 CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
+CONV_Y_BF16, CONV_MASK_BF16 = 1 << 18, 1 << 19      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
 CONV_FLAGS = 0
 
 
@@ -356,23 +358,26 @@ def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up):
     return wsrc.packed(0, nb, w, Cin, Cout, ks, stride), wsrc.div
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None):
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None, out_bf16=False):
+    """out_bf16: y as a torch.bfloat16 tensor (first_conv_output_as_bf16 says when the kernel that runs can write it)."""
     N, Cin, H, W = x.shape
     Cout, Cin_w, ks, ks2 = w.shape
     assert Cin_w == Cin and ks == ks2, (x.shape, w.shape)
     OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
     if out is None:
         assert not accumulate
-        out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     else:
         assert tuple(out.shape) == (N, Cout, OH, OW)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up) if not (relu and accumulate) else (None, None)
     xb16 = x.dtype == torch.bfloat16      # a tensor its producer wrote in bf16 (box2_fwd(bf16=True)): matrix-core kernel only
+    yb16 = out.dtype == torch.bfloat16
     call("agl_conv2d_fwd", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
-         ptr(out), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up,
-         int(in_relu), int(relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0), stream())
+         ptr(out, out.dtype if yb16 else torch.float32), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+         N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), int(relu), int(accumulate),
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0), stream())
     return out
 
 
@@ -460,9 +465,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
             pk, pdiv = wsrc.packed(1, nb, w, Cin, Cout, ks, stride, make=make_base), wsrc.div
     if w is None and pk is None:
         w = make_w()
-    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None, ptr(pos_mask), ptr(out),
+    mb16 = pos_mask is not None and pos_mask.dtype == torch.bfloat16
+    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None,
+         ptr(pos_mask, torch.bfloat16 if mb16 else torch.float32), ptr(out),
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad,
-         0, int(accumulate), CONV_FLAGS, stream())
+         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0), stream())
     return out
 
 
@@ -600,6 +607,22 @@ def box2_fwd(x, bf16=False):
     xb = torch.empty((N, Cc, H + 1, W + 1), dtype=torch.float32, device=x.device)
     call("agl_box2_fwd", ptr(x), ptr(xb), N * Cc, H, W, stream())
     return xb
+
+
+def first_conv_output_as_bf16(N, Cin0, H, W, C, Cout, ks0, need_bww, need_bwd_data):
+    """True when h = relu(conv_ks0(x (N, Cin0 <= 4, H, W) -> C channels)), consumed only by a 3x3 / stride-1 / pad-1 convolution
+    C -> Cout (forward, weight gradient, and — as the ReLU mask — its input gradient), can be stored as bf16 in bf16 arithmetic with
+    identical results: the few-input-channel stream kernel writes it, the matrix-core kernels read it."""
+    if not (CONV_FLAGS & CONV_BF16) or (CONV_FLAGS & CONV_NO_PATCH) or Cin0 > 4 or W % 4 != 0 or ks0 not in (1, 3):
+        return False
+    lib = load()
+    if not lib.agl_conv2d_fwd_packed_bytes(N, C, H, W, Cout, 3, 1, 1, 0, CONV_FLAGS):
+        return False
+    if need_bww and not lib.agl_conv2d_bwd_weight_takes_bf16_x(N, C, H, W, Cout, H, W, 3, 1, 1, CONV_FLAGS):
+        return False
+    if need_bwd_data and not lib.agl_conv2d_bwd_data_takes_bf16_mask(N, C, H, W, Cout, H, W, 3, 1, 1, CONV_FLAGS):
+        return False
+    return True
 
 
 def box_input_as_bf16(N, Cin, H, W, Cout, need_bww):

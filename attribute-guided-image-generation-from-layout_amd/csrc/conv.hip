@@ -987,6 +987,8 @@ struct ConvOpts {
   int prio;          // start stagger of the co-resident workgroups of the LDS-patch kernels (0 off, 1..4: delay length)
   int ablate;        // diagnostic kernel builds (flags bits 9..11; results are wrong by construction)
   bool x_bf16;       // AGL_CONV_X_BF16 (1 << 17): the input tensor x holds bf16 elements (bf16 arithmetic, matrix-core kernels only)
+  bool y_bf16;       // AGL_CONV_Y_BF16 (1 << 18): agl_conv2d_fwd writes y as bf16 (few-input-channel stream kernel only)
+  bool mask_bf16;    // AGL_CONV_MASK_BF16 (1 << 19): agl_conv2d_bwd_data reads pos_mask as bf16 ("same" patch kernel without a reduction split)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -1002,9 +1004,11 @@ static ConvOpts conv_opts(int flags) {
   o.prio = (flags >> 14) & 7;
   o.ablate = (flags >> 9) & 31;
   o.x_bf16 = (flags & (1 << 17)) != 0;
+  o.y_bf16 = (flags & (1 << 18)) != 0;
+  o.mask_bf16 = (flags & (1 << 19)) != 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0, false, false, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1627,9 +1631,11 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
                              "agl_conv2d_fwd(small Cout)");
   if (Cin <= 4 && Cout >= 16 && stride == 1 && up_log2 == 0 && OH == H && OW == W && w && co.patch) {
     // few input channels, 1x1 / 3x3: a stream over the output (few.hip; exact fp32 on the vector units in every arithmetic mode)
-    const int frc = few_cin_fwd_try(x, w, bias, y, N, Cin, H, W, Cout, ks, in_relu, relu, accumulate, st, "agl_conv2d_fwd(few input channels)");
+    const int frc = few_cin_fwd_try(x, w, bias, y, N, Cin, H, W, Cout, ks, in_relu, relu, accumulate, co.y_bf16, st,
+                                    "agl_conv2d_fwd(few input channels)");
     if (frc >= 0) return frc;
   }
+  AGL_REQUIRE(!co.y_bf16, "agl_conv2d_fwd: AGL_CONV_Y_BF16 on a call the few-input-channel stream kernel does not take");
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -1743,15 +1749,19 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
   if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18) && w)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
+  if (co.mask_bf16)
+    AGL_REQUIRE(stride == 1 && co.patch && IH == OH && IW == OW && co.prec == 1 && pos_mask && Cin > 4 && !(relu && accumulate),
+                "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 needs the stride-1 patch kernel in bf16 arithmetic (ask agl_conv2d_bwd_data_takes_bf16_mask)");
   if (stride == 1 && co.patch && IH == OH && IW == OW && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a{};    // "same" convolution: dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = co.mask_bf16;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  AGL_REQUIRE(!co.mask_bf16, "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 on a shape the patch kernel does not take without a reduction split");
   g_last_pipe = co.prec;
   if (stride == 1)
     AGL_REQUIRE(w, "agl_conv2d_bwd_data: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
@@ -1915,6 +1925,17 @@ static bool bww_swapped(int Cin, int Cout, int stride, int up, int in_relu) {
 }
 
 static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW);
+// 1 when agl_conv2d_bwd_data with AGL_CONV_BF16 runs these extents on the stride-1 patch kernel without a reduction split — the
+// launch that can read pos_mask as bf16 (AGL_CONV_MASK_BF16).
+int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || stride != 1 || IH != OH || IW != OW || Cin <= 4) return 0;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad;
+  a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = 1; a.any_grid = co.any_grid;
+  return pconv_plan_splits(a) == 1 ? 1 : 0;
+}
+
 // 1 when agl_conv2d_bwd_weight with AGL_CONV_BF16 runs these extents on the matrix-core kernel — the only one that reads a bf16 x
 // (AGL_CONV_X_BF16); a producer asks before it writes the tensor in bf16.
 int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {

@@ -171,7 +171,9 @@ struct FewCinArgs {
   int N, Cin, H, W, Cout, in_relu, relu, accumulate;
 };
 
-template <int KS, int CIN>
+// OutT = __bf16: the output is written as bf16 (round to nearest even) for a consumer that is a bf16-mode convolution reading it with
+// AGL_CONV_X_BF16 / AGL_CONV_MASK_BF16 (no accumulation onto it in that form).
+template <int KS, int CIN, typename OutT>
 __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
   constexpr int KK = KS * KS, PADK = KS / 2, NW = CIN * KK;
   extern __shared__ __attribute__((aligned(16))) float lw[];       // [Cout][NW] (+ bias [Cout])
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
         xin[c][r][0] = l; xin[c][r][5] = rr;
       }
     }
-  float* const yb = p.y + (long)n * p.Cout * HW + (long)iy * p.W + ix0;
+  OutT* const yb = reinterpret_cast<OutT*>(p.y) + (long)n * p.Cout * HW + (long)iy * p.W + ix0;
   for (int co = 0; co < p.Cout; ++co) {
     const float* wc = lw + co * NW;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -218,10 +220,16 @@ __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
         }
     const float bb = lb[co];
     float4 v = {a0 + bb, a1 + bb, a2 + bb, a3 + bb};
-    float4* dst = reinterpret_cast<float4*>(yb + (long)co * HW);
-    if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *dst = v;
+    if constexpr (sizeof(OutT) == 4) {
+      float4* dst = reinterpret_cast<float4*>(yb + (long)co * HW);
+      if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *dst = v;
+    } else {
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<bf16x4_t*>(yb + (long)co * HW) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    }
   }
 }
 
@@ -332,14 +340,18 @@ int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws,
 
 // Forward with <= 4 input channels (see few_cin_fwd_k).  -1: shape not taken.
 int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int ks, int in_relu,
-                    int relu, int accumulate, hipStream_t st, const char* name) {
-  if (!(ks == 1 || ks == 3) || Cin < 1 || Cin > 4 || W % 4 != 0 || (relu && accumulate)) return -1;
+                    int relu, int accumulate, int y_bf16, hipStream_t st, const char* name) {
+  if (!(ks == 1 || ks == 3) || Cin < 1 || Cin > 4 || W % 4 != 0 || (relu && accumulate) || (y_bf16 && accumulate)) return -1;
   const long lds = ((long)Cout * Cin * ks * ks + Cout) * 4;
   if (lds > 48 * 1024) return -1;
   if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
   FewCinArgs p{x, w, bias, y, N, Cin, H, W, Cout, in_relu, relu, accumulate};
   const dim3 g((unsigned)agl_cdiv((long)N * H * (W / 4), 256));
-#define FC_LAUNCH(KS_, C_) hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_>), g, dim3(256), (size_t)lds, st, p)
+#define FC_LAUNCH(KS_, C_)                                                                                       \
+  do {                                                                                                          \
+    if (y_bf16) hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_, __bf16>), g, dim3(256), (size_t)lds, st, p);       \
+    else hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_, float>), g, dim3(256), (size_t)lds, st, p);               \
+  } while (0)
   if (ks == 1) { if (Cin == 1) FC_LAUNCH(1, 1); else if (Cin == 2) FC_LAUNCH(1, 2); else if (Cin == 3) FC_LAUNCH(1, 3); else FC_LAUNCH(1, 4); }
   else { if (Cin == 1) FC_LAUNCH(3, 1); else if (Cin == 2) FC_LAUNCH(3, 2); else if (Cin == 3) FC_LAUNCH(3, 3); else FC_LAUNCH(3, 4); }
 #undef FC_LAUNCH

@@ -17,6 +17,7 @@ struct PConvArgs {
                                     // per-call pack_weights_k launch; the packed tensor w0 may differ from w by a scalar: w = w0 / *out_div
   const float* out_div;             // optional device scalar: the accumulated products are divided by it before bias / mask / ReLU
   int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
+  int mask_bf16;                    // pos_mask points to bf16 elements (AGL_CONV_MASK_BF16; launches without a reduction split only)
 };
 // Packed form of a weight tensor for pconv_try (forward: flip 0, w_sm = Cin*ks*ks, w_sc = ks*ks; "same" input gradient: flip 1, roles
 // swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
@@ -31,6 +32,8 @@ long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
 long pconv_ws_bytes_split(int Cin, int Cout, int ks, int nsplit, long out_numel);
 // True when pconv_try would launch for these extents (given enough workspace).
 bool pconv_eligible(const PConvArgs& a);
+// Reduction splits pconv_try would use for these extents (1: none), -1 when the shape is not eligible.
+int pconv_plan_splits(const PConvArgs& a);
 // Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.
 int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
 

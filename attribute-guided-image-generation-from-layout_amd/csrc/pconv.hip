@@ -38,6 +38,7 @@ struct PArgs {
   int nch, mpad;
   unsigned x_bytes;
   int x_bf16;                // the input tensor is stored as bf16 (2-byte elements: a tensor only convolutions read, written by its producer in bf16)
+  int mask_bf16;             // pos_mask points to bf16 elements (plain epilogue without a reduction split only)
   int xgy, xchunk, xitems;   // XCD-aware workgroup order (xchunk > 0): the grid is 1-D, see pconv_k
   float* stats;      // optional: per-channel (sum, sum of squares) of the stored outputs, one row per (pixel tile, wave column)
   float* slabs;      // optional reduction split: blockIdx.z takes `cps` channel chunks and writes its raw partial output to slab z
@@ -532,7 +533,17 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
           old[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(p.y + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      if (p.pos_mask) {
+      if (p.pos_mask && p.mask_bf16) {      // (bf16 -> fp32 is a shift: sign and zero are those of the stored value)
+        const unsigned short* const mk = reinterpret_cast<const unsigned short*>(p.pos_mask);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = mb + 8 * ps;
+          uint2 b = {0u, 0u};
+          if (m < p.Cout && img < p.N) b = *reinterpret_cast<const uint2*>(mk + pbase + (long)m * OHW);
+          msk[ps] = float4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                           __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+        }
+      } else if (p.pos_mask) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
@@ -1017,6 +1028,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 }
 
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
+int pconv_plan_splits(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0 ? pl.splits : -1; }
 long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
 
 #ifndef AGL_PCONV_XCD
@@ -1065,7 +1077,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
   }
-  p.x_bf16 = a.x_bf16;
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
+  if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
   pconv_xcd_order(p, g);
@@ -1279,7 +1292,7 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
-  p.x_bf16 = 0;
+  p.x_bf16 = 0; p.mask_bf16 = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * 4);
   if (a.nsplit == 1) {
     dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
@@ -1359,7 +1372,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
-  p.x_bf16 = 0;
+  p.x_bf16 = 0; p.mask_bf16 = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
   pconv_xcd_order(p, g, geo == 3 ? 4 : 2);

@@ -63,6 +63,10 @@ const char* agl_last_error(void);
                            * would round the fp32 tensor to these very values when staging it, so results are identical and the tensor
                            * costs half the HBM traffic.  Needs AGL_CONV_BF16 and a shape the matrix-core kernels take
                            * (agl_conv2d_fwd_packed_bytes != 0 / agl_conv2d_bwd_weight_takes_bf16_x); otherwise the call is rejected. */
+#define AGL_CONV_Y_BF16 (1 << 18) /* agl_conv2d_fwd: y points to bf16 elements (round to nearest even; no accumulate) — only the few-input-
+                           * channel stream kernel (Cin <= 4, 1x1 / 3x3, stride 1, W % 4 == 0) writes that form; otherwise rejected */
+#define AGL_CONV_MASK_BF16 (1 << 19) /* agl_conv2d_bwd_data: pos_mask points to bf16 elements (the bf16-stored output of the producer
+                           * whose ReLU backward this call applies); needs agl_conv2d_bwd_data_takes_bf16_mask(...) == 1 */
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
 long agl_conv2d_bwd_data_ws_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad);
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel);
@@ -102,6 +106,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
                         int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream);
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
 int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
 /* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] = sum over (n, oh, ow) of dy, added to dbias
  * when dbias_accumulate (its own flag: a spectrally normalised layer returns dw fresh but accumulates db in place).  The
  * matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway; *dbias_done (host int) is 1 when the call did so

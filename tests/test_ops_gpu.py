@@ -1219,3 +1219,34 @@ def test_box_filtered_map_stored_as_bf16_gives_identical_results(shape):
         r = lambda t: t.to(torch.bfloat16).to(torch.float32)
         xb = TF.avg_pool2d(TF.pad(x, (1, 1, 1, 1)), 2, stride=1)
         close(res[0][0], TF.conv2d(r(xb), r(w), b, stride=2), 3e-5, "y vs an fp32 convolution of the bf16-rounded operands")
+
+
+@pytest.mark.parametrize("N", [16, 40])
+def test_flat_block_first_conv_output_stored_as_bf16_gives_identical_results(N):
+    """bf16 arithmetic: in a discriminator block without down-sampling (reference discriminator.py:29-60, 128 px object / attribute
+    discriminators) h = relu(c1(x)) is read by c2 only — as its input, as the x operand of its weight gradient and as the ReLU mask
+    of its input gradient.  Stored as bf16 (AGL_CONV_Y_BF16 -> AGL_CONV_X_BF16 / AGL_CONV_MASK_BF16) it holds the values c2 rounds it
+    to anyway: output and every gradient must be bit-identical to the fp32-stored path."""
+    from agl import functional as F, lib as L
+    from agl.discriminator import OptimizedBlock
+    torch.manual_seed(3)
+    blk = OptimizedBlock(3, 64, downsample=False).to(DEV)
+    x = rn(N, 3, 64, 64)
+    gy = rn(N, 64, 64, 64, seed=4)
+    res = []
+    with L.conv_flags(L.CONV_BF16):
+        took = L.first_conv_output_as_bf16(N, 3, 64, 64, 64, 64, 3, True, True)
+        for h16 in (True, False):
+            F.H_BF16 = h16
+            try:
+                for p_ in blk.parameters():
+                    p_.grad = None
+                xg = dev(x).requires_grad_(True)
+                y = blk(xg)
+                y.backward(dev(gy))
+            finally:
+                F.H_BF16 = True
+            res.append([y.detach().clone(), xg.grad.clone()] + [p_.grad.clone() for p_ in blk.parameters()])
+    assert took, "the 64 -> 64 layer at this size is expected on the matrix-core kernels"
+    for k, (a_, b_) in enumerate(zip(res[0], res[1])):
+        assert torch.equal(a_, b_), f"tensor {k} differs between the bf16-stored and the fp32-stored h"
