@@ -1458,12 +1458,11 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   //  workgroups it removes were hiding the longer matrix segments.)
   const long zcap = std::max(4L, operand_bytes / (slab_bytes * (a.nsplit == 1 ? AGL_PBWW_ZCAP_DIV_BF16 : 1)));
   long blocks = (long)agl_cdiv(a.Cout, 64 * *rt) * (a.Cin / (16 * *ct)) * npass;
-#ifndef AGL_PBWW_WGS_BF16
-#define AGL_PBWW_WGS_BF16 512
-#endif
-  // ~3 workgroups per CU: enough to fill the chip without piling up slabs — 2 per CU in bf16 mode, where the kernel is memory-bound
-  // and every further split is slab traffic (128 px step with 1024 / 768 / 512 / 384 / 256: 264-265 / 262-267 / 267-272 / 257-264 / 258-259)
-  const long wgs = a.nsplit == 1 ? AGL_PBWW_WGS_BF16 : 768;
+  // Two workgroups per CU — what the kernel's register budget keeps resident (__launch_bounds__(NT, 2)): one full round of
+  // workgroups, no partial second round, and every further split would be slab traffic.  (Target 1024 / 768 / 640 / 512 / 384 / 256:
+  // 128 px bf16 step 264-265 / 262-267 / - / 267-272 / 257-264 / 258-259 images/s; 64 px split-mode step 481-486 / 481-483 / 477 /
+  // 485-492 / 474-478 / -.)
+  const long wgs = 512;
   long z = std::min((wgs + blocks - 1) / blocks, zcap);
   if (blocks >= 384) z = 1;      // the channel blocks alone fill the chip: one split writes dw directly (no slab pass over a large tensor)
   if (blocks * z < 256 && (*rt > 1 || *ct > 1)) {
