@@ -120,6 +120,7 @@ class Trainer:
             net.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.finish())
             net.register_forward_pre_hook(lambda module, args: None if self._in_step else self.finish())
         self.raw = torch.zeros(len(RAW), dtype=torch.float32, device=dev)
+        self._keep = {}
         self._d_ready = None
         self._g_ready = None
         self.on_d_backward = None        # optional test probes, called after backward and before Adam
@@ -370,8 +371,11 @@ class Trainer:
             self._d_ready = None
             self.flat_g.zero_grad()
             heads, grads = [], []
-            keep = torch.ones(N, dtype=torch.float32, device=self.dev)
-            keep[:n_swap] = 0                                              # :284
+            keep = self._keep.get(N)                                       # (constant per batch size: built once, two launches less per step)
+            if keep is None:
+                keep = torch.ones(N, dtype=torch.float32, device=self.dev)
+                keep[:n_swap] = 0                                          # :284
+                self._keep[N] = keep
             term(img_rec, LS.l1_rows(img_rec, b["imgs"], keep, lam["img_rec"], float(N - n_swap), self._slot("g_img_rec")))
             term(z_rand_rec, LS.l1_rows(z_rand_rec, b["z"], None, lam["z_rec"] * 0.5, 1.0, self._slot("g_z_rand")))
             term(z_rand_shift, LS.l1_rows(z_rand_shift, b["z"], None, lam["z_rec"] * 0.5, 1.0, self._slot("g_z_shift")))
