@@ -267,24 +267,30 @@ __global__ __launch_bounds__(256) void linear_bww_k(const float* __restrict__ dy
   *o = accumulate ? *o + v : v;
 }
 
-// dx[n][ci] (+)= sum_co dy[n][co] * w[co][ci], zeroed where pos_mask <= 0
+// dx[n][ci] (+)= sum_co dy[n][co] * w[co][ci], zeroed where pos_mask <= 0.  One workgroup per (row n, 64 input features): the
+// output count is small (N x Cin) and the reduction long (Cout up to 2048), so the four waves take a quarter of the output features
+// each and their partial sums are added through LDS in wave order.
 __global__ __launch_bounds__(256) void linear_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ pos_mask,
                                                          float* __restrict__ dx, int N, int Cin, int Cout, int accumulate, int rb) {
+  __shared__ float part[4][64];
   auto op = [&](float v) { return rb ? (float)(__bf16)v : v; };
-  const int ci = blockIdx.x * 64 + (threadIdx.x & 63), n = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;                             // (wave-uniform)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 64 + lane, n = blockIdx.y;
   const bool ok = ci < Cin;
   const float* wp = w + (ok ? ci : 0);
   const float* dp = dy + (long)n * Cout;
+  const int q = (Cout + 3) / 4, c_lo = wave * q, c_hi = min(Cout, c_lo + q);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int co = 0;
-  for (; co + 4 <= Cout; co += 4) {
+  int co = c_lo;
+  for (; co + 4 <= c_hi; co += 4) {
     a0 = fmaf(op(dp[co]), op(wp[(long)co * Cin]), a0); a1 = fmaf(op(dp[co + 1]), op(wp[(long)(co + 1) * Cin]), a1);
     a2 = fmaf(op(dp[co + 2]), op(wp[(long)(co + 2) * Cin]), a2); a3 = fmaf(op(dp[co + 3]), op(wp[(long)(co + 3) * Cin]), a3);
   }
-  for (; co < Cout; ++co) a0 = fmaf(op(dp[co]), op(wp[(long)co * Cin]), a0);
-  if (!ok) return;
-  float v = (a0 + a1) + (a2 + a3);
+  for (; co < c_hi; ++co) a0 = fmaf(op(dp[co]), op(wp[(long)co * Cin]), a0);
+  part[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave != 0 || !ok) return;
+  float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   const long o = (long)n * Cin + ci;
   if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
   dx[o] = accumulate ? dx[o] + v : v;
@@ -369,7 +375,7 @@ int linear_bww_launch(const float* dy, const float* x, float* dw, int N, int Cin
 
 int linear_bwd_data_launch(const float* dy, const float* w, const float* pos_mask, float* dx, int N, int Cin, int Cout, int accumulate,
                            int round_bf16, hipStream_t st, const char* name) {
-  hipLaunchKernelGGL(linear_bwd_data_k, dim3(agl_cdiv(Cin, 64), agl_cdiv(N, 4)), dim3(256), 0, st, dy, w, pos_mask, dx, N, Cin, Cout, accumulate,
+  hipLaunchKernelGGL(linear_bwd_data_k, dim3(agl_cdiv(Cin, 64), N), dim3(256), 0, st, dy, w, pos_mask, dx, N, Cin, Cout, accumulate,
                      round_bf16);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
