@@ -32,8 +32,10 @@ def bn_tape_replay(tape):
     """Entries: ("bn", moments, running_mean, running_var, nbt) — a running-statistics update, replayed from its saved moments;
     runs of them go out as one launch — or a callable."""
     run = []
+    cur = torch.cuda.current_stream()
     for e in tape:
         if isinstance(e, tuple):
+            L.used_on(cur, e[1])      # (the moments may have been written on a branch stream)
             run.append(e[1:])
             continue
         if run:
@@ -53,6 +55,9 @@ BN_DEFER = None
 
 def bn_apply_deferred(entries):
     if entries:
+        cur = torch.cuda.current_stream()
+        for e in entries:
+            L.used_on(cur, e[0])      # moments written on a branch stream, read here
         L.bn_running_update_many(list(entries), BN_MOMENTUM)
 
 
@@ -402,14 +407,16 @@ class _Crop(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, boxes, o2i, HH, WW, align):
         feats, boxes = _c(feats), _c(boxes)
-        ctx.cfg = (tuple(feats.shape), align)
+        ctx.cfg = (tuple(feats.shape), align, getattr(o2i, "_agl_sorted", False))
         ctx.save_for_backward(boxes, o2i)
         return L.crop_fwd(feats, boxes, o2i, HH, WW, align)
 
     @staticmethod
     def backward(ctx, dout):
-        shape, align = ctx.cfg
+        shape, align, in_order = ctx.cfg
         boxes, o2i = ctx.saved_tensors
+        if in_order:      # (saved tensors may come back as new Python objects: the mark travels in ctx)
+            o2i._agl_sorted = True
         return L.crop_bwd(_c(dout), boxes, o2i, shape, align), None, None, None, None, None
 
 

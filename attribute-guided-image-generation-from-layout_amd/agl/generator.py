@@ -392,7 +392,7 @@ class Generator(nn.Module):
         A._need_device(imgs)
         dev = imgs.device
         sh = dict(imgs=imgs, objs=objs, boxes=boxes, masks=masks, obj_to_img=obj_to_img, z_rand=z_rand,
-                  masks_shift=masks_shift, boxes_shift=boxes_shift, o2i_dev=obj_to_img.to(dev),
+                  masks_shift=masks_shift, boxes_shift=boxes_shift, o2i_dev=F.L.box_map_to_device(obj_to_img, dev),
                   plan=SequencePlan(obj_to_img, dev))
         sh["crops_input"] = F.crop_boxes(imgs, boxes, sh["o2i_dev"], self.obj_size)
         sh["mu"], sh["logvar"] = self.crop_encoder.trunk(sh["crops_input"], objs)
@@ -443,7 +443,7 @@ class Generator(nn.Module):
                 F.BN_DEFER = prev
         F.BN_TAPE = tape_b
         try:
-            self.part_b(sh, before_deferred=lambda: (main.wait_stream(g2), F.bn_apply_deferred(lst)))
+            self.part_b(sh, before_deferred=lambda: (main.wait_stream(g2), F.L.used_on(main, img_rec, crops_rec), F.bn_apply_deferred(lst)))
         finally:
             F.BN_TAPE = None
         return img_rec, crops_rec
@@ -480,6 +480,8 @@ class Generator(nn.Module):
                 deferred.append(lst)
             for st in streams[:2]:
                 main.wait_stream(st)
+            for tag in ("rand", "shift"):      # produced on the branch streams, read on the caller's (and the discriminators') from here on
+                F.L.used_on(main, sh["img_" + tag], sh["crops_" + tag], sh["mu_" + tag], sh["lv_" + tag])
             if before_deferred is not None:
                 before_deferred()
             for lst in deferred:

@@ -58,7 +58,7 @@ def _edit(netG, netD_att, batch, dev, objs, attribute, o2i, z, z_edit, eps, eps_
     with torch.no_grad():
         netG.eval()
         # (1) attribute estimate (:126-135)
-        crops_input = F.crop_boxes(batch["imgs"], batch["boxes"], o2i.to(dev), netG.obj_size)
+        crops_input = F.crop_boxes(batch["imgs"], batch["boxes"], F.L.box_map_to_device(o2i, dev), netG.obj_size)
         attribute_est = L.attr_estimate(netD_att(crops_input), attribute)
         # (2) generate (:138-139)
         out = netG(batch["imgs"], objs, batch["boxes"], batch["masks"], o2i, z, attribute, batch["masks_shift"], batch["boxes_shift"],

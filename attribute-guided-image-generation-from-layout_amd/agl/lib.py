@@ -49,6 +49,7 @@ SIGNATURES = {
     "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_crop_bwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "agl_crop_bwd_sorted": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
     "agl_lstm_gates_bwd": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "agl_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
@@ -61,6 +62,16 @@ SIGNATURES = {
     "agl_box2_fwd_bf16": (_I, [_P, _P, _L, _I, _I, _P]),
     "agl_conv2d_bwd_weight_takes_bf16_x": (_I, [_I] * 11),
     "agl_conv2d_bwd_data_takes_bf16_mask": (_I, [_I] * 11),
+    "agl_conv2d_fwd_writes_bf16_y": (_I, [_I] * 12),
+    "agl_conv2d_bwd_data_takes_bf16_dy": (_I, [_I] * 11),
+    "agl_conv2d_bwd_weight_takes_bf16_dy": (_I, [_I] * 11),
+    "agl_norm_fold_table": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "agl_conv2d_fwd_fold_ok": (_I, [_I] * 9),
+    "agl_conv2d_fwd_fold": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _P]),
+    "agl_conv2d_bwd_weight_fold_ok": (_I, [_I] * 11),
+    "agl_conv2d_bwd_weight_fold": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_fwd_addend": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P]),
+    "agl_norm_bwd_fold": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
@@ -113,7 +124,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 4     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 5     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -154,7 +165,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_W8, CONV_PRIO = 128, 256
 CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
-CONV_Y_BF16, CONV_MASK_BF16 = 1 << 18, 1 << 19      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
+CONV_Y_BF16, CONV_MASK_BF16, CONV_DY_BF16 = 1 << 18, 1 << 19, 1 << 20      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
 CONV_FLAGS = 0
 
 
@@ -271,6 +282,16 @@ def on_wgrad_stream(fn, *tensors):
     return out
 
 
+def used_on(stream, *tensors):
+    """Tensors allocated on one stream and read by work queued on `stream` (chains on several streams): tell the caching
+    allocator, so that freeing them does not recycle their memory before that work has run.  Ordering is the caller's job."""
+    if stream is None:
+        return
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(stream)
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): the launches that share one are ordered on that stream."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
@@ -321,14 +342,15 @@ class WeightSrc:
         cur = torch.cuda.current_stream()
         if hit is not None and hit[0] == ver and hit[1].numel() >= nbytes:
             PACK_STATS["hits"] += 1
-            if hit[3] != cur.cuda_stream:      # packed on another stream (concurrent chains share layers): order this stream behind it
-                cur.wait_event(hit[2])
+            if hit[3] != cur.cuda_stream:      # packed on another stream (concurrent chains share layers): order this stream behind it,
+                cur.wait_event(hit[2])         # and tell the allocator that this stream reads the buffer too (its memory
+                hit[1].record_stream(cur)      # must not be handed out again before the reads queued here have run)
             return hit[1]
         src = make() if make is not None else (self.base if self.base is not None else w)
-        reuse = hit is not None and hit[1].numel() >= nbytes
-        buf = hit[1] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=src.device)
-        if reuse and hit[3] != cur.cuda_stream:
-            cur.wait_event(hit[2])             # (readers of the old contents on the packing stream are ordered before the overwrite)
+        # A new version gets a NEW buffer: the old one may still be read by launches queued on other chains' streams, which nothing
+        # orders before an in-place re-pack; dropping the cache entry hands it back to the stream-aware allocator instead (its
+        # record_stream marks keep the memory out of circulation until those reads are done).
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
         call("agl_conv2d_pack_weights", ptr(src.detach()), buf.data_ptr(), buf.numel(), pass_, Cin, Cout, ks, stride, CONV_FLAGS, stream())
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -561,11 +583,22 @@ def crop_fwd(feats, boxes, o2i, HH, WW, align=False):
     return out
 
 
+def box_map_to_device(box_to_img, device):
+    """The box -> image map on the device.  When it arrives on the CPU (as in the reference's loop, train64.py:149-151) its order is
+    checked here for free: a non-decreasing map lets the crop backward run as a fixed-order gather (agl_crop_bwd_sorted)."""
+    t = box_to_img.to(device).long()
+    if not box_to_img.is_cuda:
+        t._agl_sorted = bool(box_to_img.numel() < 2 or bool((box_to_img[1:] >= box_to_img[:-1]).all()))
+    return t
+
+
 def crop_bwd(dout, boxes, o2i, feat_shape, align=False):
+    """Sorted box -> image map (marked by box_map_to_device): a gather in fixed order; else a scatter with float atomics."""
     N, Cc, H, W = feat_shape
     B, _, HH, WW = dout.shape
     dfeats = torch.zeros(feat_shape, dtype=torch.float32, device=dout.device)
-    call("agl_crop_bwd", ptr(dout), ptr(boxes), ptr(o2i, torch.int64), ptr(dfeats), N, B, Cc, H, W, HH, WW, int(align), stream())
+    name = "agl_crop_bwd_sorted" if getattr(o2i, "_agl_sorted", False) else "agl_crop_bwd"
+    call(name, ptr(dout), ptr(boxes), ptr(o2i, torch.int64), ptr(dfeats), N, B, Cc, H, W, HH, WW, int(align), stream())
     return dfeats
 
 

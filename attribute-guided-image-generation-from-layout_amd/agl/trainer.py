@@ -244,8 +244,11 @@ class Trainer:
             for st in streams or []:
                 st.wait_stream(self.main)
 
-        def on(self, k):
+        def on(self, k, *reads):
+            """`reads`: tensors produced on other streams that the chain's kernels read (marked for the allocator, agl.lib.used_on)."""
             import contextlib
+            if self.streams:
+                L.used_on(self.streams[k], *reads)
             return torch.cuda.stream(self.streams[k]) if self.streams else contextlib.nullcontext()
 
         def join(self):
@@ -270,7 +273,7 @@ class Trainer:
         o2i = b["obj_to_img"]
         if not o2i.is_cuda and o2i.numel() and (int(o2i.min()) < 0 or int(o2i.max()) >= N):
             raise IndexError(f"obj_to_img must lie in [0, {N})")
-        o2i_dev = o2i.to(self.dev)
+        o2i_dev = L.box_map_to_device(o2i, self.dev)
         s = self.netG.obj_size
 
         # ---- pre-step attribute-estimate forward (train64.py:160-161); independent of G, so the previous
@@ -287,6 +290,7 @@ class Trainer:
                 if self.d_streams:
                     est._agl_ready = torch.cuda.Event()
                     est._agl_ready.record(self.d_streams[2])
+                    L.used_on(torch.cuda.current_stream(), est)      # written on D_att's stream, read by the generator on this one
                 b = dict(b, attribute_est=est)
             self._mark("pre-step estimate done (its stream)")
         self._wait(self._g_ready)
@@ -309,14 +313,14 @@ class Trainer:
             grads.append(g)
 
         ch = self._Chains(self.d_streams)
-        with ch.on(0):
+        with ch.on(0, img_rec, img_rand, img_shift):
             for name, x, w in (("d_img_rec", img_rec, MIX[0]), ("d_img_rand", img_rand, MIX[1]), ("d_img_shift", img_shift, MIX[2])):
                 lg = self.netDi(x)
                 term(lg, LS.bce_const(lg, 0.0, lam["img_adv"] * w, self._slot(name)))
             lg = self.netDi(b["imgs"])
             term(lg, LS.bce_const(lg, 1.0, lam["img_adv"], self._slot("d_img_real")))
             self._mark("D step: D_img forward done (its stream)")
-        with ch.on(1):
+        with ch.on(1, crops_rec, crops_rand, crops_shift, crops_input):
             for name, x, w in (("d_obj_rec", crops_rec, MIX[0]), ("d_obj_rand", crops_rand, MIX[1]), ("d_obj_shift", crops_shift, MIX[2])):
                 src, _ = self.netDo(x, objs)
                 term(src, LS.bce_const(src, 0.0, lam["obj_adv"] * w, self._slot(name)))
@@ -324,7 +328,7 @@ class Trainer:
             term(src, LS.bce_const(src, 1.0, lam["obj_adv"], self._slot("d_obj_real")))
             term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"], self._slot("d_obj_cls")))
             self._mark("D step: D_obj forward done (its stream)")
-        with ch.on(2):
+        with ch.on(2, crops_input):
             att = self.netDa(crops_input)
             term(att, LS.bce_posw(att, b["attribute_gt"], self.pos_weight, lam["att_cls"], self._slot("d_att")))
             self._mark("D step: D_att forward done (its stream)")
@@ -383,18 +387,18 @@ class Trainer:
             term(mu, dmu)
             term(logvar, dlv)
             ch = self._Chains(self.d_streams)
-            with ch.on(0):
+            with ch.on(0, img_rec, img_rand, img_shift):
                 for tag, x, w in (("rec", img_rec, MIX[0]), ("rand", img_rand, MIX[1]), ("shift", img_shift, MIX[2])):
                     lg = self.netDi(x)
                     term(lg, LS.bce_const(lg, 1.0, lam["img_adv"] * w, self._slot("g_img_adv_" + tag)))
                 self._mark("G step: D_img forward done (its stream)")
-            with ch.on(1):
+            with ch.on(1, crops_rec, crops_rand, crops_shift):
                 for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
                     src, cls = self.netDo(x, objs)
                     term(src, LS.bce_const(src, 1.0, lam["obj_adv"] * w, self._slot("g_obj_adv_" + tag)))
                     term(cls, LS.cross_entropy(cls, objs, lam["obj_cls"] * w, self._slot("g_obj_cls_" + tag)))
                 self._mark("G step: D_obj forward done (its stream)")
-            with ch.on(2):
+            with ch.on(2, crops_rec, crops_rand, crops_shift):
                 for tag, x, w in (("rec", crops_rec, MIX[0]), ("rand", crops_rand, MIX[1]), ("shift", crops_shift, MIX[2])):
                     att = self.netDa(x)
                     term(att, LS.bce_posw(att, b["attribute"], self.pos_weight, lam["att_cls"] * w, self._slot("g_att_" + tag)))

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "../../include/agl.h"      // AGL_ABI_VERSION, and the declarations this unit defines
+
 static thread_local char g_err[512] = "";
 
 void agl_set_error(const char* fmt, ...) {
@@ -14,5 +16,5 @@ void agl_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* agl_last_error(void) { return g_err; }
-int agl_version(void) { return 4; }   // = AGL_ABI_VERSION of include/agl.h (bumped with every signature change)
+int agl_version(void) { return AGL_ABI_VERSION; }   // include/agl.h (bumped with every signature change)
 }

@@ -989,6 +989,7 @@ struct ConvOpts {
   bool x_bf16;       // AGL_CONV_X_BF16 (1 << 17): the input tensor x holds bf16 elements (bf16 arithmetic, matrix-core kernels only)
   bool y_bf16;       // AGL_CONV_Y_BF16 (1 << 18): agl_conv2d_fwd writes y as bf16 (few-input-channel stream kernel only)
   bool mask_bf16;    // AGL_CONV_MASK_BF16 (1 << 19): agl_conv2d_bwd_data reads pos_mask as bf16 ("same" patch kernel without a reduction split)
+  bool dy_bf16;      // AGL_CONV_DY_BF16 (1 << 20): agl_conv2d_bwd_weight reads dy as bf16 (matrix-core kernel, bf16 arithmetic)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -1006,9 +1007,10 @@ static ConvOpts conv_opts(int flags) {
   o.x_bf16 = (flags & (1 << 17)) != 0;
   o.y_bf16 = (flags & (1 << 18)) != 0;
   o.mask_bf16 = (flags & (1 << 19)) != 0;
+  o.dy_bf16 = (flags & (1 << 20)) != 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, false, 0, false, false, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, 0, 0, false, false, false, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1545,6 +1547,8 @@ thread_local int g_last_pipe = 0;
 }  // namespace
 
 extern "C" {
+long agl_conv2d_fwd_packed_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags);
+long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
 
 // Bytes of split-K scratch the forward / input-gradient pass wants for these extents (0 = none needed).
 long agl_conv2d_splitk_ws_bytes(int M, long out_pixels, int phases, int K, long out_numel) {
@@ -1571,7 +1575,7 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
 static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
                            void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
                            int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
-                           int* stat_rows);
+                           int* stat_rows, const InFold* fold = nullptr, const float* addend = nullptr);
 
 int agl_conv2d_fwd(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws,
                    long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu,
@@ -1590,12 +1594,38 @@ int agl_conv2d_fwd_stats(const float* x, const float* w, const void* packed_w, c
                          flags, stream, stats, stats_floats, stat_rows);
 }
 
-long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW) { return pconv_stat_rows_max(N, OH, OW) * Cout * 2; }
+long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW) { return pconv_stat_rows_max(N, OH, OW) * Cout * 3; }
+
+// Forward convolution with the normalise-modulate of the BatchNorm that reads x folded into the input staging (include/agl.h):
+// y = conv(relu?((x - mean) * scale + shift)), zero padding after the transform; optionally the BatchNorm partial rows of y.
+int agl_conv2d_fwd_fold(const float* x, const float* in_mean, const float* in_scale, const float* in_shift, int in_per_n, const float* w,
+                        const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin,
+                        int H, int W, int Cout, int ks, int stride, int pad, int in_relu, int flags, float* stats, long stats_floats,
+                        int* stat_rows, void* stream) {
+  AGL_REQUIRE(in_mean && in_scale && in_shift, "agl_conv2d_fwd_fold: null table");
+  AGL_REQUIRE((stats == nullptr) == (stat_rows == nullptr), "agl_conv2d_fwd_fold: stats and stat_rows go together");
+  if (stat_rows) *stat_rows = 0;
+  const InFold f{in_mean, in_scale, in_shift, in_per_n};
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, 0, in_relu, 0, 0, flags,
+                         stream, stats, stats_floats, stat_rows, &f, nullptr);
+}
+int agl_conv2d_fwd_fold_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
+  return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
+}
+// y = conv(x) + addend (+ bias, output ReLU), written out of place — as bf16 with AGL_CONV_Y_BF16: the sum is formed in fp32 and rounded
+// once.  The shortcut of a discriminator block (discriminator.py:58-60, :97-99) whose sum only convolutions read afterwards.
+int agl_conv2d_fwd_addend(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* addend,
+                          float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int in_relu,
+                          int relu, int flags, void* stream) {
+  AGL_REQUIRE(addend, "agl_conv2d_fwd_addend: null addend");
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, 0, in_relu, relu, 0, flags,
+                         stream, nullptr, 0, nullptr, nullptr, addend);
+}
 
 static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
                            void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
                            int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
-                           int* stat_rows) {
+                           int* stat_rows, const InFold* fold, const float* addend) {
   AGL_REQUIRE(x && (w || packed_w) && y, "agl_conv2d_fwd: null pointer");
   g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
@@ -1607,19 +1637,44 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
+  if (fold || addend) {      // folded input transform / out-of-place addend: forms of the matrix-core patch kernel only (the caller asked *_ok)
+    AGL_REQUIRE((co.prec == 1 || co.split3) && co.patch && !accumulate && !co.x_bf16, "agl_conv2d_fwd_fold: needs the matrix-core patch kernel");
+    AGL_REQUIRE(!co.y_bf16 || co.prec == 1, "agl_conv2d_fwd: AGL_CONV_Y_BF16 needs AGL_CONV_BF16");
+    PConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
+    a.accumulate = 0; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid;
+    a.w8 = co.w8; a.prio = co.prio;
+    a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
+    if (fold) a.fold = *fold;
+    a.addend = addend; a.y_bf16 = co.y_bf16;
+    const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, folded input transform / addend)");
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd_fold: a shape the patch kernel does not take in this form (ask agl_conv2d_fwd_fold_ok)");
+    g_last_pipe = a.nsplit;
+    return prc;
+  }
   if (co.x_bf16) {      // a bf16 input exists for the matrix-core patch kernel in bf16 arithmetic only (the caller asked agl_conv2d_fwd_packed_bytes)
     AGL_REQUIRE(co.prec == 1 && co.patch && !(relu && accumulate), "agl_conv2d_fwd: AGL_CONV_X_BF16 needs AGL_CONV_BF16 and the patch kernel");
+    if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH == H && OW == W && w && !co.y_bf16) {      // few output channels, 7x7
+      PVertArgs v{x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, 1, 1};
+      const int vrc = pconv_vert_try(v, ws, ws_bytes, st, "agl_conv2d_fwd(vertical + diagonal, bf16 input)");
+      AGL_REQUIRE(vrc >= 0, "agl_conv2d_fwd: AGL_CONV_X_BF16 on a few-output-channel shape the vertical form does not take");
+      g_last_pipe = 1;
+      return vrc;
+    }
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1; a.y_bf16 = co.y_bf16;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, bf16 input)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd: AGL_CONV_X_BF16 on a shape the patch kernel does not take");
     g_last_pipe = 1;
     return prc;
   }
+  AGL_REQUIRE(!co.y_bf16 || Cout > 4, "agl_conv2d_fwd: AGL_CONV_Y_BF16 on a few-output-channel layer (ask agl_conv2d_fwd_writes_bf16_y)");
   if (Cout <= 4 && stride == 1 && up_log2 == 0 && !in_relu && OH == H && OW == W && w && co.patch && (co.prec == 1 || co.split3)) {
     // few output channels, 7x7: vertical convolution on the matrix cores + diagonal sum (pconv.hip)
     PVertArgs v{x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, relu, accumulate, co.prec == 1 ? 1 : 3};
@@ -1635,17 +1690,18 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
                                     "agl_conv2d_fwd(few input channels)");
     if (frc >= 0) return frc;
   }
-  AGL_REQUIRE(!co.y_bf16, "agl_conv2d_fwd: AGL_CONV_Y_BF16 on a call the few-input-channel stream kernel does not take");
+  AGL_REQUIRE(!co.y_bf16 || co.prec == 1, "agl_conv2d_fwd: AGL_CONV_Y_BF16 needs AGL_CONV_BF16");
   if (co.patch && (co.prec == 1 || co.split3) && !(relu && accumulate)) {
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.y_bf16 = co.y_bf16;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  AGL_REQUIRE(!co.y_bf16, "agl_conv2d_fwd: AGL_CONV_Y_BF16 on a call no bf16-writing kernel takes (ask agl_conv2d_fwd_writes_bf16_y)");
   AGL_REQUIRE(w, "agl_conv2d_fwd: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
                  "(ask agl_conv2d_fwd_packed_bytes first)");
   g_last_pipe = co.prec;
@@ -1749,6 +1805,25 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
   if (Cin <= 4 && stride == 1 && IH * IW >= 64 && (long)OH * OW * 8 < (1L << 18) && w)   // dx = conv(dy, flipped taps, channel roles swapped), pad' = ks-1-pad
     return launch_small_cout(dy, w, bias, pos_mask, dx, N, Cout, OH, OW, Cin, ks, ks - 1 - pad, ks * ks, Cin * ks * ks, 1, relu,
                              accumulate, st, "agl_conv2d_bwd_data(small Cin)");
+  if (co.x_bf16) {      // dy stored as bf16 (the bf16-stored input of a transposed convolution): matrix-core kernels in bf16 arithmetic only
+    AGL_REQUIRE(co.prec == 1 && co.patch && Cin > 4 && !bias && !(relu && accumulate) && !co.mask_bf16,
+                "agl_conv2d_bwd_data: AGL_CONV_X_BF16 needs AGL_CONV_BF16 and a matrix-core form (ask agl_conv2d_bwd_data_takes_bf16_dy)");
+    PConvArgs a{};
+    a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
+    a.OH = IH; a.OW = IW; a.ks = ks; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate; a.nsplit = 1;
+    a.any_grid = co.any_grid; a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1;
+    int prc = -1;
+    if (stride == 1 && IH == OH && IW == OW) {
+      a.stride = 1; a.pad = ks - 1 - pad; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1;
+      prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv, bf16 dy)");
+    } else if (stride == 2 && ks == 4) {
+      a.stride = 2; a.pad = pad; a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0;
+      prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases, bf16 dy)");
+    }
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_data: AGL_CONV_X_BF16 on a shape the matrix-core kernels do not take");
+    g_last_pipe = 1;
+    return prc;
+  }
   if (co.mask_bf16)
     AGL_REQUIRE(stride == 1 && co.patch && IH == OH && IW == OW && co.prec == 1 && pos_mask && Cin > 4 && !(relu && accumulate),
                 "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 needs the stride-1 patch kernel in bf16 arithmetic (ask agl_conv2d_bwd_data_takes_bf16_mask)");
@@ -2000,9 +2075,47 @@ static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW) {
 }
 
 // dw[Cout,Cin,ks,ks] (+)= sum_{n,oh,ow} dy * im2col(x).  ws: agl_conv2d_bwd_weight_ws_bytes() bytes (may be null if 0).
+static int conv2d_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws,
+                                 long ws_bytes, int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2,
+                                 int in_relu, int accumulate, int flags, void* stream, const InFold* fold);
 int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws,
                           long ws_bytes, int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2,
                           int in_relu, int accumulate, int flags, void* stream) {
+  return conv2d_bwd_weight_impl(dy, x, dw, dbias, dbias_accumulate, dbias_done, ws, ws_bytes, N, Cin, H, W, Cout, OH, OW, ks, stride, pad,
+                                up_log2, in_relu, accumulate, flags, stream, nullptr);
+}
+// The weight gradient of a convolution whose input was normalised on the fly (agl_conv2d_fwd_fold): x is the RAW tensor, the same
+// transform (+ in_relu) is applied while it is staged.  Matrix-core kernel only (agl_conv2d_bwd_weight_fold_ok).
+int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_mean, const float* in_scale, const float* in_shift,
+                               int in_per_n, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N,
+                               int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate,
+                               int flags, void* stream) {
+  AGL_REQUIRE(in_mean && in_scale && in_shift, "agl_conv2d_bwd_weight_fold: null table");
+  const InFold f{in_mean, in_scale, in_shift, in_per_n};
+  return conv2d_bwd_weight_impl(dy, x, dw, dbias, dbias_accumulate, dbias_done, ws, ws_bytes, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, 0,
+                                in_relu, accumulate, flags, stream, &f);
+}
+int agl_conv2d_bwd_weight_fold_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (!co.patch || !(co.prec == 1 || co.split3) || Cin <= 4) return 0;
+  PBwwArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad;
+  a.nsplit = co.prec == 1 ? 1 : 3;
+  return pbww_ws_bytes(a) > 0 ? 1 : 0;
+}
+// 1 when agl_conv2d_bwd_weight with AGL_CONV_BF16 | AGL_CONV_DY_BF16 runs these extents on the matrix-core kernel (8-pixel pieces of dy)
+int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || Cin <= 4) return 0;
+  if (OW % 8 != 0 && !(OW == 4 && OH == 4)) return 0;
+  PBwwArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.nsplit = 1;
+  a.dy_bf16 = 1;
+  return pbww_ws_bytes(a) > 0 ? 1 : 0;
+}
+static int conv2d_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws,
+                                 long ws_bytes, int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int up_log2,
+                                 int in_relu, int accumulate, int flags, void* stream, const InFold* fold) {
   AGL_REQUIRE(dy && x && dw, "agl_conv2d_bwd_weight: null pointer");
   AGL_REQUIRE(!dbias || dbias_done, "agl_conv2d_bwd_weight: dbias needs dbias_done");
   if (dbias_done) *dbias_done = 0;
@@ -2011,15 +2124,19 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
-  if (co.x_bf16) {
-    AGL_REQUIRE(co.prec == 1 && co.patch, "agl_conv2d_bwd_weight: AGL_CONV_X_BF16 needs AGL_CONV_BF16 and the matrix-core kernel");
+  if (co.x_bf16 || co.dy_bf16 || fold) {
+    AGL_REQUIRE(co.patch && (co.prec == 1 || (co.split3 && !co.x_bf16 && !co.dy_bf16)),
+                "agl_conv2d_bwd_weight: bf16-stored operands need AGL_CONV_BF16, a folded input transform the matrix-core kernel");
     PBwwArgs a{};
     a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
-    a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = 1; a.x_bf16 = 1;
+    a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = co.prec == 1 ? 1 : 3;
+    a.x_bf16 = co.x_bf16; a.dy_bf16 = co.dy_bf16;
+    if (fold) a.fold = *fold;
     a.dbias = dbias; a.dbias_accumulate = dbias_accumulate; a.dbias_done = dbias_done;
     const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww, bf16 input)");
-    AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_weight: AGL_CONV_X_BF16 on a shape the matrix-core kernel does not take (ask agl_conv2d_bwd_weight_takes_bf16_x)");
-    g_last_pipe = 1;
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_weight: bf16-stored operand / folded transform on a shape the matrix-core kernel does not take "
+                          "(ask agl_conv2d_bwd_weight_takes_bf16_x / _takes_bf16_dy / _fold_ok)");
+    g_last_pipe = a.nsplit;
     return prc;
   }
   if (ks == 1 && H == 1 && W == 1 && OH == 1 && OW == 1 && pad == 0 && up_log2 == 0 && co.patch)      // nn.Linear (few.hip)
@@ -2101,6 +2218,32 @@ int agl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* dbi
 }
 
 int agl_conv2d_last_pipe(void) { return g_last_pipe; }
+
+// 1 when agl_conv2d_fwd with AGL_CONV_BF16 | AGL_CONV_Y_BF16 would write these extents as bf16: the few-input-channel stream kernel
+// (Cin <= 4, 1x1 / 3x3 "same") or the matrix-core patch kernel without a reduction split (the two kernels that have that store).
+int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int relu, int accumulate,
+                                 int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || Cout <= 4 || accumulate) return 0;
+  const int Hl = H << up_log2, Wl = W << up_log2;
+  const int OH = (Hl + 2 * pad - ks) / stride + 1, OW = (Wl + 2 * pad - ks) / stride + 1;
+  if (Cin <= 4) {      // the acceptance conditions of few_cin_fwd_try (few.hip), alignment aside (torch allocations are 16-byte aligned)
+    return (stride == 1 && up_log2 == 0 && OH == H && OW == W && Cout >= 16 && (ks == 1 || ks == 3) && W % 4 == 0 &&
+            ((long)Cout * Cin * ks * ks + Cout) * 4 <= 48 * 1024) ? 1 : 0;
+  }
+  (void)relu;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
+  a.nsplit = 1; a.any_grid = co.any_grid;
+  return pconv_plan_splits(a) == 1 && OW % 4 == 0 ? 1 : 0;
+}
+// 1 when agl_conv2d_bwd_data with AGL_CONV_BF16 | AGL_CONV_X_BF16 (dy stored as bf16) runs these extents on a matrix-core kernel
+int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || Cin <= 4) return 0;
+  if (stride == 2 && (IH != 2 * OH || IW != 2 * OW)) return 0;      // (the odd-sized form's edge kernel reads an fp32 dy)
+  return agl_conv2d_bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad, flags) > 0 ? 1 : 0;
+}
 
 // ---- pre-packed weights (include/agl.h): bytes of the packed form when the call would run on the LDS-patch kernel, else 0
 long agl_conv2d_fwd_packed_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int flags) {

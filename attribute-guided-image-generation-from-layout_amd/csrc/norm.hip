@@ -28,10 +28,11 @@ __device__ __forceinline__ float group_sum(float v, float* scratch4) {
 
 // ---------------------------------------------------------------- statistics
 // Partial sums over a contiguous range of the channel's elements.  With HW % 4 == 0 the range is walked in 16-byte pieces
-// (a channel row is HW contiguous floats, 16-byte aligned); the sums are accumulated in double either way.
+// (a channel row is HW contiguous floats; taken only when the tensor starts on a 16-byte boundary); every element is widened to
+// double before it is added, in both forms.
 __device__ __forceinline__ void channel_moments(const float* __restrict__ x, int C, int HW, int c, long e0, long e1, double& a, double& b) {
   a = 0.0; b = 0.0;
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // (a sub-view that starts off a 16-byte boundary: scalar walk)
     // (32-bit index arithmetic — the tensors hold < 2^30 elements — and two independent 16-byte loads in flight per thread: the
     //  64-bit division per load of the first form held the kernel at 2.6 TB/s)
     const unsigned Q = HW >> 2, g1 = (unsigned)(e1 >> 2);
@@ -40,7 +41,7 @@ __device__ __forceinline__ void channel_moments(const float* __restrict__ x, int
       return *reinterpret_cast<const float4*>(x + ((long)n * C + c) * HW + 4 * q);
     };
     auto add = [&](const float4& v) {
-      a += (double)((v.x + v.y) + (v.z + v.w));
+      a += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
       b += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     };
     unsigned g = (unsigned)(e0 >> 2) + threadIdx.x;
@@ -128,26 +129,41 @@ __global__ void bn_stats_final(const double* __restrict__ part, int C, int S, lo
   }
 }
 
-// Statistics from the partial rows a convolution wrote beside its output (agl_conv2d_fwd_stats): part[row][c][{sum, sum sq}].
-// One wave per channel, rows summed in double in a fixed order.
+// Statistics from the partial rows a convolution wrote beside its output (agl_conv2d_fwd_stats): part[row][c][{count, mean, M2}] over
+// disjoint pixel sets.  One wave per channel; the rows are merged in double with Chan's update (mean and M2 of a union from the
+// means and M2s of its parts: no difference of large sums anywhere), lanes in a fixed order, then across the wave.
+__device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, double n2, double mu2, double m22) {
+  const double nt = n + n2;
+  if (nt > 0.0) {
+    const double dl = mu2 - mu;
+    mu += dl * (n2 / nt);
+    m2 += m22 + dl * dl * (n * n2 / nt);
+  }
+  n = nt;
+}
 __global__ __launch_bounds__(64) void bn_stats_from_rows(const float* __restrict__ part, int rows, int C, long M, float eps, float momentum,
                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, long long* __restrict__ nbt, double* __restrict__ moments) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && nbt) *nbt += 1;
-  double a = 0.0, b = 0.0;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
   for (int r = lane; r < rows; r += 64) {
-    const float2 v = *reinterpret_cast<const float2*>(part + ((long)r * C + c) * 2);
-    a += (double)v.x; b += (double)v.y;
+    const float* v = part + ((long)r * C + c) * 3;
+    chan_merge(n, mu, m2, (double)v[0], (double)v[1], (double)v[2]);
   }
-  a = wave_sum(a); b = wave_sum(b);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {      // (both partners compute the merged triple; lane 0's order is fixed)
+    const double n2 = __shfl_xor(n, o), mu2 = __shfl_xor(mu, o), m22 = __shfl_xor(m2, o);
+    if ((lane & o) == 0) chan_merge(n, mu, m2, n2, mu2, m22);
+    else { double a = n2, b = mu2, d = m22; chan_merge(a, b, d, n, mu, m2); n = a; mu = b; m2 = d; }
+  }
   if (lane != 0) return;
-  const double mu = a / (double)M;
-  double var = b / (double)M - mu * mu;
+  (void)M;      // (= n: the rows cover every output element exactly once)
+  double var = n > 0.0 ? m2 / n : 0.0;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+  const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
   if (moments) { moments[2 * c] = mu; moments[2 * c + 1] = unb; }      // for agl_bn_running_update (bit-identical replays)
   if (rmean) {
     rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
@@ -196,7 +212,19 @@ struct NormArgs {
   // mode 3 with a gathered gamma|beta: p0 is (N, 2C, src_w, src_w) on a coarser (block-class) grid and pixel (iy, ix) of the
   // W-wide map reads cell (map[iy], map[ix]) — the expansion agl_grid_gather_fwd would write out is folded into the reads
   const int* map; int W, src_w;
+  // backward of a FOLDED forward (agl_norm_fold_table + agl_conv2d_fwd_fold: the normalised tensor y was never stored): the ReLU mask
+  // is recomputed from x with the very expression the consumer's staging pass evaluated, fmaf(x - mean, fscale[r], fshift[r]) > 0
+  const float* fscale; const float* fshift; int f_per_n;
 };
+
+// ReLU mask of element `idx` of row (n, c): from the stored output y, or recomputed from x (folded forward; fs / fh = the row's table entries)
+__device__ __forceinline__ bool relu_dead(const float* __restrict__ y, long idx, float x, float mu, float fs, float fh) {
+  return y ? !(y[idx] > 0.f) : !(fmaf(x - mu, fs, fh) > 0.f);
+}
+__device__ __forceinline__ void fold_row(const NormArgs& a, int n, int c, float& fs, float& fh) {
+  fs = 0.f; fh = 0.f;
+  if (a.fscale) { const long r = (a.f_per_n ? (long)n * a.C : 0) + c; fs = a.fscale[r]; fh = a.fshift[r]; }
+}
 
 // offset of pixel i's gamma (beta: + C planes) inside its (n, c) plane of p0, and the plane size
 __device__ __forceinline__ int gb_index(const NormArgs& a, int i) {
@@ -296,11 +324,14 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
   float* dgam = a.mode == 3 ? dgb + ((long)n * 2 * a.C + c) * a.HW : nullptr;
   float* dbet = a.mode == 3 ? dgb + ((long)n * 2 * a.C + a.C + c) * a.HW : nullptr;
   float s1 = 0.f, s2 = 0.f;
+  float fs, fh;
+  fold_row(a, n, c, fs, fh);
   if (live) {
     for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
       float g = dy[base + i];
-      if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
-      float xh = (a.x[base + i] - mu) * rs;
+      const float xv = a.x[base + i];
+      if (a.relu && relu_dead(y, base + i, xv, mu, fs, fh)) g = 0.f;
+      float xh = (xv - mu) * rs;
       if (a.mode == 3) {
         dgam[i] = g * xh;         // (full resolution either way: a gathered gamma|beta is reduced to its grid by agl_grid_gather_bwd)
         dbet[i] = g;
@@ -332,14 +363,16 @@ __global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* _
   float4* dbet = a.mode == 3 ? reinterpret_cast<float4*>(dgb + ((long)n * 2 * a.C + a.C + c) * a.HW) : nullptr;
   const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
   const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
-  const float4* y4 = a.relu ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  const float4* y4 = (a.relu && y) ? reinterpret_cast<const float4*>(y + base) : nullptr;
   float s1 = 0.f, s2 = 0.f;
+  float fs, fh;
+  fold_row(a, n, c, fs, fh);
   for (int i = threadIdx.x; i < a.HW / 4; i += 256) {
     const float4 gv = dy4[i], xv = x4[i];
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = y4[i];
+      const float4 yv = y4 ? y4[i] : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -513,10 +546,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
   row_affine(a, n, c, ge, b);
   const long base = (long)row * a.HW;
   const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
+  float fs, fh;
+  fold_row(a, n, c, fs, fh);
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float g = dy[base + i];
-    if (a.relu && !(y[base + i] > 0.f)) g = 0.f;
-    float xh = (a.x[base + i] - mu) * rs;
+    const float xv = a.x[base + i];
+    if (a.relu && relu_dead(y, base + i, xv, mu, fs, fh)) g = 0.f;
+    float xh = (xv - mu) * rs;
     float gg = a.mode == 3 ? g * (1.f + gam[gb_index(a, i)]) : g * ge;
     dx[base + i] = rs * (gg - m1 - xh * m2);
   }
@@ -559,14 +595,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
   const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
   const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
   const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
-  const float4* y4 = a.relu ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  const float4* y4 = (a.relu && y) ? reinterpret_cast<const float4*>(y + base) : nullptr;
   float4* dx4 = reinterpret_cast<float4*>(dx + base);
+  float fs, fh;
+  fold_row(a, n, c, fs, fh);
   for (int i = threadIdx.x; i < a.HW / 4; i += 256) {
     const float4 gv = dy4[i], xv = x4[i];
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = y4[i];
+      const float4 yv = y4 ? y4[i] : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -591,6 +629,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
 }
 
 int pick_lpr(int HW) { return HW <= 4 ? 4 : (HW <= 16 ? 16 : (HW <= 512 ? 64 : 256)); }
+
+// Tables of the folded normalise-modulate (agl_norm_fold_table): scale[r][c] = rstd[c] * gamma(r, c), shift[r][c] = beta(r, c)
+__global__ void norm_fold_table_k(NormArgs a, int rows, float* __restrict__ scale, float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * a.C) return;
+  const int n = i / a.C, c = i - n * a.C;
+  float g, b;
+  row_affine(a, n, c, g, b);
+  scale[i] = a.rstd[c] * g;
+  shift[i] = b;
+}
 
 }  // namespace
 
@@ -694,6 +743,7 @@ static int fill_args(NormArgs& a, const float* x, const float* mean, const float
   a.x = x; a.mean = mean; a.rstd = rstd; a.p0 = p0; a.p1 = p1; a.labels = labels;
   a.mode = mode; a.relu = relu; a.N = N; a.C = C; a.HW = HW;
   a.map = nullptr; a.W = 0; a.src_w = 0;
+  a.fscale = nullptr; a.fshift = nullptr; a.f_per_n = 0;
   return AGL_OK;
 }
 // gathered gamma|beta of mode 3 (gb_map: W device ints, the row AND column map of a square W x W map onto a src_w x src_w grid)
@@ -734,16 +784,56 @@ long agl_norm_bwd_ws_bytes(int N, int C) { return ((long)N * C * 2 + (long)C * 2
 // dp0/dp1: mode 1 -> dgamma[C], dbeta[C] (overwritten, or added to when param_accumulate); mode 2 -> dtable[V][2C] (ALWAYS
 //          accumulated into; a caller without a gradient slot zeroes it first); mode 3 -> dp0 = dgb[N][2C][HW] (overwritten).
 //          Either may be NULL to skip parameter gradients (not mode 3).
+static int norm_bwd_impl(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
+                         const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                         float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                         int W, int src_w, void* ws, long ws_bytes, void* stream, const float* fscale, const float* fshift, int f_per_n);
+
 int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
                  float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
                  int W, int src_w, void* ws, long ws_bytes, void* stream) {
+  AGL_REQUIRE(!relu || y, "agl_norm_bwd: relu needs the forward output y (or agl_norm_bwd_fold)");
+  return norm_bwd_impl(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dx, dp0, dp1, N, C, HW, n_classes, param_accumulate,
+                       gb_map, gb_lo, W, src_w, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// Backward of a FOLDED normalise-modulate(+ReLU) (agl_norm_fold_table + agl_conv2d_fwd_fold): dy is the gradient with respect to the
+// never-stored activation y = relu?(fmaf(x - mean, scale, shift)); the ReLU mask is recomputed from x and the tables.  Modes 0-2.
+int agl_norm_bwd_fold(const float* dy, const float* x, const float* mean, const float* rstd, const float* fold_scale, const float* fold_shift,
+                      int fold_per_n, int mode, const float* p0, const float* p1, const long long* labels, int relu, int batch_stats,
+                      float* dx, float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
+                      void* stream) {
+  AGL_REQUIRE(mode >= 0 && mode <= 2 && fold_scale && fold_shift, "agl_norm_bwd_fold: modes 0-2 with the tables of agl_norm_fold_table");
+  return norm_bwd_impl(dy, x, nullptr, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dx, dp0, dp1, N, C, HW, n_classes, param_accumulate,
+                       nullptr, nullptr, 0, 0, ws, ws_bytes, stream, fold_scale, fold_shift, fold_per_n);
+}
+
+// scale[rows][C] = rstd[c] * gamma(r, c), shift[rows][C] = beta(r, c) of the normalise-modulate in `mode` (0: gamma 1, beta 0;
+// 1: affine; 2: class table rows picked by labels) — rows = N for mode 2 (per object), else 1.
+int agl_norm_fold_table(const float* mean, const float* rstd, int mode, const float* p0, const float* p1, const long long* labels, int N, int C,
+                        float* scale, float* shift, void* stream) {
+  NormArgs a;
+  AGL_REQUIRE(mode >= 0 && mode <= 2 && scale && shift, "agl_norm_fold_table: modes 0-2");
+  int rc = fill_args(a, mean, mean, rstd, mode, p0, p1, labels, 0, N, C, 1, "agl_norm_fold_table");
+  if (rc) return rc;
+  const int rows = mode == 2 ? N : 1;
+  hipLaunchKernelGGL(norm_fold_table_k, dim3(agl_cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, rows, scale, shift);
+  AGL_CHECK_LAUNCH("agl_norm_fold_table");
+  return AGL_OK;
+}
+
+static int norm_bwd_impl(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int mode,
+                         const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                         float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                         int W, int src_w, void* ws, long ws_bytes, void* stream, const float* fscale, const float* fshift, int f_per_n) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_bwd");
   if (rc) return rc;
   rc = fill_gather(a, gb_map, W, src_w, "agl_norm_bwd");
   if (rc) return rc;
-  AGL_REQUIRE(dy && dx && (!relu || y), "agl_norm_bwd: null pointer");
+  a.fscale = fscale; a.fshift = fshift; a.f_per_n = f_per_n;
+  AGL_REQUIRE(dy && dx && (!relu || y || fscale), "agl_norm_bwd: null pointer");
   AGL_REQUIRE(mode != 3 || dp0, "agl_norm_bwd: SPADE mode needs dgb output");
   if (!ws || ws_bytes < agl_norm_bwd_ws_bytes(N, C)) {
     agl_set_error("agl_norm_bwd: workspace too small");

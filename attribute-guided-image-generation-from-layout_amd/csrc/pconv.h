@@ -2,6 +2,12 @@
 #pragma once
 #include "agl_internal.h"
 
+// Input transform applied while an operand is staged: the normalise-modulate of the BatchNorm2d / ConditionalBatchNorm2d that reads the
+// tensor (generator_obj_att.py:31-44, :433, :583) folded into the convolution that consumes its output —
+//   v = (x - mean[c]) * scale[r * C + c] + shift[r * C + c],  r = image index when per_n, else 0   (then the fused input ReLU)
+// with scale = rstd * gamma, shift = beta (agl_norm_fold_table).  Zero padding is applied AFTER the transform (padding stays 0).
+struct InFold { const float* mean; const float* scale; const float* shift; int per_n; };
+
 struct PConvArgs {
   const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up); OH, OW: output map
@@ -18,6 +24,9 @@ struct PConvArgs {
   const float* out_div;             // optional device scalar: the accumulated products are divided by it before bias / mask / ReLU
   int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
   int mask_bf16;                    // pos_mask points to bf16 elements (AGL_CONV_MASK_BF16; launches without a reduction split only)
+  InFold fold;                      // optional (scale != NULL): transform of x while it is staged (stride-1 / stride-2 forward forms)
+  int y_bf16;                       // y points to bf16 elements (AGL_CONV_Y_BF16; launches without a reduction split only)
+  const float* addend;              // optional fp32 tensor shaped like y, added before the output ReLU (no reduction split)
 };
 // Packed form of a weight tensor for pconv_try (forward: flip 0, w_sm = Cin*ks*ks, w_sc = ks*ks; "same" input gradient: flip 1, roles
 // swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
@@ -25,6 +34,7 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
                const char* name);
 // Upper bound of the partial rows pconv_try writes for an output of N images of OH x OW pixels
 long pconv_stat_rows_max(int N, int OH, int OW);
+long pconv_stat_row_floats(int Cout);      // floats per partial row: [Cout][{count, mean, M2}]
 
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
@@ -50,6 +60,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
 struct PVertArgs {
   const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
   int N, Cred, H, W, CO, ks, pad, w_so, w_sc, flip, relu, accumulate, nsplit;
+  int x_bf16;                       // x points to bf16 elements (nsplit 1 only)
 };
 long pconv_vert_ws_bytes(int N, int Cred, int H, int W, int CO, int ks, int nsplit);
 int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
@@ -59,6 +70,8 @@ struct PBwwArgs {
   int N, Cin, H, W, Cout, OH, OW;   // H, W: stored input map (logical size H<<up)
   int ks, stride, pad, up, in_relu, accumulate, nsplit;
   int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
+  int dy_bf16;                      // dy points to bf16 elements (AGL_CONV_DY_BF16; nsplit 1 only)
+  InFold fold;                      // optional transform of x while it is staged (as in PConvArgs)
   float* dbias; int dbias_accumulate; int* dbias_done;    // optional: also (+= when dbias_accumulate) the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
 };
 long pbww_ws_bytes(const PBwwArgs& a);

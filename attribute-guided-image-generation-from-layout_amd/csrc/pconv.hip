@@ -47,7 +47,11 @@ struct PArgs {
   int prio;          // raise the wave priority for the conversion / LDS-store segment of every stage (A/B switch)
   int oh2, ow2;      // phase mode: extent of the output map (2*OH x 2*OW, or one more row and column for an odd-sized input)
   const float* odiv; // optional device scalar: the products are divided by it before bias / mask / ReLU (pre-packed weights of a
-};                   // spectrally normalised layer: packed W_orig, divisor sigma)
+                     // spectrally normalised layer: packed W_orig, divisor sigma)
+  InFold fold;       // optional input transform of the staged patch (pconv.h): the normalise-modulate of the BatchNorm that reads x
+  int y_bf16;        // y points to bf16 elements (plain epilogue only: no phases, no reduction split)
+  const float* addend;   // optional fp32 tensor shaped like y, added to the result before the output ReLU (out-of-place accumulate)
+};
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
 __device__ __forceinline__ void split3(float a, __bf16& t0, __bf16& t1, __bf16& t2) {
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   const unsigned esz = p.x_bf16 ? 2u : 4u;      // bytes per stored input element
   unsigned bsrc[BR];   // patch item e = (half h, image ti, row yy, column xx): byte offset of channel 8h, or OOB31
   int bdst[BR];        // LDS piece index h*NQ + q, or -1
+  int faff[BR];
 #pragma unroll
   for (int r = 0; r < BR; ++r) {
     const int e = tid + NT * r;
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
     bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
     bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
+    faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // (fold) row offset of this item's 8 channels in the scale / shift tables
   }
   const unsigned cstride = (unsigned)(p.H * p.W) * esz;
   unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
@@ -238,8 +244,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 
   float pb[BR][8];
   u32x4 pa[AR];
+  int c_staged = 0;    // first channel of the chunk in pb
   auto gload_b = [&](int c0) {
     if ((ABL & 8) && c0 != 16 * (p.slabs ? zsplit * p.cps : 0)) return;
+    c_staged = c0;
     if (p.x_bf16) {      // (a bf16 value is the upper half of its fp32 form: the conversion at the LDS store is then exact)
 #pragma unroll
       for (int r = 0; r < BR; ++r)
@@ -265,6 +273,16 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       if (bdst[r] < 0) continue;
+      if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
+        const float4* const mp = reinterpret_cast<const float4*>(p.fold.mean + c_staged + (faff[r] & 8));
+        const float4* const sp = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r]);
+        const float4* const hp = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r]);
+        const float4 m0 = mp[0], m1 = mp[1], s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
+        pb[r][0] = fmaf(pb[r][0] - m0.x, s0.x, h0.x); pb[r][1] = fmaf(pb[r][1] - m0.y, s0.y, h0.y);
+        pb[r][2] = fmaf(pb[r][2] - m0.z, s0.z, h0.z); pb[r][3] = fmaf(pb[r][3] - m0.w, s0.w, h0.w);
+        pb[r][4] = fmaf(pb[r][4] - m1.x, s1.x, h1.x); pb[r][5] = fmaf(pb[r][5] - m1.y, s1.y, h1.y);
+        pb[r][6] = fmaf(pb[r][6] - m1.z, s1.z, h1.z); pb[r][7] = fmaf(pb[r][7] - m1.w, s1.w, h1.w);
+      }
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -407,12 +425,14 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   const long OHW = (long)p.OH * p.OW;
   const float osc = (p.odiv && !p.slabs) ? 1.0f / *p.odiv : 1.0f;     // (slabs carry raw sums: the slab reduction divides)
   const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8*pass, columns ec..ec+3
-  // BatchNorm statistics of the output (p.stats): every lane sums the values it stores, per channel row
-  float ssum[WTM][4], ssq[WTM][4];
+  // BatchNorm statistics of the output (p.stats): every lane accumulates the values it stores, per channel row, as deviations from
+  // the FIRST value it sees for that row (sref): sum d, sum d^2 — a channel whose mean is large against its spread (mean / std = 100)
+  // then loses nothing to cancellation, unlike raw sum / sum-of-squares partials in fp32
+  float ssum[WTM][4], ssq[WTM][4], sref[WTM][4], scnt[WTM][4];
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; }
+    for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; sref[i][ps] = 0.f; scnt[i][ps] = 0.f; }
 #pragma unroll
   for (int jt = 0; jt < WTN; ++jt) {
     const int j = wn * (BN / WNW) + 32 * jt + ec;
@@ -526,11 +546,13 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         continue;
       }
       float4 old[4], msk[4];
-      if (p.accumulate) {
+      const bool add_old = p.accumulate || p.addend != nullptr;
+      if (add_old) {
+        const float* const src = p.addend ? p.addend : p.y;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
-          old[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(p.y + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
+          old[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(src + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
         }
       }
       if (p.pos_mask && p.mask_bf16) {      // (bf16 -> fp32 is a shift: sign and zero are those of the stored value)
@@ -562,29 +584,49 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             if (!(msk[ps].z > 0.f)) o.z = 0.f;
             if (!(msk[ps].w > 0.f)) o.w = 0.f;
           }
-          if (p.accumulate) { o.x += old[ps].x; o.y += old[ps].y; o.z += old[ps].z; o.w += old[ps].w; }
+          if (add_old) { o.x += old[ps].x; o.y += old[ps].y; o.z += old[ps].z; o.w += old[ps].w; }
           if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-          *reinterpret_cast<float4*>(p.y + pbase + (long)m * OHW) = o;
+          if (p.y_bf16) {      // four bf16 (round to nearest even) in one 8-byte store
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + pbase + (long)m * OHW) = __builtin_bit_cast(uint2, ob);
+          } else {
+            *reinterpret_cast<float4*>(p.y + pbase + (long)m * OHW) = o;
+          }
           if (p.stats) {
-            ssum[i][ps] += (o.x + o.y) + (o.z + o.w);
-            ssq[i][ps] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            if (scnt[i][ps] == 0.f) sref[i][ps] = o.x;
+            const float rf = sref[i][ps];
+            const float d0 = o.x - rf, d1 = o.y - rf, d2 = o.z - rf, d3 = o.w - rf;
+            ssum[i][ps] += (d0 + d1) + (d2 + d3);
+            ssq[i][ps] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            scnt[i][ps] += 4.f;
           }
         }
       }
     }
   }
   if constexpr (!PHS) {
-    if (p.stats) {      // the 8 lanes of a channel row hold its pixels: butterfly within the octet, lane 0 of it writes the partial
-      float* const row = p.stats + ((long)bx * WNW + wn) * p.Cout * 2;
+    if (p.stats) {      // the 8 lanes of a channel row hold its pixels: (count, mean, M2) per lane, merged pairwise within the octet
+      float* const row = p.stats + ((long)bx * WNW + wn) * p.Cout * 3;      // (Chan's update: exact in real arithmetic, no cancellation)
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-          float a = ssum[i][ps], b = ssq[i][ps];
+          float n = scnt[i][ps];
+          const float inv = n > 0.f ? 1.0f / n : 0.f;
+          float mu = sref[i][ps] + ssum[i][ps] * inv;
+          float m2 = fmaxf(ssq[i][ps] - ssum[i][ps] * ssum[i][ps] * inv, 0.f);
 #pragma unroll
-          for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+          for (int o = 1; o < 8; o <<= 1) {
+            const float n2 = __shfl_xor(n, o), mu2 = __shfl_xor(mu, o), m22 = __shfl_xor(m2, o);
+            const float nt = n + n2, dl = mu2 - mu, wgt = nt > 0.f ? n2 / nt : 0.f;
+            // (symmetric in the two partners up to rounding; both lanes keep the merged triple)
+            mu = n >= n2 ? mu + dl * wgt : mu2 - dl * (nt > 0.f ? n / nt : 0.f);
+            m2 = m2 + m22 + dl * dl * (nt > 0.f ? n * n2 / nt : 0.f);
+            n = nt;
+          }
           const int m = bm0 + wm * (BM / 2) + 32 * i + er + 8 * ps;
-          if ((lane & 7) == 0 && m < p.Cout) { row[2 * m] = a; row[2 * m + 1] = b; }
+          if ((lane & 7) == 0 && m < p.Cout) { row[3 * m] = n; row[3 * m + 1] = mu; row[3 * m + 2] = m2; }
         }
     }
   }
@@ -678,6 +720,8 @@ struct WArgs {
   int tiles, tiles_per_split;
   unsigned x_bytes, dy_bytes;
   int x_bf16;             // x is stored as bf16 (see PArgs)
+  int dy_bf16;            // dy is stored as bf16 (the bf16-stored input of a transposed convolution, whose weight gradient has it in this role)
+  InFold fold;            // optional input transform of x (pconv.h): the normalise-modulate of the BatchNorm that reads x, as in pconv_k
   int xgyz, xchunk, xitems, xgy;      // XCD-aware workgroup order (xchunk > 0): 1-D grid, see pbww_k
 };
 
@@ -756,6 +800,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   constexpr int NXI = NQ * (BC / 8), XR = (NXI + NT - 1) / NT;           // x items (channel octet, patch pixel)
   float4 pdy[DR][2];
   float px[XR][8];
+  bool pxin[XR];           // (fold) the staged patch pixel lies inside the map: padding must stay zero
   auto tile_origin = [&](int tile, int& img0, int& ty0, int& tx0) {
     if constexpr (TI == 1) {
       img0 = tile / tpi;
@@ -775,6 +820,16 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       // (16-byte buffer loads are not usable here: this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to ONE dword
       //  load; plain 16-byte global loads from a clamped, always-valid address + a select instead)
       const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px_) : 0;
+      if (p.dy_bf16) {      // eight bf16 in one 16-byte load (bf16 -> fp32 is a shift)
+        const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.dy) + idx);
+        const float4 lo = {__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                           __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+        const float4 hi = {__builtin_bit_cast(float, b.z << 16), __builtin_bit_cast(float, b.z & 0xffff0000u),
+                           __builtin_bit_cast(float, b.w << 16), __builtin_bit_cast(float, b.w & 0xffff0000u)};
+        pdy[sl][0] = ok ? lo : float4{0.f, 0.f, 0.f, 0.f};
+        pdy[sl][1] = ok ? hi : float4{0.f, 0.f, 0.f, 0.f};
+        return;
+      }
       const float4 lo = *reinterpret_cast<const float4*>(p.dy + idx);
       const float4 hi = *reinterpret_cast<const float4*>(p.dy + idx + 4);
       pdy[sl][0] = ok ? lo : float4{0.f, 0.f, 0.f, 0.f};
@@ -789,6 +844,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
       const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
       const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
+      pxin[sl] = ok;
       if (p.x_bf16) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
@@ -827,11 +883,23 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       }
     }
   };
+  int img0_staged = 0;      // first image of the tile whose operands are in the prefetch registers
   auto sstore_x = [&](int r, int sl) {
     {
       const int e = tid + NT * r;
       if (NXI % NT != 0 && e >= NXI) return;
       const int oc = e / NQ, q = e - oc * NQ;
+      if (p.fold.scale && pxin[sl]) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS (see pconv_k)
+        const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
+        const float4* const mp = reinterpret_cast<const float4*>(p.fold.mean + ch);
+        const float4* const sp = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch);
+        const float4* const hp = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch);
+        const float4 m0 = mp[0], m1 = mp[1], s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
+        px[sl][0] = fmaf(px[sl][0] - m0.x, s0.x, h0.x); px[sl][1] = fmaf(px[sl][1] - m0.y, s0.y, h0.y);
+        px[sl][2] = fmaf(px[sl][2] - m0.z, s0.z, h0.z); px[sl][3] = fmaf(px[sl][3] - m0.w, s0.w, h0.w);
+        px[sl][4] = fmaf(px[sl][4] - m1.x, s1.x, h1.x); px[sl][5] = fmaf(px[sl][5] - m1.y, s1.y, h1.y);
+        px[sl][6] = fmaf(px[sl][6] - m1.z, s1.z, h1.z); px[sl][7] = fmaf(px[sl][7] - m1.w, s1.w, h1.w);
+      }
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
@@ -853,6 +921,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   auto gload = [&](int tile) {
     int img0, ty0, tx0;
     tile_origin(tile, img0, ty0, tx0);
+    img0_staged = img0;
 #pragma unroll
     for (int r = 0; r < DR; ++r) gload_dy(img0, ty0, tx0, r, r);
 #pragma unroll
@@ -869,6 +938,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     } else {                                           // item by item through one register set
       int img0, ty0, tx0;
       tile_origin(tile, img0, ty0, tx0);
+      img0_staged = img0;
 #pragma unroll 2
       for (int r = 0; r < DR; ++r) { gload_dy(img0, ty0, tx0, r, 0); sstore_dy(r, 0); }
 #pragma unroll 2
@@ -1030,6 +1100,7 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
 int pconv_plan_splits(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0 ? pl.splits : -1; }
 long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
+long pconv_stat_row_floats(int Cout) { return 3L * Cout; }      // a partial row: [Cout][{count, mean, M2}]
 
 #ifndef AGL_PCONV_XCD
 #define AGL_PCONV_XCD 1
@@ -1073,12 +1144,15 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const bool small_grid = ptiles * agl_cdiv(a.Cout, bm) * (pl.splits > 1 ? pl.splits : 1) < 512;
   const bool w8 = (a.w8 || small_grid) && a.nsplit == 3 && !s2 && (a.ks == 3 || a.ks == 5) && geo != 2 && geo != 3;
   const int wcols = w8 ? 4 : 2;                 // wave columns = statistic rows per pixel tile
-  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 2 <= a.stats_floats) {
+  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 3 <= a.stats_floats) {
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
   }
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
+  p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend;
+  if ((a.y_bf16 || a.addend) && pl.splits > 1) return -1;            // (... writes fp32 in place)
+  if (a.y_bf16 && a.accumulate && !a.addend) return -1;              // (in-place accumulation reads y as fp32)
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), pl.splits > 1 ? agl_cdiv(nch, p.cps) : 1);
   pconv_xcd_order(p, g);
@@ -1292,8 +1366,9 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
-  p.x_bf16 = 0; p.mask_bf16 = 0;
-  p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * 4);
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr;
+  p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * (a.x_bf16 ? 2 : 4));
+  if (a.x_bf16 && a.nsplit != 1) return -1;
   if (a.nsplit == 1) {
     dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
     pconv_xcd_order(p, g);
@@ -1355,7 +1430,7 @@ long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel) {
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int geo, bm, splits; long ptiles;
   if (pconvT_plan(a, &geo, &bm, &ptiles, &splits) != 0) return -1;
-  if (a.OH == 2 * a.H + 1 && !a.w) return -1;      // (the edge kernel of the odd-sized form reads the unpacked weights)
+  if (a.OH == 2 * a.H + 1 && (!a.w || a.x_bf16)) return -1;      // (the edge kernel of the odd-sized form reads the unpacked weights and an fp32 dy)
   const long packed = a.packed ? 0 : pconvT_ws_bytes(a.Cin, a.Cout, a.nsplit), out_numel = (long)a.N * a.Cout * a.OH * a.OW;
   const long need = packed + (splits > 1 ? out_numel * 4 * splits : 0);
   if (need > 0 && (!ws || ws_bytes < need)) return -1;
@@ -1372,8 +1447,9 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
-  p.x_bf16 = 0; p.mask_bf16 = 0;
-  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * 4);
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr;
+  if (a.x_bf16 && a.nsplit != 1) return -1;
+  p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
   pconv_xcd_order(p, g, geo == 3 ? 4 : 2);
 #define PT_LAUNCH(TW_, TH_, TI_, BM_, NS_) hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, NS_, 4, true>), g, dim3(NT), 0, st, p)
@@ -1392,8 +1468,10 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   AGL_CHECK_LAUNCH(name);
   if (a.OH == 2 * a.H + 1) {      // odd-sized input: its last row and column
     dim3 ge((unsigned)(2 * a.N), agl_cdiv(a.Cout, 128));
-#define PE_LAUNCH(W_) hipLaunchKernelGGL((phase_edge_k<W_>), ge, dim3(128), 0, st, a.x, a.w, a.pos_mask, a.y, a.out_div, a.N, a.Cin, a.Cout, \
-                                        a.w_sm, a.w_sc, a.relu, a.accumulate, a.nsplit == 1)
+    // (the edge kernel reads the UNPACKED a.w, which by the ABI contract already is w0 / *out_div: no divisor here — the packed
+    //  phases above read w0 and divide in their epilogue)
+#define PE_LAUNCH(W_) hipLaunchKernelGGL((phase_edge_k<W_>), ge, dim3(128), 0, st, a.x, a.w, a.pos_mask, a.y, (const float*)nullptr, a.N, a.Cin, \
+                                        a.Cout, a.w_sm, a.w_sc, a.relu, a.accumulate, a.nsplit == 1)
     if (a.W == 8) PE_LAUNCH(8); else if (a.W == 16) PE_LAUNCH(16); else PE_LAUNCH(32);
 #undef PE_LAUNCH
     AGL_CHECK_LAUNCH(name);
@@ -1498,7 +1576,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
-  p.x_bf16 = a.x_bf16;
+  p.x_bf16 = a.x_bf16; p.dy_bf16 = a.dy_bf16; p.fold = a.fold;
+  if (a.dy_bf16 && (a.nsplit != 1 || (a.OW % 8 != 0 && !(a.OW == 4 && a.OH == 4)))) return -1;      // (16-byte pieces of 8 bf16)
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4)); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));

@@ -96,6 +96,74 @@ __global__ void crop_bwd(const float* __restrict__ dout, const float* __restrict
   if (yb && xb) atomicAdd(dst + (g.y0 + 1) * W + g.x0 + 1, d * (g.wx1 * g.wy1));
 }
 
+// One axis of crop_geom: source coordinate of crop sample j (of `steps`) of a box side [b0, b1] (already mapped to [-1, 1]).
+__device__ __forceinline__ float crop_axis(float b0, float b1, int j, int steps, int size, int align) {
+  float ws, we;
+  lin_weights(j, steps, ws, we);
+  return unnormalize(ws * b0 + we * b1, size, align);
+}
+// Candidate samples of one axis whose two taps can touch source position p: the coordinate is monotone in j and linear up to
+// rounding, so the range comes from the end points, widened by one sample on either side (every candidate is re-checked exactly).
+__device__ __forceinline__ void crop_axis_range(float b0, float b1, int steps, int size, int align, int p, int& lo, int& hi) {
+  lo = 0; hi = steps - 1;
+  if (steps < 2) return;
+  const float c0 = crop_axis(b0, b1, 0, steps, size, align), c1 = crop_axis(b0, b1, steps - 1, steps, size, align);
+  const float slope = (c1 - c0) / (float)(steps - 1);
+  if (!(fabsf(slope) > 1e-6f)) return;
+  const float ta = ((float)(p - 1) - c0) / slope, tb = ((float)(p + 1) - c0) / slope;
+  const float tlo = fminf(ta, tb), thi = fmaxf(ta, tb);
+  if (!(thi >= -2.f && tlo <= (float)steps + 1.f)) { lo = 1; hi = 0; return; }      // (empty: the box never reaches p)
+  lo = max(0, (int)floorf(fmaxf(tlo, -2.f)) - 1);
+  hi = min(steps - 1, (int)ceilf(fminf(thi, (float)steps + 1.f)) + 1);
+}
+
+// Backward of crop_fwd as a GATHER, for a non-decreasing box -> image map (the boxes of an image are a contiguous run — what
+// models/bilinear.py:77-90 builds and the training loop always passes): one thread per source element (n, c, y, x) walks the boxes
+// of its image in order and, per box, the crop samples (i, j) whose bilinear footprint covers (y, x), adding d * (wx * wy) in a
+// fixed order — no atomics, bit-reproducible.  Weights are those of crop_fwd (same functions).  dfeats is added to.
+__global__ void crop_bwd_sorted(const float* __restrict__ dout, const float* __restrict__ boxes, const long long* __restrict__ o2i,
+                                float* __restrict__ dfeats, int N, int B, int C, int H, int W, int HH, int WW, int align) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long total = (long)N * C * H * W;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  long t = idx / W;
+  const int y = (int)(t % H); t /= H;
+  const int c = (int)(t % C);
+  const int n = (int)(t / C);
+  auto lower = [&](long long v) {          // first box whose image id is >= v
+    int lo = 0, hi = B;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (o2i[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int b0 = lower(n), b1 = lower((long long)n + 1);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* box = boxes + 4 * b;
+    const float bx0 = 2.f * box[0] - 1.f, by0 = 2.f * box[1] - 1.f, bx1 = 2.f * box[2] - 1.f, by1 = 2.f * box[3] - 1.f;
+    int ilo, ihi, jlo, jhi;
+    crop_axis_range(by0, by1, HH, H, align, y, ilo, ihi);
+    crop_axis_range(bx0, bx1, WW, W, align, x, jlo, jhi);
+    const float* d = dout + ((long)b * C + c) * HH * WW;
+    for (int i = ilo; i <= ihi; ++i) {
+      const float iy = crop_axis(by0, by1, i, HH, H, align), fy = floorf(iy);
+      const int y0 = (int)fy;
+      const float wy1 = iy - fy;
+      float wy;
+      if (y0 == y) wy = 1.f - wy1; else if (y0 + 1 == y) wy = wy1; else continue;
+      for (int j = jlo; j <= jhi; ++j) {
+        const float ix = crop_axis(bx0, bx1, j, WW, W, align), fx = floorf(ix);
+        const int x0 = (int)fx;
+        const float wx1 = ix - fx;
+        float wx;
+        if (x0 == x) wx = 1.f - wx1; else if (x0 + 1 == x) wx = wx1; else continue;
+        acc += d[i * WW + j] * (wx * wy);
+      }
+    }
+  }
+  dfeats[idx] += acc;
+}
+
 // ---------------------------------------------------------------- ConvLSTM gates (i, f, o, g order)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -698,6 +766,19 @@ int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_
   if (B == 0) return AGL_OK;
   LAUNCH1D(crop_bwd, (long)B * C * HH * WW, dout, boxes, box_to_img, dfeats, N, B, C, H, W, HH, WW, align_corners);
   AGL_CHECK_LAUNCH("agl_crop_bwd");
+  return AGL_OK;
+}
+
+// The same gradient for a NON-DECREASING box_to_img (boxes of an image contiguous, as models/bilinear.py:77-90 and the training
+// loop build them): a gather in fixed order, no atomics — bit-reproducible.  The caller guarantees the order (checked on the host
+// where the map lives on the CPU); boxes whose image index is outside [0, N) contribute nothing.
+int agl_crop_bwd_sorted(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C, int H,
+                        int W, int HH, int WW, int align_corners, void* stream) {
+  AGL_REQUIRE(dout && boxes && box_to_img && dfeats, "agl_crop_bwd_sorted: null pointer");
+  AGL_REQUIRE(N > 0 && B >= 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "agl_crop_bwd_sorted: bad extent");
+  if (B == 0) return AGL_OK;
+  LAUNCH1D(crop_bwd_sorted, (long)N * C * H * W, dout, boxes, box_to_img, dfeats, N, B, C, H, W, HH, WW, align_corners);
+  AGL_CHECK_LAUNCH("agl_crop_bwd_sorted");
   return AGL_OK;
 }
 

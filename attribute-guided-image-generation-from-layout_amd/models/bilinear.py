@@ -18,7 +18,7 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn', al
         lo, hi = int(bbox_to_feats.min()), int(bbox_to_feats.max())
         if lo < 0 or hi >= feats.size(0):
             raise IndexError("crop_bbox_batch: bbox_to_feats must lie in [0, %d), got [%d, %d]" % (feats.size(0), lo, hi))
-    return _F.crop_boxes(feats, bbox, bbox_to_feats.to(feats.device).long(), HH, WW, align_corners)
+    return _F.crop_boxes(feats, bbox, _F.L.box_map_to_device(bbox_to_feats, feats.device), HH, WW, align_corners)
 
 
 crop_bbox_batch_cudnn = crop_bbox_batch
@@ -28,4 +28,5 @@ def crop_bbox(feats, bbox, HH, WW=None, backend='cudnn', align_corners=False):
     """Per-map crop: crops[i] from feats[i] (reference :107)."""
     assert bbox.size(0) == feats.size(0) and bbox.size(1) == 4
     idx = torch.arange(feats.size(0), device=feats.device)
+    idx._agl_sorted = True      # (one box per map, in order: the fixed-order backward applies)
     return _F.crop_boxes(feats, bbox, idx, HH, WW, align_corners)

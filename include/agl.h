@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 4
+#define AGL_ABI_VERSION 5
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -65,6 +65,7 @@ const char* agl_last_error(void);
                            * (agl_conv2d_fwd_packed_bytes != 0 / agl_conv2d_bwd_weight_takes_bf16_x); otherwise the call is rejected. */
 #define AGL_CONV_Y_BF16 (1 << 18) /* agl_conv2d_fwd: y points to bf16 elements (round to nearest even; no accumulate) — only the few-input-
                            * channel stream kernel (Cin <= 4, 1x1 / 3x3, stride 1, W % 4 == 0) writes that form; otherwise rejected */
+#define AGL_CONV_DY_BF16 (1 << 20) /* agl_conv2d_bwd_weight: dy points to bf16 elements; needs agl_conv2d_bwd_weight_takes_bf16_dy(...) == 1 */
 #define AGL_CONV_MASK_BF16 (1 << 19) /* agl_conv2d_bwd_data: pos_mask points to bf16 elements (the bf16-stored output of the producer
                            * whose ReLU backward this call applies); needs agl_conv2d_bwd_data_takes_bf16_mask(...) == 1 */
 long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2);
@@ -92,7 +93,8 @@ int agl_conv2d_last_pipe(void);
 /* The same forward (no output ReLU, no accumulate) that may also leave the BatchNorm partial sums of its output in
  * `stats` — the statistics pass of the nn.BatchNorm2d that follows the convolution (generator_obj_att.py:54-57, 433, 583;
  * normalization.py:77-78 + 97) then needs no read of y.  stats: stats_floats floats (agl_conv2d_fwd_stats_floats());
- * *stat_rows = rows written, each row = [Cout][{sum, sum of squares}] over a disjoint set of output pixels — 0 when the
+ * *stat_rows = rows written, each row = [Cout][{count, mean, M2 = sum of squared deviations from that mean}] over a disjoint set
+ * of output pixels (shift-invariant: a channel offset of 100 standard deviations costs no accuracy) — 0 when the
  * launch that ran does not produce them (the caller then uses agl_bn_stats).  Feed the rows to agl_bn_stats_from_partials. */
 long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW);
 int agl_conv2d_fwd_stats(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
@@ -107,6 +109,41 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
 long agl_conv2d_bwd_weight_ws_bytes(int N, int Cin, int Cout, int ks, int OH, int OW);
 int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
 int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+/* bf16-stored operands of the other passes (bf16 arithmetic only; each producer asks the matching predicate before it writes bf16):
+ * AGL_CONV_Y_BF16 on agl_conv2d_fwd also covers the matrix-core patch kernel (no reduction split): agl_conv2d_fwd_writes_bf16_y;
+ * AGL_CONV_X_BF16 on agl_conv2d_bwd_data: dy holds bf16 (the bf16-stored input of a ConvTranspose2d, generator_obj_att.py:532-540,
+ * whose forward IS this call): agl_conv2d_bwd_data_takes_bf16_dy;  AGL_CONV_DY_BF16 on agl_conv2d_bwd_weight: dy holds bf16 (the
+ * same tensor in the weight gradient of that transposed convolution): agl_conv2d_bwd_weight_takes_bf16_dy. */
+int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int relu, int accumulate,
+                                 int flags);
+int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+/* ---- normalise-modulate folded into the consuming convolution (BASELINE north_star; SURVEY a2 "apply+ReLU into next conv prologue").
+ * conv(relu(CondBN(x))) — generator_obj_att.py:395-416 (CropEncoder), :494-504 (LayoutEncoder), :437-446 (GlobalEncoder) — without
+ * ever storing the normalised tensor: agl_norm_fold_table turns (mean, rstd, affine / class-table parameters) into per-(row, channel)
+ * tables scale = rstd * gamma, shift = beta (row = object for ConditionalBatchNorm2d, one row otherwise); agl_conv2d_fwd_fold applies
+ * v = (x - mean[c]) * scale[r][c] + shift[r][c] (then the ReLU, then the zero padding) while it stages its input patch — forms of
+ * the matrix-core patch kernel (agl_conv2d_fwd_fold_ok), optionally leaving the BatchNorm partial rows of its own output like
+ * agl_conv2d_fwd_stats; agl_conv2d_bwd_weight_fold applies the same transform to the raw x in the weight gradient; agl_norm_bwd_fold
+ * is agl_norm_bwd for a y that does not exist: the ReLU mask is recomputed from x with the staging pass's expression. */
+int agl_norm_fold_table(const float* mean, const float* rstd, int mode, const float* p0, const float* p1, const long long* labels, int N, int C,
+                        float* scale, float* shift, void* stream);
+int agl_conv2d_fwd_fold_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
+int agl_conv2d_fwd_fold(const float* x, const float* in_mean, const float* in_scale, const float* in_shift, int in_per_n, const float* w,
+                        const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin,
+                        int H, int W, int Cout, int ks, int stride, int pad, int in_relu, int flags, float* stats, long stats_floats,
+                        int* stat_rows, void* stream);
+int agl_conv2d_bwd_weight_fold_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_mean, const float* in_scale, const float* in_shift,
+                               int in_per_n, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N,
+                               int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate,
+                               int flags, void* stream);
+/* y = conv(x) + addend (+ bias, output ReLU) written out of place; with AGL_CONV_Y_BF16 the fp32 sum is rounded once to bf16.
+ * The shortcut sum of a discriminator block (discriminator.py:58-60, :97-99) in bf16 arithmetic.  Matrix-core patch kernel only
+ * (agl_conv2d_fwd_writes_bf16_y / agl_conv2d_fwd_packed_bytes for the same extents). */
+int agl_conv2d_fwd_addend(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* addend,
+                          float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int in_relu,
+                          int relu, int flags, void* stream);
 /* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] = sum over (n, oh, ow) of dy, added to dbias
  * when dbias_accumulate (its own flag: a spectrally normalised layer returns dw fresh but accumulates db in place).  The
  * matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway; *dbias_done (host int) is 1 when the call did so
@@ -168,6 +205,10 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
                  float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
                  int W, int src_w, void* ws, long ws_bytes, void* stream);
+int agl_norm_bwd_fold(const float* dy, const float* x, const float* mean, const float* rstd, const float* fold_scale, const float* fold_shift,
+                      int fold_per_n, int mode, const float* p0, const float* p1, const long long* labels, int relu, int batch_stats,
+                      float* dx, float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
+                      void* stream);
 
 /* ---- per-object bilinear crop (models/bilinear.py:26 crop_bbox_batch -> :107 crop_bbox -> F.grid_sample :136)
  * out[b] = bilinear resample of feats[box_to_img[b]] over boxes[b]=[x0,y0,x1,y1] in [0,1]; zero padding;
@@ -178,6 +219,11 @@ int agl_crop_fwd(const float* feats, const float* boxes, const long long* box_to
                  int H, int W, int HH, int WW, int align_corners, void* stream);
 int agl_crop_bwd(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C,
                  int H, int W, int HH, int WW, int align_corners, void* stream);
+/* The same gradient for a NON-DECREASING box_to_img (the boxes of an image form one contiguous run — what bilinear.py:77-90 builds
+ * and train64.py always passes): a gather in a fixed order instead of a scatter with atomics, bit-reproducible from run to run.
+ * The caller vouches for the order (the Python host checks it where the map lives on the CPU, as in the reference's loop). */
+int agl_crop_bwd_sorted(const float* dout, const float* boxes, const long long* box_to_img, float* dfeats, int N, int B, int C,
+                        int H, int W, int HH, int WW, int align_corners, void* stream);
 
 /* ---- ConvLSTM gate math (generator_obj_att.py:105-112), gates stored post-activation in i,f,o,g order */
 int agl_lstm_gates_fwd(const float* ccx, const long long* rows, const float* cch, const float* c_prev, float* h, float* c,

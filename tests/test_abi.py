@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     dll = ctypes.CDLL(L.LIB_PATH)
     for name in decls:
         assert hasattr(dll, name), f"{name} declared in include/agl.h but not exported by libagl.so"
-    assert dll.agl_version() >= 1
+    ver = int(re.search(r"#define\s+AGL_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "agl.h")).read()).group(1))
+    assert dll.agl_version() == ver == L.ABI_VERSION, (dll.agl_version(), ver, L.ABI_VERSION)
 
 
 def test_binding_table_matches_header():

@@ -654,8 +654,11 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
     the fp32 CPU oracle on the box's host cores.  The size-dependent kernel choices (200-workgroup threshold of the matrix-core
     kernels, reduction splits, 256-pixel tiles, packed-weight reuse) differ from the batch-2 fixture and the batch-8 test, so
     the arithmetic mode the bench's 128 px line is measured in is checked at exactly that size: losses <= 1 % relative, images
-    <= 5e-2 worst pixel and <= 1e-2 RMS relative to the image maximum, and every large per-tensor gradient norm within 10 %
-    (operands rounded to bf16: 2^-9 relative per operand, thousands of terms per output)."""
+    <= 5e-2 worst pixel and <= 1e-2 RMS relative to the image maximum, ALL eleven generator outputs (crops <= 5e-2 like the images
+    they are cut from; mu / logvar / the two re-encoded latents <= 3e-2 relative-to-max), every large per-tensor gradient norm
+    within 10 %, and every large gradient tensor's DIRECTION: relative L2 distance to the oracle's gradient <= 6e-2 for the
+    discriminators and <= 1.5e-1 for the generator (operands rounded to bf16: 2^-9 relative per operand, thousands of terms per
+    output; the generator's gradient additionally passes through the discriminators after their first lr*sign(g) update)."""
     from agl import synth
     from agl.trainer import Trainer, batch_to_device
     import oracle.step as OS
@@ -670,12 +673,13 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
     gen = torch.Generator().manual_seed(9)
     eps_d = [torch.randn(O, 64, generator=gen) for _ in range(3)]
     eps_g = [torch.randn(O, 64, generator=gen) for _ in range(3)]
-    norms, ref_norms = {}, {}
+    norms, ref_norms, grads, ref_grads = {}, {}, {}, {}
 
     def grab(which):
         def f(t):
             for k in which:
                 norms[k] = np.array([float(q.grad.double().norm()) for q in nets[k].parameters()])
+                grads[k] = [q.grad.detach().cpu().clone() for q in nets[k].parameters()]
         return f
 
     def grab_ref(which):
@@ -683,6 +687,7 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
             st = be.states()
             for k in which:
                 ref_norms[k] = np.array([float(v.grad.double().norm()) for v in st[k].values() if v.requires_grad])
+                ref_grads[k] = [v.grad.detach().clone() for v in st[k].values() if v.requires_grad]
         return f
 
     tr = Trainer(G, Di, Do, Da, pw, conv_dtype="bf16")
@@ -692,6 +697,16 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
     torch.cuda.synchronize()
     hip = tr.loss_dict()
     bc = {k: torch.from_numpy(v) for k, v in bn.items()}
+
+    # The discriminators' first Adam update is lr * sign(g): where bf16 noise flips the sign of a small gradient the two
+    # implementations' weights end up 2 lr apart, and the generator's gradient (which flows through the updated discriminators)
+    # would measure THAT instead of the kernels.  The oracle's D update is therefore replaced by a copy of the weights the HIP
+    # iteration used in its G step (its own D gradients are compared before that, from identical state).
+    def step_d_synced():
+        for P, net in ((ob.Pi, Di), (ob.Po, Do), (ob.Pa, Da)):
+            for name, q in net.named_parameters():
+                P[name].data.copy_(q.detach().cpu())
+    ob.step_d = step_d_synced
     ref, out_ref = OS.run_step(ob, bc, pw, eps_d, eps_g, on_d_backward=grab_ref(["D_img", "D_obj", "D_att"]),
                                on_g_backward=grab_ref(["G"]))
     for k, r in ref.items():
@@ -700,6 +715,13 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
         close(t, r, 5e-2, n + " (bf16 mode, 128 px, batch 32)")
         rms = float((t.detach().cpu() - r).pow(2).mean().sqrt() / r.abs().max())
         assert rms <= 1e-2, (n, rms)
+    out_names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift", "mu", "logvar",
+                 "z_rand_rec", "z_rand_shift"]
+    for n, t, r in zip(out_names, tr.last_outputs, out_ref):
+        tol = 5e-2 if (n.startswith("crops") or n.startswith("img")) else 3e-2
+        err = float((t.detach().cpu().double() - r.double()).abs().max() / max(float(r.abs().max()), 1e-6))
+        print(f"[config-3 size, bf16] output {n}: rel-to-max error {err:.2e} (limit {tol:.0e})")
+        close(t, r, tol, n + " (bf16 mode, 128 px, batch 32)")
     for k in nets:
         rel = np.abs(norms[k] - ref_norms[k]) / (ref_norms[k] + 1e-9)
         big = ref_norms[k] > 1e-2 * ref_norms[k].max()
@@ -707,6 +729,18 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
         bad = np.nonzero((rel > 0.10) & big)[0]
         print(f"[config-3 size, bf16] {k}: worst relative gradient-norm deviation {float(rel[big].max()):.2e}")
         assert bad.size == 0, (k, [(names[i], float(norms[k][i]), float(ref_norms[k][i])) for i in bad[:5]])
+    worst = {}
+    for k in nets:
+        names = [n for n, _ in nets[k].named_parameters()]
+        big = ref_norms[k] > 1e-2 * ref_norms[k].max()
+        dist = np.array([float((a.double() - r.double()).norm()) for a, r in zip(grads[k], ref_grads[k])])
+        rel2 = dist / (ref_norms[k] + 1e-30)
+        order = np.argsort(-(rel2 * big))
+        worst[k] = (float(rel2[big].max()), [(names[i], round(float(rel2[i]), 4)) for i in order[:4]])
+        print(f"[config-3 size, bf16] {k}: worst relative L2 gradient distance {worst[k][0]:.2e}  {worst[k][1]}")
+    for k in nets:
+        lim = 1.5e-1 if k == "G" else 6e-2
+        assert worst[k][0] <= lim, (k, worst[k])
 
 
 def test_concurrent_schedule_equals_sequential_schedule():

@@ -179,6 +179,43 @@ def test_crop_matches_reference_fixture(golden_dir):
             close(fg.grad, torch.from_numpy(g[k + "_dfeats"]), 1e-4, k + " dfeats")
 
 
+def test_crop_backward_in_fixed_order_for_a_sorted_box_map(golden_dir):
+    """agl_crop_bwd_sorted: with a non-decreasing box -> image map the gradient is a gather in fixed order —
+    equal to the reference fixture, to torch's grid_sample backward on boxes that leave the map / are tiny / degenerate, to the
+    scatter form, and bit-identical from run to run (the scatter's float atomics are not)."""
+    from agl import functional as F
+    from agl import lib as L
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    feats, boxes, o2i = torch.from_numpy(g["crop_feats"]), torch.from_numpy(g["crop_boxes"]), torch.from_numpy(g["crop_sorted_o2i"])
+    od = L.box_map_to_device(o2i, DEV)
+    assert od._agl_sorted and not getattr(L.box_map_to_device(torch.from_numpy(g["crop_unsorted_o2i"]), DEV), "_agl_sorted", False)
+    for HH, WW in ((8, 8), (5, 7), (32, 32)):
+        k = f"crop_sorted_{HH}x{WW}"
+        fg = dev(feats).requires_grad_(True)
+        F.crop_boxes(fg, dev(boxes), od, HH, WW).backward(dev(torch.from_numpy(g[k + "_gy"])))
+        close(fg.grad, torch.from_numpy(g[k + "_dfeats"]), 1e-4, k + " dfeats (gather form)")
+    # boxes past the borders, a one-pixel box, a zero-width box, a flipped box, several boxes per image, an image without boxes
+    N, Cc, H, W, s = 5, 3, 24, 40, 16
+    bx = torch.tensor([[-0.2, -0.1, 0.5, 0.6], [0.3, 0.2, 1.3, 1.1], [0.5, 0.5, 0.52, 0.53], [0.4, 0.1, 0.4, 0.9], [0.9, 0.8, 0.1, 0.2],
+                       [0.0, 0.0, 1.0, 1.0], [0.1, 0.6, 0.35, 0.95], [0.25, 0.25, 0.75, 0.75]])
+    o2 = torch.tensor([0, 0, 0, 1, 1, 3, 4, 4])
+    x = rn(N, Cc, H, W)
+    gy = rn(bx.shape[0], Cc, s, s, seed=1)
+    xr = x.clone().requires_grad_(True)
+    t = torch.linspace(0, 1, s)
+    X = (1 - t).view(1, 1, s) * (2 * bx[:, 0] - 1).view(-1, 1, 1) + t.view(1, 1, s) * (2 * bx[:, 2] - 1).view(-1, 1, 1)
+    Y = (1 - t).view(1, s, 1) * (2 * bx[:, 1] - 1).view(-1, 1, 1) + t.view(1, s, 1) * (2 * bx[:, 3] - 1).view(-1, 1, 1)
+    grid = torch.stack([X.expand(-1, s, s), Y.expand(-1, s, s)], dim=3)
+    TF.grid_sample(xr[o2], grid, mode="bilinear", padding_mode="zeros", align_corners=False).backward(gy)
+    d_sorted = L.crop_bwd(dev(gy), dev(bx), L.box_map_to_device(o2, DEV), (N, Cc, H, W))
+    d_atomic = L.crop_bwd(dev(gy), dev(bx), dev(o2), (N, Cc, H, W))
+    close(d_sorted, xr.grad, 2e-5, "gather form vs torch grid_sample backward")
+    close(d_sorted, d_atomic.cpu(), 2e-6, "gather form vs scatter form")
+    assert float(d_sorted[2].abs().max()) == 0.0, "an image without boxes receives no gradient"
+    for _ in range(3):
+        assert torch.equal(L.crop_bwd(dev(gy), dev(bx), L.box_map_to_device(o2, DEV), (N, Cc, H, W)), d_sorted), "not reproducible"
+
+
 def test_pool_upsample_sum_reparam_maskouter():
     from agl import functional as F
     x = rn(3, 5, 8, 12)
@@ -894,7 +931,10 @@ def test_packed_weight_cache_and_divisor(mode):
     from agl import lib as L
     flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
     ver = [0]
-    for (N, Cin, H, Cout, ks, stride, pad) in ((6, 64, 16, 64, 3, 1, 1), (5, 64, 8, 128, 1, 1, 0), (4, 64, 16, 64, 4, 2, 1), (3, 48, 32, 80, 5, 1, 2)):
+    # (the 33 x 33 case: odd-sized input of a 4x4 / stride-2 layer — its last row and column come from phase_edge_k, which reads the
+    #  unpacked, already divided weights: ADVICE r3, the divisor must not be applied twice there)
+    for (N, Cin, H, Cout, ks, stride, pad) in ((6, 64, 16, 64, 3, 1, 1), (5, 64, 8, 128, 1, 1, 0), (4, 64, 16, 64, 4, 2, 1), (3, 48, 32, 80, 5, 1, 2),
+                                               (3, 64, 33, 64, 4, 2, 1)):
         x, w = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5)
         OH = (H + 2 * pad - ks) // stride + 1
         dy = rn(N, Cout, OH, OH, seed=3)
@@ -920,7 +960,11 @@ def test_packed_weight_cache_and_divisor(mode):
             close(ys, y0 / 1.7, 1e-6, "forward with divisor == plain / sigma")
             assert L.bwd_data_packed_bytes(N, Cin, H, H, Cout, OH, OH, ks, stride, pad) > 0, "case must exercise the packed input-gradient path"
             dxs = L.conv2d_bwd_data(dyd, w_sn, (H, H), stride, pad, wsrc=src_sn)
-            close(dxs, dx0 / 1.7, 1e-6, "input gradient with divisor == plain / sigma")
+            # (odd-sized input in bf16 arithmetic: the edge kernel rounds w / sigma to bf16, the phases round w and divide afterwards)
+            close(dxs, dx0 / 1.7, 1e-2 if (H % 2 == 1 and mode == "bf16") else 1e-6, "input gradient with divisor == plain / sigma")
+            if H % 2 == 1:      # last row / column alone (1 / (2W) of the elements: an error there must not hide in the max)
+                close(dxs[:, :, -1, :], dx0[:, :, -1, :] / 1.7, 1e-2 if mode == "bf16" else 2e-6, "edge row with divisor")
+                close(dxs[:, :, :, -1], dx0[:, :, :, -1] / 1.7, 1e-2 if mode == "bf16" else 2e-6, "edge column with divisor")
             # new weight version: the cache must follow
             owner.data.mul_(-0.5)
             ver[0] += 1
@@ -1125,16 +1169,15 @@ def test_few_channel_7x7_as_vertical_conv_plus_diagonal_sum(case, mode):
 
 
 def test_conv_batchnorm_partials_with_a_large_channel_offset():
-    """the convolution epilogue accumulates (sum, sum of squares) per lane in fp32 before the rows are added in double, and
-    the variance is E[x^2] - mean^2; for a channel with |mean| >> std the cancellation costs ~1e-7 * mean^2 / var relative to the
-    variance.  The generator's convolutions in front of a BatchNorm have no bias and near-zero means (measured mean/std <= ~1 on the
-    path), so the fused form is used there; this test pins the behaviour OUTSIDE that regime: with mean/std = 100 (a bias of 100 on
-    unit-variance outputs) the fused statistics must still agree with agl_bn_stats (double accumulation of the squares) to 1e-2 in
-    rstd and 1e-5 in the mean — and to 1e-5 / 1e-4 at mean/std = 3."""
+    """the convolution epilogue's BatchNorm partials are shift-invariant — every lane accumulates deviations from
+    the first value it sees, a partial row is (count, mean, M2), and rows are merged with Chan's update in double — so a channel with
+    |mean| >> std costs no accuracy (raw fp32 sum / sum-of-squares partials lost 1e-2 of rstd at mean/std = 100).  With a bias of 100
+    or 1000 on unit-variance outputs the fused statistics agree with agl_bn_stats (double accumulation over the stored tensor) to
+    1e-4 in rstd and 1e-6 of the mean; the same at mean/std = 3."""
     from agl import lib as L
     N, Cin, H, Cout = 8, 32, 16, 64
     x, w = rn(N, Cin, H, H), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5)
-    for offset, tol_rstd in ((100.0, 1e-2), (3.0, 1e-4)):
+    for offset, tol_rstd in ((1000.0, 1e-4), (100.0, 1e-4), (3.0, 1e-4)):
         b = torch.full((Cout,), offset)
         with L.conv_flags(L.CONV_SPLIT3 | L.CONV_ANY_GRID):
             y, part, rows = L.conv2d_fwd_stats(dev(x), dev(w), dev(b), 1, 1)
@@ -1144,7 +1187,7 @@ def test_conv_batchnorm_partials_with_a_large_channel_offset():
         m2, r2 = L.bn_stats(y, 1e-5, 0.1)
         std = float((1.0 / r2).mean())
         assert abs(float(m2.mean()) / std) > 0.5 * offset / 1.2, "the case must have the intended mean / std ratio"
-        close(m1, m2, 1e-5, f"mean at offset {offset}")
+        close(m1, m2, 1e-6, f"mean at offset {offset}")
         rel = float(((r1 - r2).abs() / r2).max())
         assert rel <= tol_rstd, (offset, rel)
 
