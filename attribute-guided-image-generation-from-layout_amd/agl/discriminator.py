@@ -15,6 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import dtrunk as T
 from . import functional as F
 from . import lib as L
 from . import nn as A
@@ -120,8 +121,28 @@ class _Discriminator(nn.Module):
 
     def _trunk(self, x, W):
         A._need_device(x)
+        blocks = list(self.main)
+        k0 = k1 = 0
+        if W is not None and x.dim() == 4 and x.shape[1] == 3:
+            # bf16 arithmetic: a prefix of the block chain as ONE graph node with bf16-stored activations inside (agl.dtrunk)
+            kinds = [("first_down" if b.downsample else "first_flat") if isinstance(b, OptimizedBlock) else "down" for b in blocks]
+            if all(b.downsample for b in blocks[1:]) and all(getattr(b, "learnable_sc", False) for b in blocks):
+                chans = [(b.resi[0].in_channels, b.resi[2].out_channels) if isinstance(b, OptimizedBlock)
+                         else (b.resi[1].in_channels, b.resi[3].out_channels) for b in blocks]
+                k0, k1, out16 = T.cover(kinds, chans, x.shape[0], x.shape[2], x.shape[3])
         h = x
-        for blk in self.main:
+        for blk in blocks[:k0]:
+            h = blk(h, W)
+        if k1 > k0:
+            spec, params = [], []
+            for b, kind in zip(blocks[k0:k1], kinds[k0:k1]):
+                c1, c2 = (b.resi[0], b.resi[2]) if isinstance(b, OptimizedBlock) else (b.resi[1], b.resi[3])
+                spec.append((kind, not isinstance(b, OptimizedBlock)))
+                for m in (c1, c2, b.sc):
+                    w = _w(W, m)
+                    params += [w if w is not None else m.weight, m.bias]
+            h = T.run(h, spec, out16, params)
+        for blk in blocks[k1:]:
             h = blk(h, W)
         return F.sum_hw(h, in_relu=True)
 

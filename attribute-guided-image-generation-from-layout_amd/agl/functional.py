@@ -307,6 +307,222 @@ def conv_transpose2d_k4s2p1(x, w):
 
 
 # --------------------------------------------------------------------------- normalisation
+def _batch_statistics(x, rmean, rvar, nbt, training):
+    """(mean, rstd) of a BatchNorm over x: batch statistics (+ the running update, taped / deferred as the schedule asks) in
+    training mode — from the partial rows the producing convolution left, when it did — else the running statistics."""
+    part, rows = _take_stats(x)
+    if not training:
+        return L.bn_stats_eval(rmean, rvar, BN_EPS)
+    # on a tape the call also leaves its (mean, unbiased variance) in double: the replay re-applies the running update
+    # from them — the same arithmetic on the same numbers, without a second read of the activation
+    defer = BN_DEFER is not None and rmean is not None
+    taped = BN_TAPE is not None and rmean is not None
+    mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device) if (taped or defer) else None
+    upd = (None, None, None) if defer else (rmean, rvar, nbt)      # deferred: the kernel leaves the running statistics alone
+    if part is not None:
+        mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, *upd, moments=mom)
+    else:
+        mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, *upd, moments=mom)
+    if defer:
+        BN_DEFER.append((mom, rmean, rvar, nbt))
+    if taped:
+        BN_TAPE.append(("bn", mom, rmean, rvar, nbt))
+    return mean, rstd
+
+
+class _NormConv(torch.autograd.Function):
+    """conv2d(relu?(norm(x)), w, bias) with the normalise-modulate folded into the convolution's input staging (BASELINE north_star;
+    SURVEY a2): norm = BatchNorm2d without / with affine parameters (mode 0 / 1) or ConditionalBatchNorm2d (mode 2,
+    generator_obj_att.py:31-44).  The normalised tensor is never stored: the forward is statistics (from the producer's partial rows
+    where it left them) -> table kernel -> agl_conv2d_fwd_fold; the backward is the convolution's input gradient -> agl_norm_bwd_fold
+    (ReLU mask recomputed from x) and agl_conv2d_bwd_weight_fold (same transform on the raw x).  NORM_FOLD / conv_fold_ok say when."""
+
+    @staticmethod
+    def forward(ctx, x, p0, p1, labels, rmean, rvar, nbt, mode, relu, training, w, bias, stride, pad):
+        global _LAST_STATS
+        ctx.pslots = (_slot(p0), _slot(p1))
+        ctx.wslots = (_slot(w), _slot(bias))
+        ctx.wsrc = wsrc = getattr(w, "_agl_wsrc", None)
+        x, w = _c(x), _c(w)
+        mean, rstd = _batch_statistics(x, rmean, rvar, nbt, training)      # (consumes / clears _LAST_STATS)
+        p0c = _c(p0) if p0 is not None else None
+        fold = L.norm_fold_table(mean, rstd, mode, p0c, p1, labels, x.shape[0])
+        y, part, rows = L.conv2d_fwd_fold(x, fold, w, bias, stride, pad, relu, wsrc=wsrc, want_stats=EMIT_STATS)
+        _LAST_STATS = (y, y._version, part, rows) if part is not None else None
+        ctx.cfg = (mode, relu, training, stride, pad, bias is not None)
+        ctx.fold = fold
+        ctx.save_for_backward(x, mean, rstd, p0c, p1, labels, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, relu, training, stride, pad, has_bias = ctx.cfg
+        x, mean, rstd, p0, p1, labels, w = ctx.saved_tensors
+        fold = ctx.fold
+        dy = _c(dy)
+        need = ctx.needs_input_grad
+        ks = w.shape[2]
+        dx = dp0 = dp1 = dw = db = None
+        # weight (and bias) gradient: the same transform on the raw x while it is staged
+        wslot, bslot = ctx.wslots
+        want_b = has_bias and need[11]
+        if need[10]:
+            if wslot is not None:
+                fuse_b = want_b and bslot is not None
+                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight_fold(dy, x, fold, ks, stride, pad, relu, out=wslot, accumulate=True,
+                                                                   dbias=bslot if fuse_b else None), dy, x, fold.scale, fold.shift, mean)
+            else:
+                fuse_b = want_b
+                if fuse_b and bslot is None:
+                    db = torch.empty(w.shape[0], dtype=torch.float32, device=dy.device)
+                dw = L.conv2d_bwd_weight_fold(dy, x, fold, ks, stride, pad, relu, dbias=(bslot if bslot is not None else db) if fuse_b else None,
+                                              dbias_accumulate=bslot is not None)
+            want_b = want_b and not fuse_b
+        if want_b:
+            if bslot is not None:
+                L.channel_sum(dy, out=bslot, accumulate=True)
+            else:
+                db = L.channel_sum(dy)
+        if need[0] or need[1] or need[2]:
+            g = L.conv2d_bwd_data(dy, w, (x.shape[2], x.shape[3]), stride, pad, wsrc=ctx.wsrc)      # w.r.t. the (never stored) activation
+            s0, s1 = ctx.pslots
+            in_slots = False
+            if mode == 1:
+                if s0 is not None and s1 is not None and need[1] and need[2]:
+                    dp0, dp1, in_slots = s0, s1, True
+                else:
+                    dp0, dp1 = torch.empty_like(p0), torch.empty_like(p1)
+            elif mode == 2:
+                if s0 is not None and need[1]:
+                    dp0, in_slots = s0, True
+                else:
+                    dp0 = torch.zeros_like(p0)
+            dx = L.norm_bwd_fold(g, x, mean, rstd, fold, mode, p0, p1, labels, relu, training, dp0, dp1, param_accumulate=in_slots)
+            if in_slots:
+                dp0 = dp1 = None
+        return dx, dp0, dp1, None, None, None, None, None, None, None, dw, db, None, None
+
+
+NORM_FOLD = os.environ.get("AGL_NORM_FOLD", "1") != "0"      # A/B switch: 0 = normalise-modulate as its own pass in front of the convolution
+
+
+def norm_conv2d(x, norm, labels, conv, relu=True, training=True):
+    """conv(relu?(norm(x))) for norm = agl.nn.BatchNorm2d (affine or not) or a ConditionalBatchNorm2d-like module (.bn, .embed) and
+    conv = agl.nn.Conv2d: folded into one convolution where the matrix-core kernels take the shape, else the two passes."""
+    bn = getattr(norm, "bn", norm)
+    if hasattr(norm, "embed"):
+        mode, p0, p1 = 2, norm.embed.weight, None
+    elif bn.affine:
+        mode, p0, p1 = 1, bn.weight, bn.bias
+    else:
+        mode, p0, p1 = 0, None, None
+    N, Cin, H, W = x.shape
+    ks, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    if NORM_FOLD and L.conv_fold_ok(N, Cin, H, W, conv.out_channels, ks, stride, pad, need_bww=conv.weight.requires_grad):
+        return _NormConv.apply(x, p0, p1, labels if mode == 2 else None, bn.running_mean, bn.running_var, bn.num_batches_tracked, mode, relu,
+                               training, conv.weight, conv.bias, stride, pad)
+    h = _NormAct.apply(x, p0, p1, None, labels if mode == 2 else None, bn.running_mean, bn.running_var, bn.num_batches_tracked, mode, relu, training)
+    return conv(h)
+
+
+def _spade_backward(g, x, y, mean, rstd, gb, relu, training, gather):
+    """Backward of the SPADE modulation (mode 3): (dx, d gamma|beta on gb's grid)."""
+    fused_reduce = gather is not None and x.shape[-1] in (64, 128) and x.shape[-2] == x.shape[-1]
+    dgb = (torch.empty_like(gb) if fused_reduce else
+           torch.empty((x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device))
+    dx = L.norm_bwd(g, x, y, mean, rstd, 3, gb, None, None, relu, training, dgb, None,
+                    gb_map=gather[0] if gather is not None else None, gb_lo=gather[1] if fused_reduce else None)
+    if gather is not None and not fused_reduce:
+        lo, h = gather[1], gb.shape[-1]
+        dsrc = torch.empty_like(gb)
+        L.call("agl_grid_gather_bwd", L.ptr(dgb), L.ptr(lo, torch.int32), L.ptr(lo, torch.int32), L.ptr(dsrc), dgb.shape[0] * dgb.shape[1],
+               h, h, dgb.shape[-1], dgb.shape[-1], L.stream())
+        dgb = dsrc
+    return dx, dgb
+
+
+class _SpadeThenConv(torch.autograd.Function):
+    """SPADE's normalise-modulate(+ReLU) (normalization.py:97,106) and the ONE layer that reads its output — a convolution
+    (generator_obj_att128.py:588-597: spade_4 -> c6) or a ConvTranspose2d(4, 2, 1) (generator_obj_att.py:546-572: spade_k -> dc_{k+1}) —
+    as one graph node, so that the modulated tensor never is an autograd edge: in bf16 arithmetic it is stored as bf16 (an edge of that
+    dtype would have its gradient cast by autograd).  Its readers — the consumer's forward, the consumer's weight gradient, the ReLU
+    mask of the modulation's backward — round it to bf16 when they stage it anyway: identical results at half the bytes on the largest
+    tensors of the decoder.  Same launches as spade_modulate + conv2d / conv_transpose2d_k4s2p1 otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, gb, rmean, rvar, nbt, relu, training, gather, w, bias, kind, stride, pad):
+        global _LAST_STATS
+        ctx.wslots = (_slot(w), _slot(bias))
+        ctx.wsrc = wsrc = getattr(w, "_agl_wsrc", None)
+        x, gb, w = _c(x), _c(gb), _c(w)
+        mean, rstd = _batch_statistics(x, rmean, rvar, nbt, training)
+        y16 = L.norm_apply_fwd(x, mean, rstd, 3, gb, None, None, None, relu, gb_map=gather[0] if gather is not None else None, out_bf16=True)
+        _LAST_STATS = None
+        if kind == "convT":
+            out = L.conv2d_bwd_data(y16, w, (2 * x.shape[2], 2 * x.shape[3]), 2, 1, wsrc=wsrc)
+        elif EMIT_STATS:
+            out, part, rows = L.conv2d_fwd_stats(y16, w, bias, stride, pad, wsrc=wsrc)
+            if part is not None:
+                _LAST_STATS = (out, out._version, part, rows)
+        else:
+            out = L.conv2d_fwd(y16, w, bias, stride, pad, wsrc=wsrc)
+        ctx.cfg = (relu, training, gather, kind, stride, pad, bias is not None)
+        ctx.save_for_backward(x, y16, mean, rstd, gb, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        relu, training, gather, kind, stride, pad, has_bias = ctx.cfg
+        x, y16, mean, rstd, gb, w = ctx.saved_tensors
+        dout = _c(dout)
+        need = ctx.needs_input_grad
+        dx = dgb = dw = db = None
+        g = None
+        if need[0] or need[1]:
+            if kind == "convT":
+                g = L.conv2d_fwd(dout, w, None, 2, 1, wsrc=ctx.wsrc)
+            else:
+                g = L.conv2d_bwd_data(dout, w, (x.shape[2], x.shape[3]), stride, pad, wsrc=ctx.wsrc)
+        if kind == "convT":
+            if need[8]:
+                wslot = ctx.wslots[0]
+                if wslot is not None:
+                    L.on_wgrad_stream(lambda: L.conv2d_bwd_weight(y16, dout, 4, 2, 1, out=wslot, accumulate=True), y16, dout)
+                else:
+                    dw = L.conv2d_bwd_weight(y16, dout, 4, 2, 1)
+        else:
+            dw, db = _conv_param_grads(ctx.wslots, need[8], has_bias and need[9], dout, y16, w, stride, pad, 0, False)
+        if g is not None:
+            dx, dgb = _spade_backward(g, x, y16, mean, rstd, gb, relu, training, gather)
+        return dx, dgb, None, None, None, None, None, None, dw, db, None, None, None
+
+
+SPADE_Y16 = os.environ.get("AGL_SPADE_Y16", "1") != "0"      # A/B switch: 0 keeps the modulated tensors in fp32 in bf16 arithmetic
+
+
+def spade_modulate_then(x, gb, rmean, rvar, nbt, relu, training, gather, consumer):
+    """spade_modulate(...) followed by `consumer` (agl.nn.Conv2d or agl.nn.ConvTranspose2d), with the modulated tensor stored as
+    bf16 between them where bf16 arithmetic and the kernels allow (_SpadeThenConv); else the two graph nodes."""
+    g = None
+    if gather is not None:
+        m, lo, src = _grid_map(gather[0], gather[1], gather[2], x.device)
+        assert gb.shape[2] == gb.shape[3] == src and x.shape[2] == x.shape[3] == m.numel(), (gb.shape, x.shape, gather)
+        g = (m, lo)
+    N, Cc, H, W = x.shape
+    is_t = isinstance(consumer, torch.nn.ConvTranspose2d)
+    w = consumer.weight
+    if is_t:
+        ok = SPADE_Y16 and L.norm_output_as_bf16(N, Cc, H, W, "convT", w.shape[1], need_bww=w.requires_grad)
+        kind, stride, pad, bias = "convT", 2, 1, None
+    else:
+        ks, stride, pad, bias = consumer.kernel_size[0], consumer.stride[0], consumer.padding[0], consumer.bias
+        ok = SPADE_Y16 and L.norm_output_as_bf16(N, Cc, H, W, "conv", w.shape[0], ks, stride, pad, need_bww=w.requires_grad)
+        kind = "conv"
+    if ok:
+        return _SpadeThenConv.apply(x, gb, rmean, rvar, nbt, relu, training, g, w, bias, kind, stride, pad)
+    return consumer(_NormAct.apply(x, gb, None, None, None, rmean, rvar, nbt, 3, relu, training, g))
+
+
 class _NormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p0, p1, residual, labels, rmean, rvar, nbt, mode, relu, training, gather=None):
@@ -315,24 +531,7 @@ class _NormAct(torch.autograd.Function):
         ctx.gather = gather
         gmap = gather[0] if gather is not None else None
         x = _c(x)
-        part, rows = _take_stats(x)
-        if training:
-            # on a tape the call also leaves its (mean, unbiased variance) in double: the replay re-applies the running update
-            # from them — the same arithmetic on the same numbers, without a second read of the activation
-            defer = BN_DEFER is not None and rmean is not None
-            taped = BN_TAPE is not None and rmean is not None
-            mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device) if (taped or defer) else None
-            upd = (None, None, None) if defer else (rmean, rvar, nbt)      # deferred: the kernel leaves the running statistics alone
-            if part is not None:
-                mean, rstd = L.bn_stats_from_partials(part, rows, x.shape[1], x.numel() // x.shape[1], BN_EPS, BN_MOMENTUM, *upd, moments=mom)
-            else:
-                mean, rstd = L.bn_stats(x, BN_EPS, BN_MOMENTUM, *upd, moments=mom)
-            if defer:
-                BN_DEFER.append((mom, rmean, rvar, nbt))
-            if taped:
-                BN_TAPE.append(("bn", mom, rmean, rvar, nbt))
-        else:
-            mean, rstd = L.bn_stats_eval(rmean, rvar, BN_EPS)
+        mean, rstd = _batch_statistics(x, rmean, rvar, nbt, training)
         p0c = _c(p0) if p0 is not None else None
         y = L.norm_apply_fwd(x, mean, rstd, mode, p0c, p1, labels, _c(residual) if residual is not None else None, relu, gb_map=gmap)
         ctx.cfg = (mode, relu, training, residual is not None)

@@ -127,10 +127,12 @@ class CropEncoder(nn.Module):
 
     def trunk(self, imgs, objs=None):
         """Everything up to (mu, logvar): independent of the random draw."""
-        x = imgs
-        for conv, bn in ((self.c1, self.bn1), (self.c2, self.bn2), (self.c3, self.bn3), (self.c4, self.bn4),
-                         (self.conv5, self.bn5)):
-            x = bn(conv(x), objs, relu=True)
+        # conv -> CondBN -> ReLU -> conv ...: every normalise-modulate(+ReLU) between two convolutions is folded into the staging pass
+        # of the convolution that consumes it (F.norm_conv2d: the normalised tensor is never stored); the last one feeds the spatial mean
+        x = self.c1(imgs)
+        for bn, conv in ((self.bn1, self.c2), (self.bn2, self.c3), (self.bn3, self.c4), (self.bn4, self.conv5)):
+            x = F.norm_conv2d(x, bn, objs, conv, relu=True, training=self.training)
+        x = self.bn5(x, objs, relu=True)
         x = F.sum_hw(x, False, 1.0 / (x.shape[2] * x.shape[3]))
         return self.fc_mu(x), self.fc_logvar(x)
 
@@ -151,7 +153,7 @@ class GlobalEncoder(nn.Module):
         self.c2 = A.Conv2d(128, 128, kernel_size=4, stride=2, padding=1, bias=False)
 
     def forward(self, h):
-        return F.sum_hw(self.c2(self.bn1(self.c1(h), relu=True)))
+        return F.sum_hw(F.norm_conv2d(self.c1(h), self.bn1, None, self.c2, relu=True, training=self.training))
 
 
 class LayoutEncoder(nn.Module):
@@ -209,9 +211,9 @@ class LayoutEncoder(nn.Module):
                                 bn.num_batches_tracked, self.training)
         else:
             h = self.c2(self.bn1(F.mask_outer(u, masks, 1), objs, relu=True))
-        h = self.bn2(h, objs, relu=True)
-        h = self.bn3(self.c3(h), objs, relu=True)
-        h = self.bn4(self.c4(h), objs)
+        h = F.norm_conv2d(h, self.bn2, objs, self.c3, relu=True, training=self.training)      # bn2 + ReLU folded into c3's staging pass
+        h = F.norm_conv2d(h, self.bn3, objs, self.c4, relu=True, training=self.training)      # bn3 + ReLU into c4's
+        h = self.bn4(h, objs)
         if self.pool_to_8:
             assert h.shape[2] == 16, "AdaptiveAvgPool2d(8) is an exact 2x2 mean on the 16x16 map of the 128 px model"
             h = F.avg_pool2(h)
@@ -238,7 +240,14 @@ class SPADE(nn.Module):
         """Parameters FlatParams should place back to back (their dim-0 concatenation becomes an arena view)."""
         return [("gb_weight", self.mlp_gamma.weight, self.mlp_beta.weight), ("gb_bias", self.mlp_gamma.bias, self.mlp_beta.bias)]
 
-    def forward(self, x, segmap, relu=False):
+    def forward(self, x, segmap, relu=False, then=None):
+        """then (optional): the ONE layer that reads the result (agl.nn.Conv2d / ConvTranspose2d); returns then(SPADE(x)) — as one graph
+        node with the modulated tensor stored as bf16 inside it where bf16 arithmetic allows (F.spade_modulate_then)."""
+        def modulate(gb, gather=None):
+            n = self.param_free_norm
+            if then is not None:
+                return F.spade_modulate_then(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training, gather, then)
+            return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training, gather=gather)
         f = x.shape[2] // segmap.shape[2]
         up = f.bit_length() - 1
         assert segmap.shape[2] << up == x.shape[2] and segmap.shape[3] << up == x.shape[3], "power-of-two nearest up-sampling only"
@@ -268,9 +277,7 @@ class SPADE(nn.Module):
             if f >= 8:
                 gb5 = F.conv2d(F.grid_gather(a3, "3to5", nb), w, b, 1, 1)
                 if self.fold_gather:         # the 5-classes-per-block grid is expanded inside the modulation kernel's reads
-                    n = self.param_free_norm
-                    return F.spade_modulate(x, gb5, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training,
-                                            gather=("5tof", nb, f))
+                    return modulate(gb5, ("5tof", nb, f))
                 gb = F.grid_gather(gb5, "5tof", nb, f)
             else:
                 gb = F.conv2d(F.grid_gather(a3, "3tof", nb, f), w, b, 1, 1)
@@ -278,8 +285,7 @@ class SPADE(nn.Module):
             # actv feeds exactly one convolution, which masks its input gradient by actv > 0 (no separate ReLU-backward pass)
             actv = self.mlp_shared[0](segmap, relu=True, up=up, relu_grad_by_consumer=True)
             gb = F.conv2d(actv, w, b, 1, 1, x_relu=True)
-        n = self.param_free_norm
-        return F.spade_modulate(x, gb, n.running_mean, n.running_var, n.num_batches_tracked, relu, self.training)
+        return modulate(gb)
 
 
 class Decoder(nn.Module):
@@ -309,17 +315,17 @@ class Decoder(nn.Module):
     def forward(self, hidden, global_h, z=None):
         seg = hidden
         h = self.c0_new(F.concat_channels(hidden, global_h))      # global vector broadcast over the 8x8 map
-        h = self.spade_0(h, seg, relu=True)
-        h = self.spade_1(self.dc1(h), seg, relu=True)
-        h = self.spade_2(self.dc2(h), seg, relu=True)
-        h = self.spade_3(self.dc3(h), seg, relu=True)
-        h = self.c4(h)
+        # every SPADE output has ONE reader, the layer behind it: passed as `then`, the pair is one graph node and the modulated
+        # tensor between them is stored as bf16 in bf16 arithmetic
+        h = self.spade_0(h, seg, relu=True, then=self.dc1)
+        h = self.spade_1(h, seg, relu=True, then=self.dc2)
+        h = self.spade_2(h, seg, relu=True, then=self.dc3)
+        h = self.spade_3(h, seg, relu=True, then=self.c4)
         if not self.res128:
             return h
         h = self.c5(h, up=1)                                   # nearest x2 folded into the 7x7 conv's gather
-        h = self.spade_4(h, seg, relu=True)
-        h = self.spade_5(self.c6(h), seg, relu=True)
-        return self.c7(h)
+        h = self.spade_4(h, seg, relu=True, then=self.c6)
+        return self.spade_5(h, seg, relu=True, then=self.c7)
 
 
 class AttributeEncoder(nn.Module):

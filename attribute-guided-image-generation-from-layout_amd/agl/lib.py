@@ -45,6 +45,8 @@ SIGNATURES = {
     "agl_conv2d_fwd_stats_floats": (_L, [_I] * 4),
     "agl_conv2d_fwd_stats": (_I, [_P] * 7 + [_L] + [_I] * 11 + [_P, _L, _P, _P]),
     "agl_norm_apply_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "agl_norm_apply_fwd_y16": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "agl_norm_bwd_y16": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _L, _P]),
     "agl_norm_bwd_ws_bytes": (_L, [_I, _I]),
     "agl_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _L, _P]),
     "agl_crop_fwd": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
@@ -63,6 +65,7 @@ SIGNATURES = {
     "agl_conv2d_bwd_weight_takes_bf16_x": (_I, [_I] * 11),
     "agl_conv2d_bwd_data_takes_bf16_mask": (_I, [_I] * 11),
     "agl_conv2d_fwd_writes_bf16_y": (_I, [_I] * 12),
+    "agl_conv2d_fwd_takes_bf16_x": (_I, [_I] * 9),
     "agl_conv2d_bwd_data_takes_bf16_dy": (_I, [_I] * 11),
     "agl_conv2d_bwd_weight_takes_bf16_dy": (_I, [_I] * 11),
     "agl_norm_fold_table": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
@@ -75,6 +78,10 @@ SIGNATURES = {
     "agl_box2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "agl_avgpool2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "agl_avgpool2_fwd_x16": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "agl_avgpool2_bwd_x16": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "agl_conv2d_fwd_shortcut_ok": (_I, [_I] * 8),
+    "agl_conv2d_fwd_shortcut": (_I, [_P] * 8 + [_I, _P, _P, _L] + [_I] * 10 + [_P]),
     "agl_upsample_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_upsample_nearest_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_sum_hw_fwd": (_I, [_P, _P, _L, _I, _I, _F, _P]),
@@ -158,7 +165,8 @@ def load() -> C.CDLL:
 # dense count minus the padded taps the position-major path skips) or algorithmic HBM bytes for the normalisation family.
 EVENT_LOG = None
 EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight", "agl_bn_stats",
-               "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd"}
+               "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd", "agl_conv2d_fwd_fold", "agl_conv2d_bwd_weight_fold",
+               "agl_conv2d_fwd_addend", "agl_conv2d_fwd_shortcut", "agl_norm_bwd_fold", "agl_norm_apply_fwd_y16", "agl_norm_bwd_y16"}
 
 # Convolution flags passed with every agl_conv2d_* call (include/agl.h AGL_CONV_*).  This is host-side state of the
 # Python binding only — the C ABI has no process-wide switches.
@@ -205,10 +213,23 @@ def work_of(name, args) -> float:
         return lib.agl_conv2d_bwd_data_flops(*args[9:19], args[21])
     if name == "agl_conv2d_bwd_weight":
         return lib.agl_conv2d_bwd_weight_flops(*args[8:20], args[21])
+    if name == "agl_conv2d_fwd_fold":
+        return lib.agl_conv2d_fwd_flops(*args[12:20], 0, args[21])
+    if name == "agl_conv2d_fwd_shortcut":
+        N, Cin, H, W, Cout, ks, pad = args[12:19]
+        return lib.agl_conv2d_fwd_flops(N, Cin, H, W, Cout, ks, 1, pad, 0, args[21]) + 2.0 * N * Cout * H * W * args[8]
+    if name == "agl_conv2d_fwd_addend":
+        return lib.agl_conv2d_fwd_flops(*args[9:17], 0, args[19])
+    if name == "agl_conv2d_bwd_weight_fold":
+        return lib.agl_conv2d_bwd_weight_flops(*args[12:22], 0, args[22], args[24])
+    if name == "agl_norm_bwd_fold":                  # dy, x read twice (sums, then apply); dx written — the mask costs no read
+        return 4.0 * args[16] * args[17] * args[18] * 5
     if name == "agl_bn_stats":                       # one read of x (4*N*C*HW)
         return 4.0 * args[1] * args[2] * args[3]
     if name == "agl_bn_stats_from_partials":         # the statistics read of x the fused form avoids: algorithmic bytes 0
         return 0.0
+    if name in ("agl_norm_apply_fwd_y16", "agl_norm_bwd_y16"):      # algorithmic bytes as the fp32 forms, whatever is stored
+        return work_of(name[:-4], args)
     if name == "agl_norm_apply_fwd":                 # x read + y write (+ gamma|beta planes for SPADE, + residual)
         mode, res, N, Cc, HW = args[3], args[7], args[10], args[11], args[12]
         return 4.0 * N * Cc * HW * (2 + (2 if mode == 3 else 0) + (1 if res is not None else 0))
@@ -371,20 +392,23 @@ def _packed_bytes(fn, *dims):
 
 
 # --------------------------------------------------------------------------- raw ops (no autograd)
-def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up):
+def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up, make=None):
     if wsrc is None or not (CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3)):
         return None, None
     nb = _packed_bytes("agl_conv2d_fwd_packed_bytes", N, Cin, H, W, Cout, ks, stride, pad, up, CONV_FLAGS)
     if not nb:
         return None, None
-    return wsrc.packed(0, nb, w, Cin, Cout, ks, stride), wsrc.div
+    return wsrc.packed(0, nb, w, Cin, Cout, ks, stride, make=make), wsrc.div
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None, out_bf16=False):
-    """out_bf16: y as a torch.bfloat16 tensor (first_conv_output_as_bf16 says when the kernel that runs can write it)."""
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None, out_bf16=False,
+               w_shape=None, make_base=None):
+    """out_bf16: y as a torch.bfloat16 tensor (agl_conv2d_fwd_writes_bf16_y says when the kernel that runs can write it).
+    w may be None when w_shape + wsrc + make_base are given: a derived weight that only exists in packed form (cached under wsrc;
+    make_base() builds the tensor to pack on a miss) — the call must then run on the matrix-core patch kernel."""
     N, Cin, H, W = x.shape
-    Cout, Cin_w, ks, ks2 = w.shape
-    assert Cin_w == Cin and ks == ks2, (x.shape, w.shape)
+    Cout, Cin_w, ks, ks2 = w.shape if w is not None else w_shape
+    assert Cin_w == Cin and ks == ks2, (x.shape, w_shape if w is None else w.shape)
     OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
     if out is None:
         assert not accumulate
@@ -393,13 +417,50 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
         assert tuple(out.shape) == (N, Cout, OH, OW)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
-    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up) if not (relu and accumulate) else (None, None)
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up, make=make_base) if not (relu and accumulate) else (None, None)
+    assert w is not None or pk is not None, "a derived weight needs the packed path"
     xb16 = x.dtype == torch.bfloat16      # a tensor its producer wrote in bf16 (box2_fwd(bf16=True)): matrix-core kernel only
     yb16 = out.dtype == torch.bfloat16
     call("agl_conv2d_fwd", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
          ptr(out, out.dtype if yb16 else torch.float32), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
          N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), int(relu), int(accumulate),
          CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0), stream())
+    return out
+
+
+def conv2d_fwd_addend(x, w, bias, addend, stride=1, pad=0, in_relu=False, relu=False, wsrc=None, out_bf16=False):
+    """y = conv(x) + addend (+ bias, ReLU) out of place (agl_conv2d_fwd_addend); y bf16 on request (the fp32 sum rounded once)."""
+    N, Cin, H, W = x.shape
+    Cout, _, ks, _ = w.shape
+    OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
+    assert tuple(addend.shape) == (N, Cout, OH, OW) and addend.dtype == torch.float32
+    out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0)
+    ws = workspace(need, x.device) if need else None
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, 0)
+    xb16 = x.dtype == torch.bfloat16
+    call("agl_conv2d_fwd_addend", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
+         ptr(addend), ptr(out, out.dtype), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+         N, Cin, H, W, Cout, ks, stride, pad, int(in_relu), int(relu),
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0), stream())
+    return out
+
+
+def conv2d_fwd_shortcut(x, w, bias, sc_x, sc_w, sc_bias, pad=1, in_relu=False, relu=False, wsrc=None, out_bf16=False):
+    """y = conv3x3(x) + bias + conv1x1(sc_x; sc_w, sc_bias) with the few-channel shortcut evaluated in the epilogue (agl_conv2d_fwd_shortcut)."""
+    N, Cin, H, W = x.shape
+    Cout, _, ks, _ = w.shape
+    sc_cin = sc_x.shape[1]
+    assert tuple(sc_x.shape) == (N, sc_cin, H, W) and sc_w.numel() == Cout * sc_cin
+    out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, 1, pad, 0)
+    ws = workspace(need, x.device) if need else None
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, 1, pad, 0)
+    xb16 = x.dtype == torch.bfloat16
+    call("agl_conv2d_fwd_shortcut", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv),
+         ptr(bias), ptr(sc_x), ptr(sc_w), ptr(sc_bias), sc_cin, ptr(out, out.dtype), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, pad, int(in_relu), int(relu),
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0), stream())
     return out
 
 
@@ -416,11 +477,99 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, wsrc
     stats = torch.empty(nst, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up)
-    call("agl_conv2d_fwd_stats", ptr(x), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out),
-         ws.data_ptr() if ws is not None else None,
-         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), CONV_FLAGS,
+    xb16 = x.dtype == torch.bfloat16
+    call("agl_conv2d_fwd_stats", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv),
+         ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0),
          stats.data_ptr(), nst, C.addressof(rows), stream())
     return out, (stats if rows.value > 0 else None), rows.value
+
+
+# ---- normalise-modulate folded into the consuming convolution (include/agl.h: agl_norm_fold_table, agl_conv2d_fwd_fold, ...)
+class Fold:
+    """Tables of a folded normalise-modulate: v = (x - mean[c]) * scale[r][c] + shift[r][c], r = object (per_n) or 0."""
+    __slots__ = ("mean", "scale", "shift", "per_n")
+
+    def __init__(self, mean, scale, shift, per_n):
+        self.mean, self.scale, self.shift, self.per_n = mean, scale, shift, int(per_n)
+
+
+def norm_fold_table(mean, rstd, mode, p0, p1, labels, N):
+    Cc = mean.numel()
+    rows = N if mode == 2 else 1
+    scale = torch.empty((rows, Cc), dtype=torch.float32, device=mean.device)
+    shift = torch.empty_like(scale)
+    call("agl_norm_fold_table", ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1), ptr(labels, torch.int64), N, Cc, ptr(scale), ptr(shift), stream())
+    return Fold(mean, scale, shift, mode == 2)
+
+
+def conv_fold_ok(N, Cin, H, W, Cout, ks, stride, pad, need_bww=True):
+    """True when conv(relu?(norm(x))) can run with the norm folded into the convolution's staging (forward and weight gradient)."""
+    if not (CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3)) or (CONV_FLAGS & CONV_NO_PATCH):
+        return False
+    lib = load()
+    if not lib.agl_conv2d_fwd_fold_ok(N, Cin, H, W, Cout, ks, stride, pad, CONV_FLAGS):
+        return False
+    OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
+    return (not need_bww) or bool(lib.agl_conv2d_bwd_weight_fold_ok(N, Cin, H, W, Cout, OH, OW, ks, stride, pad, CONV_FLAGS))
+
+
+def conv2d_fwd_fold(x, fold, w, bias=None, stride=1, pad=0, in_relu=False, wsrc=None, want_stats=False):
+    """conv(relu?(fold(x))) -> (y, BatchNorm partial rows of y or None, row count)."""
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, ks, _ = w.shape
+    assert Cin_w == Cin
+    OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
+    out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0)
+    ws = workspace(need, x.device) if need else None
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, 0)
+    stats = rows = None
+    nst = 0
+    if want_stats:
+        nst = load().agl_conv2d_fwd_stats_floats(N, Cout, OH, OW)
+        stats = torch.empty(nst, dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+    call("agl_conv2d_fwd_fold", ptr(x), ptr(fold.mean), ptr(fold.scale), ptr(fold.shift), fold.per_n, ptr(w),
+         pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, int(in_relu), CONV_FLAGS,
+         stats.data_ptr() if stats is not None else None, nst, C.addressof(rows) if rows is not None else None, stream())
+    if rows is not None and rows.value > 0:
+        return out, stats, rows.value
+    return out, None, 0
+
+
+def conv2d_bwd_weight_fold(dy, x, fold, ks, stride=1, pad=0, in_relu=False, out=None, accumulate=False, dbias=None, dbias_accumulate=None):
+    if dbias_accumulate is None:
+        dbias_accumulate = accumulate
+    N, Cout, OH, OW = dy.shape
+    _, Cin, H, W = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dy.device)
+    need = load().agl_conv2d_bwd_weight_ws_bytes(N, Cin, Cout, ks, OH, OW)
+    if accumulate:
+        need = max(need, Cout * Cin * ks * ks * 4)
+    ws = workspace(need, dy.device) if need else None
+    done = C.c_int(0)
+    call("agl_conv2d_bwd_weight_fold", ptr(dy), ptr(x), ptr(fold.mean), ptr(fold.scale), ptr(fold.shift), fold.per_n, ptr(out), ptr(dbias),
+         int(dbias_accumulate), C.addressof(done) if dbias is not None else None, ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, int(in_relu), int(accumulate), CONV_FLAGS, stream())
+    if dbias is not None and not done.value:
+        channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
+    return out
+
+
+def norm_bwd_fold(dy, x, mean, rstd, fold, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False):
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    nb = load().agl_norm_bwd_ws_bytes(N, Cc)
+    ws = workspace(nb, x.device)
+    call("agl_norm_bwd_fold", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(fold.scale), ptr(fold.shift), fold.per_n, mode, ptr(p0), ptr(p1),
+         ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW, p0.shape[0] if mode == 2 else 0,
+         int(param_accumulate), ws.data_ptr(), ws.numel(), stream())
+    return dx
 
 
 def bn_stats_from_partials(partials, rows, Cc, count, eps, momentum, running_mean=None, running_var=None, nbt=None, moments=None):
@@ -488,10 +637,11 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     if w is None and pk is None:
         w = make_w()
     mb16 = pos_mask is not None and pos_mask.dtype == torch.bfloat16
-    call("agl_conv2d_bwd_data", ptr(dy), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None,
+    db16 = dy.dtype == torch.bfloat16      # (the bf16-stored input of a transposed convolution: this call is its forward)
+    call("agl_conv2d_bwd_data", ptr(dy, dy.dtype if db16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None,
          ptr(pos_mask, torch.bfloat16 if mb16 else torch.float32), ptr(out),
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad,
-         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0), stream())
+         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0) | (CONV_X_BF16 if db16 else 0), stream())
     return out
 
 
@@ -510,14 +660,35 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
         need = max(need, Cout * Cin * ks * ks * 4)
     ws = workspace(need, dy.device) if need else None
     done = C.c_int(0)
-    xb16 = x.dtype == torch.bfloat16
-    call("agl_conv2d_bwd_weight", ptr(dy), ptr(x, x.dtype if xb16 else torch.float32), ptr(out), ptr(dbias), int(dbias_accumulate),
-         C.addressof(done) if dbias is not None else None,
+    xb16, db16 = x.dtype == torch.bfloat16, dy.dtype == torch.bfloat16
+    call("agl_conv2d_bwd_weight", ptr(dy, dy.dtype if db16 else torch.float32), ptr(x, x.dtype if xb16 else torch.float32), ptr(out), ptr(dbias),
+         int(dbias_accumulate), C.addressof(done) if dbias is not None else None,
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up,
-         int(in_relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0), stream())
+         int(in_relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_DY_BF16 if db16 else 0), stream())
     if dbias is not None and not done.value:
+        assert not db16
         channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
     return out
+
+
+def norm_output_as_bf16(N, Cc, H, W, consumer, Cout, ks=0, stride=1, pad=0, need_bww=True):
+    """True when the normalised (+ReLU'd) tensor (N, C, H, W) that feeds ONLY `consumer` — "conv": a convolution C -> Cout (forward
+    and weight gradient read it as x); "convT": ConvTranspose2d(4, 2, 1) C -> Cout (its forward is an input-gradient call with the
+    tensor in the dy role, its weight gradient has it in the dy role too) — can be stored as bf16 in bf16 arithmetic: every kernel
+    that would read it runs on the matrix cores and takes that form."""
+    if not (CONV_FLAGS & CONV_BF16) or (CONV_FLAGS & CONV_NO_PATCH) or W % 8 != 0:
+        return False
+    lib = load()
+    if consumer == "conv":
+        OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
+        if not lib.agl_conv2d_fwd_takes_bf16_x(N, Cc, H, W, Cout, ks, stride, pad, CONV_FLAGS):
+            return False
+        return (not need_bww) or bool(lib.agl_conv2d_bwd_weight_takes_bf16_x(N, Cc, H, W, Cout, OH, OW, ks, stride, pad, CONV_FLAGS))
+    if consumer == "convT":      # C-ABI roles: dx (N, Cout, 2H, 2W) from dy = the tensor (N, C, H, W), weights [C][Cout][4][4]
+        if not lib.agl_conv2d_bwd_data_takes_bf16_dy(N, Cout, 2 * H, 2 * W, Cc, H, W, 4, 2, 1, CONV_FLAGS):
+            return False
+        return (not need_bww) or bool(lib.agl_conv2d_bwd_weight_takes_bf16_dy(N, Cout, 2 * H, 2 * W, Cc, H, W, 4, 2, 1, CONV_FLAGS))
+    return False
 
 
 def channel_sum(x, out=None, accumulate=False):
@@ -549,14 +720,15 @@ def bn_stats_eval(running_mean, running_var, eps):
     return mean, rstd
 
 
-def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu, gb_map=None):
-    """gb_map (mode 3 only): int32 device tensor of W entries — p0 is then (N, 2C, s, s) on a coarser grid, read through the map."""
+def norm_apply_fwd(x, mean, rstd, mode, p0, p1, labels, residual, relu, gb_map=None, out_bf16=False):
+    """gb_map (mode 3 only): int32 device tensor of W entries — p0 is then (N, 2C, s, s) on a coarser grid, read through the map.
+    out_bf16: y as a torch.bfloat16 tensor (for consumers that are bf16-mode convolutions; the caller asked their predicates)."""
     N, Cc = x.shape[0], x.shape[1]
     HW = x.numel() // (N * Cc)
-    y = torch.empty_like(x)
-    call("agl_norm_apply_fwd", ptr(x), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1), ptr(labels, torch.int64),
-         ptr(residual), int(relu), ptr(y), N, Cc, HW, ptr(gb_map, torch.int32), x.shape[-1] if gb_map is not None else 0,
-         p0.shape[-1] if gb_map is not None else 0, stream())
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    call("agl_norm_apply_fwd_y16" if out_bf16 else "agl_norm_apply_fwd", ptr(x), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
+         ptr(labels, torch.int64), ptr(residual), int(relu), ptr(y, y.dtype), N, Cc, HW, ptr(gb_map, torch.int32),
+         x.shape[-1] if gb_map is not None else 0, p0.shape[-1] if gb_map is not None else 0, stream())
     return y
 
 
@@ -567,7 +739,9 @@ def norm_bwd(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dp0=
     dx = torch.empty_like(x)
     nb = load().agl_norm_bwd_ws_bytes(N, Cc)
     ws = workspace(nb, x.device)
-    call("agl_norm_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), mode, ptr(p0), ptr(p1),
+    y16 = y is not None and y.dtype == torch.bfloat16
+    call("agl_norm_bwd_y16" if y16 else "agl_norm_bwd", ptr(dy), ptr(x), ptr(y, torch.bfloat16 if y16 else torch.float32), ptr(mean), ptr(rstd),
+         mode, ptr(p0), ptr(p1),
          ptr(labels, torch.int64), int(relu), int(batch_stats), ptr(dx), ptr(dp0), ptr(dp1), N, Cc, HW,
          p0.shape[0] if mode == 2 else 0, int(param_accumulate), ptr(gb_map, torch.int32), ptr(gb_lo, torch.int32),
          x.shape[-1] if gb_map is not None else 0,
@@ -677,9 +851,13 @@ def box2_bwd(dxb, mask=None):
 
 
 def avgpool2_fwd(x, in_relu=False):
+    """x fp32 or (a discriminator block output stored as bf16) bfloat16; the result is fp32."""
     N, Cc, H, W = x.shape
     y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    call("agl_avgpool2_fwd", ptr(x), ptr(y), N * Cc, H, W, int(in_relu), stream())
+    if x.dtype == torch.bfloat16:
+        call("agl_avgpool2_fwd_x16", ptr(x, torch.bfloat16), ptr(y), N * Cc, H, W, int(in_relu), stream())
+    else:
+        call("agl_avgpool2_fwd", ptr(x), ptr(y), N * Cc, H, W, int(in_relu), stream())
     return y
 
 
@@ -689,7 +867,11 @@ def avgpool2_bwd(dy, x_or_shape, in_relu=False, out=None, accumulate=False):
     N, Cc, H, W = shape
     if out is None:
         out = torch.empty(tuple(shape), dtype=torch.float32, device=dy.device)
-    call("agl_avgpool2_bwd", ptr(dy), ptr(x), ptr(out), N * Cc, H, W, int(in_relu), int(accumulate), stream())
+    if x is not None and x.dtype == torch.bfloat16:
+        assert in_relu
+        call("agl_avgpool2_bwd_x16", ptr(dy), ptr(x, torch.bfloat16), ptr(out), N * Cc, H, W, int(accumulate), stream())
+    else:
+        call("agl_avgpool2_bwd", ptr(dy), ptr(x), ptr(out), N * Cc, H, W, int(in_relu), int(accumulate), stream())
     return out
 
 

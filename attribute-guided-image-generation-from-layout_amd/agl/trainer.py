@@ -18,6 +18,7 @@ builder's job (agl.synth); the batch carries attribute / attribute_gt / attribut
 from __future__ import annotations
 
 import math
+import threading
 import time
 import os
 from typing import Dict, Optional, Sequence
@@ -50,6 +51,14 @@ def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
     out = {k: torch.from_numpy(batch_np[k]).to(device) for k in BATCH_KEYS}
     out["obj_to_img"] = torch.from_numpy(batch_np["obj_to_img"])
     return out
+
+
+# One iteration at a time per process.  The schedule of an iteration lives in module-level switches of agl.functional / agl.lib
+# (BatchNorm tape, deferred updates, private gradient arenas, convolution flags, weight-gradient stream map) that its forward passes
+# set and its backward passes — run by autograd's device thread — read; they are set and restored inside step(), so trainers that
+# alternate on one thread never see each other's state, and this lock makes two trainers driven from two host threads take turns
+# instead of interleaving (the design is one process per GPU with one host thread issuing).
+_STEP_LOCK = threading.RLock()
 
 
 class Trainer:
@@ -258,12 +267,16 @@ class Trainer:
     # ------------------------------------------------------------------ the step
     def step(self, b: Dict[str, torch.Tensor], eps_d: Optional[Sequence[torch.Tensor]] = None,
              eps_g: Optional[Sequence[torch.Tensor]] = None):
-        self._in_step = True
-        try:
-            with L.conv_flags(self.conv_flags):
-                return self._step(b, eps_d, eps_g)
-        finally:
-            self._in_step = False
+        with _STEP_LOCK:
+            self._in_step = True
+            saved = (F.BN_TAPE, F.BN_DEFER, F.GRAD_ARENA, F.EMIT_STATS, L.WGRAD_STREAMS)
+            try:
+                with L.conv_flags(self.conv_flags):
+                    return self._step(b, eps_d, eps_g)
+            finally:
+                F.BN_TAPE, F.BN_DEFER, F.GRAD_ARENA, F.EMIT_STATS, L.WGRAD_STREAMS = saved
+                F._LAST_STATS = None
+                self._in_step = False
 
     def _step(self, b, eps_d, eps_g):
         lam = self.lam

@@ -1575,7 +1575,8 @@ long agl_conv2d_fwd_ws_bytes(int N, int Cin, int H, int W, int Cout, int ks, int
 static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
                            void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
                            int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
-                           int* stat_rows, const InFold* fold = nullptr, const float* addend = nullptr);
+                           int* stat_rows, const InFold* fold = nullptr, const float* addend = nullptr, const float* sc_x = nullptr,
+                           const float* sc_w = nullptr, const float* sc_b = nullptr, int sc_cin = 0);
 
 int agl_conv2d_fwd(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws,
                    long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu,
@@ -1610,10 +1611,31 @@ int agl_conv2d_fwd_fold(const float* x, const float* in_mean, const float* in_sc
                          stream, stats, stats_floats, stat_rows, &f, nullptr);
 }
 int agl_conv2d_fwd_fold_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
+  if (!(ks == 4 && stride == 2)) return 0;      // (the transform is compiled into the 4x4 / stride-2 instantiations of the patch kernel)
   return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
 }
 // y = conv(x) + addend (+ bias, output ReLU), written out of place — as bf16 with AGL_CONV_Y_BF16: the sum is formed in fp32 and rounded
 // once.  The shortcut of a discriminator block (discriminator.py:58-60, :97-99) whose sum only convolutions read afterwards.
+// y = conv(x) + bias + [1x1 shortcut of a few-channel tensor: sc_b[m] + sum_c sc_w[m][c] * sc_x[n][c][pixel]] (+ output ReLU), the shortcut
+// evaluated in the convolution's epilogue — the first discriminator block, out = c2(h) + sc(x) (discriminator.py:36-44, :58-60), in ONE
+// launch that reads 3 input channels instead of adding a second 64-channel tensor.  x may be bf16 (AGL_CONV_X_BF16), y bf16
+// (AGL_CONV_Y_BF16).  bf16 3x3 stride-1 "same" forms of the patch kernel with <= 64 output channels (agl_conv2d_fwd_shortcut_ok).
+int agl_conv2d_fwd_shortcut(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* sc_x,
+                            const float* sc_w, const float* sc_bias, int sc_cin, float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W,
+                            int Cout, int ks, int pad, int in_relu, int relu, int flags, void* stream) {
+  AGL_REQUIRE(sc_x && sc_w && sc_cin >= 1 && sc_cin <= 4, "agl_conv2d_fwd_shortcut: bad shortcut operands");
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, 1, pad, 0, in_relu, relu, 0, flags, stream,
+                         nullptr, 0, nullptr, nullptr, nullptr, sc_x, sc_w, sc_bias, sc_cin);
+}
+int agl_conv2d_fwd_shortcut_ok(int N, int Cin, int H, int W, int Cout, int ks, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || ks != 3 || pad != 1 || Cout > 64 || W % 4 != 0) return 0;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = H; a.OW = W; a.ks = 3; a.stride = 1; a.pad = 1; a.nsplit = 1;
+  a.any_grid = co.any_grid;
+  if (pconv_plan_splits(a) != 1) return 0;
+  return (H == 4 && W == 4) ? 0 : 1;      // (not the 4 x 4-map tile form)
+}
 int agl_conv2d_fwd_addend(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* addend,
                           float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int in_relu,
                           int relu, int flags, void* stream) {
@@ -1625,7 +1647,8 @@ int agl_conv2d_fwd_addend(const float* x, const float* w, const void* packed_w, 
 static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y,
                            void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2,
                            int in_relu, int relu, int accumulate, int flags, void* stream, float* stats, long stats_floats,
-                           int* stat_rows, const InFold* fold, const float* addend) {
+                           int* stat_rows, const InFold* fold, const float* addend, const float* sc_x, const float* sc_w, const float* sc_b,
+                           int sc_cin) {
   AGL_REQUIRE(x && (w || packed_w) && y, "agl_conv2d_fwd: null pointer");
   g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
@@ -1637,8 +1660,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30) && (long)Cout * Cin * ks * ks < (1L << 30),
               "agl_conv2d_fwd: tensor too large (operands are addressed with 32-bit byte offsets: < 2^30 elements)");
   hipStream_t st = (hipStream_t)stream;
-  if (fold || addend) {      // folded input transform / out-of-place addend: forms of the matrix-core patch kernel only (the caller asked *_ok)
-    AGL_REQUIRE((co.prec == 1 || co.split3) && co.patch && !accumulate && !co.x_bf16, "agl_conv2d_fwd_fold: needs the matrix-core patch kernel");
+  if (fold || addend || sc_x) {      // folded input transform / out-of-place addend / epilogue shortcut: forms of the matrix-core patch kernel only
+    AGL_REQUIRE((co.prec == 1 || co.split3) && co.patch && !accumulate && (!co.x_bf16 || !fold), "agl_conv2d_fwd_fold: needs the matrix-core patch kernel");
     AGL_REQUIRE(!co.y_bf16 || co.prec == 1, "agl_conv2d_fwd: AGL_CONV_Y_BF16 needs AGL_CONV_BF16");
     PConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.pos_mask = nullptr; a.y = y; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -1648,7 +1671,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     if (fold) a.fold = *fold;
-    a.addend = addend; a.y_bf16 = co.y_bf16;
+    a.addend = addend; a.y_bf16 = co.y_bf16; a.x_bf16 = co.x_bf16;
+    a.sc_x = sc_x; a.sc_w = sc_w; a.sc_b = sc_b; a.sc_cin = sc_cin;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, folded input transform / addend)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd_fold: a shape the patch kernel does not take in this form (ask agl_conv2d_fwd_fold_ok)");
     g_last_pipe = a.nsplit;
@@ -1821,6 +1845,19 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
       prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases, bf16 dy)");
     }
     AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_data: AGL_CONV_X_BF16 on a shape the matrix-core kernels do not take");
+    g_last_pipe = 1;
+    return prc;
+  }
+  if (co.mask_bf16 && stride == 2) {      // 4x4 / stride-2 / pad-1: the paired-phase kernel reads the bf16 mask
+    AGL_REQUIRE(ks == 4 && co.patch && co.prec == 1 && pos_mask && Cin > 4 && !bias && !(relu && accumulate),
+                "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 with stride 2 needs the 4x4 phase kernel in bf16 arithmetic");
+    PConvArgs a{};
+    a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
+    a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
+    a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = 1;
+    const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases, bf16 mask)");
+    AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 on a shape the phase kernel does not take in that form (ask agl_conv2d_bwd_data_takes_bf16_mask)");
     g_last_pipe = 1;
     return prc;
   }
@@ -2004,6 +2041,12 @@ static long bww_ws_core(int N, int Cin, int Cout, int ks, int OH, int OW);
 // launch that can read pos_mask as bf16 (AGL_CONV_MASK_BF16).
 int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
+  if (co.prec == 1 && co.patch && stride == 2 && ks == 4 && pad == 1 && Cin > 4 && IH == 2 * OH && IW == 2 * OW && OW >= 4) {
+    PConvArgs t{};      // the paired-phase kernel without a reduction split (pconvT_try's conditions for mask_bf16)
+    t.N = N; t.Cin = Cout; t.H = OH; t.W = OW; t.Cout = Cin; t.OH = IH; t.OW = IW; t.ks = 4; t.stride = 2; t.pad = 1; t.nsplit = 1;
+    t.any_grid = co.any_grid;
+    return pconvT_takes_bf16_mask(t) ? 1 : 0;
+  }
   if (co.prec != 1 || !co.patch || stride != 1 || IH != OH || IW != OW || Cin <= 4) return 0;
   PConvArgs a{};
   a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin; a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad;
@@ -2016,6 +2059,10 @@ int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout
 int agl_conv2d_bwd_weight_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
   if (co.prec != 1 || !co.patch) return 0;
+  if (bww_swapped(Cin, Cout, stride, 0, 0)) {      // few output channels: the few-channel kernel through the role swap (8-byte pieces of 4 bf16)
+    const FewBwwShape f{N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0};
+    return ((ks & 1) && few_bww_ws_bytes(f) > 0 && W % 4 == 0) ? 1 : 0;
+  }
   PBwwArgs a{};
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.nsplit = 1; a.x_bf16 = 1;
   return pbww_ws_bytes(a) > 0 ? 1 : 0;
@@ -2097,7 +2144,7 @@ int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_
 }
 int agl_conv2d_bwd_weight_fold_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
-  if (!co.patch || !(co.prec == 1 || co.split3) || Cin <= 4) return 0;
+  if (!co.patch || !(co.prec == 1 || co.split3) || Cin <= 4 || !(ks == 4 && stride == 2)) return 0;
   PBwwArgs a{};
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad;
   a.nsplit = co.prec == 1 ? 1 : 3;
@@ -2106,7 +2153,7 @@ int agl_conv2d_bwd_weight_fold_ok(int N, int Cin, int H, int W, int Cout, int OH
 // 1 when agl_conv2d_bwd_weight with AGL_CONV_BF16 | AGL_CONV_DY_BF16 runs these extents on the matrix-core kernel (8-pixel pieces of dy)
 int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
-  if (co.prec != 1 || !co.patch || Cin <= 4) return 0;
+  if (co.prec != 1 || !co.patch || Cin <= 4 || !(ks == 4 && stride == 2)) return 0;
   if (OW % 8 != 0 && !(OW == 4 && OH == 4)) return 0;
   PBwwArgs a{};
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.nsplit = 1;
@@ -2124,6 +2171,30 @@ static int conv2d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
   AGL_REQUIRE(ks_ok(ks) && (stride == 1 || stride == 2), "agl_conv2d_bwd_weight: unsupported ks=%d stride=%d", ks, stride);
   AGL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, "agl_conv2d_bwd_weight: empty extent");
   AGL_REQUIRE((long)N * Cin * H * W < (1L << 30) && (long)N * Cout * OH * OW < (1L << 30), "agl_conv2d_bwd_weight: tensor too large (< 2^30 elements per operand)");
+  if (co.x_bf16 && !co.dy_bf16 && !fold && co.prec == 1 && co.patch && bww_swapped(Cin, Cout, stride, up_log2, in_relu)) {      // (a bias gradient is left to the caller: *dbias_done stays 0)
+    // few OUTPUT channels (decoder c4 / c7) with a bf16-stored input: the role swap below hands the tensor to the few-channel
+    // kernel in the dy role (AGL_CONV_DY_BF16 of the inner call)
+    const long inner = bww_ws_core(N, Cout, Cin, ks, H, W);
+    const long tmp_bytes = (long)Cin * Cout * ks * ks * 4;
+    AGL_REQUIRE(ws && ws_bytes >= inner + tmp_bytes, "agl_conv2d_bwd_weight: workspace too small (%ld < %ld)", ws_bytes, inner + tmp_bytes);
+    float* tmp = (float*)((char*)ws + inner);
+    const int iflags = (flags & ~(1 << 17)) | (1 << 20);
+    int rc = agl_conv2d_bwd_weight(x, dy, tmp, nullptr, 0, nullptr, ws, inner, N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0, 0, iflags, stream);
+    if (rc != AGL_OK) return rc;
+    const long n = (long)Cout * Cin * ks * ks;
+    hipLaunchKernelGGL(flip_transpose_w, dim3(agl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dw, Cout, Cin, ks,
+                       accumulate);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight(flip, bf16 input)");
+    return AGL_OK;
+  }
+  if (co.dy_bf16 && !co.x_bf16 && !fold && Cin <= 4) {      // (the inner call of the swap above) few-input-channel kernel, dy as bf16
+    const FewBwwShape f{N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up_log2, in_relu};
+    int fsplits = 0;
+    const int frc = few_bww_try(f, dy, x, ws, ws_bytes, &fsplits, (hipStream_t)stream, "agl_conv2d_bwd_weight(few input channels, bf16 dy)", 1);
+    AGL_REQUIRE(frc == AGL_OK, "agl_conv2d_bwd_weight: AGL_CONV_DY_BF16 with <= 4 input channels on a shape the few-channel kernel does not take");
+    const long n = (long)Cout * Cin * ks * ks;
+    return agl_launch_slab_reduce((const float*)ws, dw, n, fsplits, accumulate, (hipStream_t)stream, "agl_conv2d_bwd_weight(few input channels: reduce)");
+  }
   if (co.x_bf16 || co.dy_bf16 || fold) {
     AGL_REQUIRE(co.patch && (co.prec == 1 || (co.split3 && !co.x_bf16 && !co.dy_bf16)),
                 "agl_conv2d_bwd_weight: bf16-stored operands need AGL_CONV_BF16, a folded input transform the matrix-core kernel");
@@ -2232,10 +2303,20 @@ int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks,
             ((long)Cout * Cin * ks * ks + Cout) * 4 <= 48 * 1024) ? 1 : 0;
   }
   (void)relu;
+  if (stride != 1 || !(ks == 1 || ks == 3)) return 0;      // (the bf16 store is compiled into the 3x3 stride-1 and 1x1 instantiations)
   PConvArgs a{};
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2;
   a.nsplit = 1; a.any_grid = co.any_grid;
   return pconv_plan_splits(a) == 1 && OW % 4 == 0 ? 1 : 0;
+}
+// 1 when agl_conv2d_fwd with AGL_CONV_BF16 | AGL_CONV_X_BF16 takes these extents: the patch kernel, or (<= 4 output channels, 7x7
+// "same") the vertical + diagonal form
+int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch) return 0;
+  if (Cout <= 4)
+    return (stride == 1 && 2 * pad == ks - 1 && pconv_vert_ws_bytes(N, Cin, H, W, Cout, ks, 1) > 0) ? 1 : 0;
+  return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
 }
 // 1 when agl_conv2d_bwd_data with AGL_CONV_BF16 | AGL_CONV_X_BF16 (dy stored as bf16) runs these extents on a matrix-core kernel
 int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {

@@ -23,6 +23,7 @@ struct FewBwwArgs {
   const float* dy; const float* x; float* slabs;
   int N, Cin, H, W, Cout, OH, OW, pad, in_relu;
   int tiles, tiles_per_split, ncols;
+  int dy_bf16;      // dy holds bf16 elements (the bf16-stored input of a few-output-channel layer, in this role through the swap of conv.hip)
 };
 
 // Tile = 128 output pixels = TH full rows of one image (OW in {32, 64, 128}, TH = 128 / OW).  The dy tile is staged as
@@ -84,7 +85,14 @@ __global__ __launch_bounds__(NT_, 2) void few_bww_k(FewBwwArgs p) {
       const int e = tid + NT_ * r, co = e >> 5, pc = e & 31;
       const bool ok = co0 + co < p.Cout;
       const long idx = ok ? ((long)img * p.Cout + co0 + co) * OHW + (long)ty0 * OW + 4 * pc : 0;
-      const float4 v = *reinterpret_cast<const float4*>(p.dy + idx);
+      float4 v;
+      if (p.dy_bf16) {      // four bf16 in one 8-byte load, widened (a shift)
+        const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.dy) + idx);
+        v = float4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                   __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+      } else {
+        v = *reinterpret_cast<const float4*>(p.dy + idx);
+      }
       pd[r] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -324,14 +332,14 @@ long few_bww_ws_bytes(const FewBwwShape& a) {
 }
 
 int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws, long ws_bytes, int* splits_out, hipStream_t st,
-                const char* name) {
+                const char* name, int dy_bf16) {
   int ntl, splits, tps, tiles;
   if (few_bww_plan(a, &ntl, &splits, &tps, &tiles) != 0) return -1;
   const long need = (long)splits * a.Cout * a.Cin * a.ks * a.ks * 4;
   if (!ws || ws_bytes < need) return -1;
   FewBwwArgs p;
   p.dy = dy; p.x = x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
-  p.pad = a.pad; p.in_relu = a.in_relu; p.tiles = tiles; p.tiles_per_split = tps; p.ncols = a.Cin * a.ks * a.ks;
+  p.pad = a.pad; p.in_relu = a.in_relu; p.tiles = tiles; p.tiles_per_split = tps; p.ncols = a.Cin * a.ks * a.ks; p.dy_bf16 = dy_bf16;
   dim3 g((unsigned)splits, agl_cdiv(a.Cout, 64));
 #define FEW_LAUNCH(KS_, NT2_) hipLaunchKernelGGL((few_bww_k<KS_, NT2_>), g, dim3(NT_), 0, st, p)
   if (a.ks == 1) FEW_LAUNCH(1, 1);

@@ -215,11 +215,23 @@ struct NormArgs {
   // backward of a FOLDED forward (agl_norm_fold_table + agl_conv2d_fwd_fold: the normalised tensor y was never stored): the ReLU mask
   // is recomputed from x with the very expression the consumer's staging pass evaluated, fmaf(x - mean, fscale[r], fshift[r]) > 0
   const float* fscale; const float* fshift; int f_per_n;
+  int y_bf16;      // the forward output y holds bf16 elements (written by agl_norm_apply_fwd_y16 for consumers that are bf16-mode convolutions)
 };
 
 // ReLU mask of element `idx` of row (n, c): from the stored output y, or recomputed from x (folded forward; fs / fh = the row's table entries)
-__device__ __forceinline__ bool relu_dead(const float* __restrict__ y, long idx, float x, float mu, float fs, float fh) {
-  return y ? !(y[idx] > 0.f) : !(fmaf(x - mu, fs, fh) > 0.f);
+__device__ __forceinline__ float bf16_at(const float* y, long idx) {      // element idx of a bf16 tensor, widened (a shift)
+  return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(y)[idx] << 16);
+}
+__device__ __forceinline__ bool relu_dead(const NormArgs& a, const float* __restrict__ y, long idx, float x, float mu, float fs, float fh) {
+  if (!y) return !(fmaf(x - mu, fs, fh) > 0.f);
+  return a.y_bf16 ? !(bf16_at(y, idx) > 0.f) : !(y[idx] > 0.f);
+}
+// four consecutive elements of y starting at element 4*i of the row at `base` (fp32 or bf16 storage)
+__device__ __forceinline__ float4 y_quad(const NormArgs& a, const float* y, long base, int i) {
+  if (!a.y_bf16) return reinterpret_cast<const float4*>(y + base)[i];
+  const uint2 b = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + base)[i];
+  return float4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
 }
 __device__ __forceinline__ void fold_row(const NormArgs& a, int n, int c, float& fs, float& fh) {
   fs = 0.f; fh = 0.f;
@@ -258,7 +270,8 @@ __global__ __launch_bounds__(256) void norm_apply_fwd(NormArgs a, const float* _
     float v = a.mode == 3 ? xh * (1.f + gam[gi]) + bet[gi] : xh * g + b;
     if (residual) v += residual[base + i];
     if (a.relu) v = fmaxf(v, 0.f);
-    y[base + i] = v;
+    if (a.y_bf16) reinterpret_cast<__bf16*>(y)[base + i] = (__bf16)v;
+    else y[base + i] = v;
   }
 }
 
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256) void norm_apply_fwd4(NormArgs a, const float* 
   const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
   const float4* r4 = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
   float4* y4 = reinterpret_cast<float4*>(y + base);
+  uint2* y2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + base);      // (bf16 storage: four elements per 8-byte store)
   for (int i = threadIdx.x % LPR; i < a.HW / 4; i += LPR) {
     const float4 xv = x4[i];
     float v[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
@@ -304,7 +318,13 @@ __global__ __launch_bounds__(256) void norm_apply_fwd4(NormArgs a, const float* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
     }
-    y4[i] = float4{v[0], v[1], v[2], v[3]};
+    if (a.y_bf16) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const bf16x4 ob = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      y2[i] = __builtin_bit_cast(uint2, ob);
+    } else {
+      y4[i] = float4{v[0], v[1], v[2], v[3]};
+    }
   }
 }
 
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
     for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
       float g = dy[base + i];
       const float xv = a.x[base + i];
-      if (a.relu && relu_dead(y, base + i, xv, mu, fs, fh)) g = 0.f;
+      if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh)) g = 0.f;
       float xh = (xv - mu) * rs;
       if (a.mode == 3) {
         dgam[i] = g * xh;         // (full resolution either way: a gathered gamma|beta is reduced to its grid by agl_grid_gather_bwd)
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* _
   float4* dbet = a.mode == 3 ? reinterpret_cast<float4*>(dgb + ((long)n * 2 * a.C + a.C + c) * a.HW) : nullptr;
   const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
   const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
-  const float4* y4 = (a.relu && y) ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  const bool have_y = a.relu && y != nullptr;
   float s1 = 0.f, s2 = 0.f;
   float fs, fh;
   fold_row(a, n, c, fs, fh);
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* _
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = y4 ? y4[i] : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -423,7 +443,7 @@ __global__ __launch_bounds__(128) void norm_bwd_rows_gathered(NormArgs a, const 
   for (int iy = 0; iy < W; ++iy) {
     const long i = base + (long)iy * W + tid;
     float g = dy[i];
-    if (a.relu && !(y[i] > 0.f)) g = 0.f;
+    if (a.relu && !((a.y_bf16 ? bf16_at(y, i) : y[i]) > 0.f)) g = 0.f;
     const float xh = (a.x[i] - mu) * rs;
     ra[tid] = g * xh; rb[tid] = g;
     __syncthreads();
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float g = dy[base + i];
     const float xv = a.x[base + i];
-    if (a.relu && relu_dead(y, base + i, xv, mu, fs, fh)) g = 0.f;
+    if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh)) g = 0.f;
     float xh = (xv - mu) * rs;
     float gg = a.mode == 3 ? g * (1.f + gam[gb_index(a, i)]) : g * ge;
     dx[base + i] = rs * (gg - m1 - xh * m2);
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
   const float* gam = a.mode == 3 ? a.p0 + ((long)n * 2 * a.C + c) * gb_plane(a) : nullptr;
   const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
   const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
-  const float4* y4 = (a.relu && y) ? reinterpret_cast<const float4*>(y + base) : nullptr;
+  const bool have_y = a.relu && y != nullptr;
   float4* dx4 = reinterpret_cast<float4*>(dx + base);
   float fs, fh;
   fold_row(a, n, c, fs, fh);
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = y4 ? y4[i] : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -743,7 +763,7 @@ static int fill_args(NormArgs& a, const float* x, const float* mean, const float
   a.x = x; a.mean = mean; a.rstd = rstd; a.p0 = p0; a.p1 = p1; a.labels = labels;
   a.mode = mode; a.relu = relu; a.N = N; a.C = C; a.HW = HW;
   a.map = nullptr; a.W = 0; a.src_w = 0;
-  a.fscale = nullptr; a.fshift = nullptr; a.f_per_n = 0;
+  a.fscale = nullptr; a.fshift = nullptr; a.f_per_n = 0; a.y_bf16 = 0;
   return AGL_OK;
 }
 // gathered gamma|beta of mode 3 (gb_map: W device ints, the row AND column map of a square W x W map onto a src_w x src_w grid)
@@ -754,15 +774,31 @@ static int fill_gather(NormArgs& a, const int* gb_map, int W, int src_w, const c
   return AGL_OK;
 }
 
+static int norm_apply_impl(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                           const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
+                           const int* gb_map, int W, int src_w, void* stream, int y_bf16);
 int agl_norm_apply_fwd(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
                        const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
                        const int* gb_map, int W, int src_w, void* stream) {
+  return norm_apply_impl(x, mean, rstd, mode, p0, p1, labels, residual, relu, y, N, C, HW, gb_map, W, src_w, stream, 0);
+}
+// The same with y stored as bf16 (round to nearest even): for an output whose only readers are bf16-mode convolutions — they would
+// round the fp32 tensor to these very values when staging it — and the ReLU mask of agl_norm_bwd_y16.
+int agl_norm_apply_fwd_y16(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                           const long long* labels, const float* residual, int relu, void* y_bf16, int N, int C, int HW,
+                           const int* gb_map, int W, int src_w, void* stream) {
+  return norm_apply_impl(x, mean, rstd, mode, p0, p1, labels, residual, relu, (float*)y_bf16, N, C, HW, gb_map, W, src_w, stream, 1);
+}
+static int norm_apply_impl(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                           const long long* labels, const float* residual, int relu, float* y, int N, int C, int HW,
+                           const int* gb_map, int W, int src_w, void* stream, int y_bf16) {
   NormArgs a;
   int rc = fill_args(a, x, mean, rstd, mode, p0, p1, labels, relu, N, C, HW, "agl_norm_apply_fwd");
   if (rc) return rc;
   rc = fill_gather(a, gb_map, W, src_w, "agl_norm_apply_fwd");
   if (rc) return rc;
   AGL_REQUIRE(y, "agl_norm_apply_fwd: null output");
+  a.y_bf16 = y_bf16;
   hipStream_t st = (hipStream_t)stream;
   const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)(mode == 3 && !gb_map ? p0 : nullptr)) & 15) == 0;
   if (HW >= 64 && HW % 4 == 0 && al16 && (!gb_map || W % 4 == 0)) {
@@ -796,6 +832,16 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
   AGL_REQUIRE(!relu || y, "agl_norm_bwd: relu needs the forward output y (or agl_norm_bwd_fold)");
   return norm_bwd_impl(dy, x, y, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dx, dp0, dp1, N, C, HW, n_classes, param_accumulate,
                        gb_map, gb_lo, W, src_w, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// agl_norm_bwd for a forward output stored as bf16 (agl_norm_apply_fwd_y16): y is read for the ReLU mask only
+int agl_norm_bwd_y16(const float* dy, const float* x, const void* y_bf16, const float* mean, const float* rstd, int mode,
+                     const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                     float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                     int W, int src_w, void* ws, long ws_bytes, void* stream) {
+  AGL_REQUIRE(!relu || y_bf16, "agl_norm_bwd_y16: relu needs the forward output");
+  return norm_bwd_impl(dy, x, (const float*)y_bf16, mean, rstd, mode, p0, p1, labels, relu, batch_stats, dx, dp0, dp1, N, C, HW, n_classes,
+                       param_accumulate, gb_map, gb_lo, W, src_w, ws, ws_bytes, stream, nullptr, nullptr, -1);
 }
 
 // Backward of a FOLDED normalise-modulate(+ReLU) (agl_norm_fold_table + agl_conv2d_fwd_fold): dy is the gradient with respect to the
@@ -832,7 +878,8 @@ static int norm_bwd_impl(const float* dy, const float* x, const float* y, const 
   if (rc) return rc;
   rc = fill_gather(a, gb_map, W, src_w, "agl_norm_bwd");
   if (rc) return rc;
-  a.fscale = fscale; a.fshift = fshift; a.f_per_n = f_per_n;
+  a.fscale = fscale; a.fshift = fshift; a.f_per_n = f_per_n < 0 ? 0 : f_per_n;
+  a.y_bf16 = f_per_n < 0;      // (f_per_n = -1: the y16 entry point)
   AGL_REQUIRE(dy && dx && (!relu || y || fscale), "agl_norm_bwd: null pointer");
   AGL_REQUIRE(mode != 3 || dp0, "agl_norm_bwd: SPADE mode needs dgb output");
   if (!ws || ws_bytes < agl_norm_bwd_ws_bytes(N, C)) {

@@ -27,6 +27,8 @@ struct PConvArgs {
   InFold fold;                      // optional (scale != NULL): transform of x while it is staged (stride-1 / stride-2 forward forms)
   int y_bf16;                       // y points to bf16 elements (AGL_CONV_Y_BF16; launches without a reduction split only)
   const float* addend;              // optional fp32 tensor shaped like y, added before the output ReLU (no reduction split)
+  const float* sc_x; const float* sc_w; const float* sc_b; int sc_cin;   // optional few-channel 1x1 shortcut added in the epilogue:
+                                    // y += sc_b[m] + sum_c sc_w[m*sc_cin + c] * sc_x[n][c][pixel] (bf16 3x3 stride-1 forms, <= 64-channel tiles)
 };
 // Packed form of a weight tensor for pconv_try (forward: flip 0, w_sm = Cin*ks*ks, w_sc = ks*ks; "same" input gradient: flip 1, roles
 // swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
@@ -50,6 +52,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 // 4x4 / stride-2 / pad-1 input gradient on the same kernel (four 2x2-tap phases): a.x = dy (a.Cin reduction channels, a.H x a.W),
 // a.y = dx (a.Cout channels, a.OH = 2H, a.OW = 2W), a.w_sm / a.w_sc = element strides of w for (dx channel, dy channel).
 bool pconvT_eligible(const PConvArgs& a);
+bool pconvT_takes_bf16_mask(const PConvArgs& a);
 long pconvT_ws_bytes(int Cred, int Crow, int nsplit);
 long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel);
 int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);

@@ -51,6 +51,9 @@ struct PArgs {
   InFold fold;       // optional input transform of the staged patch (pconv.h): the normalise-modulate of the BatchNorm that reads x
   int y_bf16;        // y points to bf16 elements (plain epilogue only: no phases, no reduction split)
   const float* addend;   // optional fp32 tensor shaped like y, added to the result before the output ReLU (out-of-place accumulate)
+  // optional few-channel 1x1 shortcut evaluated in the epilogue (FEAT 16): y += sc_b[m] + sum_c sc_w[m * sc_cin + c] * sc_x[img][c][pixel],
+  // sc_x an (N, sc_cin <= 4, OH, OW) fp32 tensor — the learnable shortcut of the discriminators' first block (discriminator.py:43-44, :58-60)
+  const float* sc_x; const float* sc_w; const float* sc_b; int sc_cin;
 };
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
@@ -137,9 +140,19 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // are copies), 4 no LDS fragment reads inside the tap loop (tap 0's fragments for every tap), 8 no global loads after the first
 // stage, 16 no LDS stores after the first stage
 // VERT: a KS x 1 window (vertical taps only, no horizontal padding): the first half of the few-channel 7x7 layers (pconv_vert_try)
+// FEAT (bit mask): features compiled into an instantiation — every one costs registers in ALL its launches (82 of 224 kernels lost a
+// workgroup per CU when they were runtime switches), so only the shapes that use them are instantiated with them:
+//   1  input transform of the staged patch (PArgs::fold): the 4x4 / stride-2 family (crop / layout / global encoder)
+//   2  BatchNorm partial rows of the output (PArgs::stats): the same family, and the 5x5 bf16 forms (decoder c6)
+//   4  bf16 output store / out-of-place addend (PArgs::y_bf16, addend)
+//   8  bf16 pos_mask in the paired-phase (stride-2 input gradient) epilogue
+//  16  few-channel 1x1 shortcut added in the plain epilogue (PArgs::sc_x; the discriminators' first block)
 template <int KS, int S, int TW, int TH, int TI, int BM, int NSPL, int TG, bool PHS = false, bool DB = false, int NTH = 256, int ABL = 0,
-          bool VERT = false>
+          bool VERT = false, int FEAT = 0>
 __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
+  constexpr bool F_FOLD = (FEAT & 1) != 0, F_STATS = (FEAT & 2) != 0, F_YOUT = (FEAT & 4) != 0;
+  constexpr bool F_SC = (FEAT & 16) != 0;          // 16: few-channel 1x1 shortcut added in the plain epilogue (PArgs::sc_x)
+  constexpr bool F_PMASK16 = (FEAT & 8) != 0;      // 8: bf16 pos_mask in the paired-phase epilogue (the bf16-stored h of a discriminator block)
   constexpr int KSW = VERT ? 1 : KS;           // window columns
   static_assert(!VERT || (S == 1 && !PHS && TG == KS), "vertical window");
   constexpr int NT = NTH;                      // (shadows the file-level 256)
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   const unsigned esz = p.x_bf16 ? 2u : 4u;      // bytes per stored input element
   unsigned bsrc[BR];   // patch item e = (half h, image ti, row yy, column xx): byte offset of channel 8h, or OOB31
   int bdst[BR];        // LDS piece index h*NQ + q, or -1
-  int faff[BR];
+  int faff[F_FOLD ? BR : 1];
 #pragma unroll
   for (int r = 0; r < BR; ++r) {
     const int e = tid + NT * r;
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
     bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
     bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
-    faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // (fold) row offset of this item's 8 channels in the scale / shift tables
+    if constexpr (F_FOLD) faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // row offset of this item's 8 channels in the scale / shift tables
   }
   const unsigned cstride = (unsigned)(p.H * p.W) * esz;
   unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   int c_staged = 0;    // first channel of the chunk in pb
   auto gload_b = [&](int c0) {
     if ((ABL & 8) && c0 != 16 * (p.slabs ? zsplit * p.cps : 0)) return;
-    c_staged = c0;
+    if constexpr (F_FOLD) c_staged = c0;
     if (p.x_bf16) {      // (a bf16 value is the upper half of its fp32 form: the conversion at the LDS store is then exact)
 #pragma unroll
       for (int r = 0; r < BR; ++r)
@@ -273,15 +286,17 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       if (bdst[r] < 0) continue;
-      if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
-        const float4* const mp = reinterpret_cast<const float4*>(p.fold.mean + c_staged + (faff[r] & 8));
-        const float4* const sp = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r]);
-        const float4* const hp = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r]);
-        const float4 m0 = mp[0], m1 = mp[1], s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
-        pb[r][0] = fmaf(pb[r][0] - m0.x, s0.x, h0.x); pb[r][1] = fmaf(pb[r][1] - m0.y, s0.y, h0.y);
-        pb[r][2] = fmaf(pb[r][2] - m0.z, s0.z, h0.z); pb[r][3] = fmaf(pb[r][3] - m0.w, s0.w, h0.w);
-        pb[r][4] = fmaf(pb[r][4] - m1.x, s1.x, h1.x); pb[r][5] = fmaf(pb[r][5] - m1.y, s1.y, h1.y);
-        pb[r][6] = fmaf(pb[r][6] - m1.z, s1.z, h1.z); pb[r][7] = fmaf(pb[r][7] - m1.w, s1.w, h1.w);
+      if constexpr (F_FOLD) {
+        if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {              // (four channels at a time: twelve table values live, not twenty-four)
+            const float4 m = reinterpret_cast<const float4*>(p.fold.mean + c_staged + (faff[r] & 8))[q];
+            const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
+            const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
+            pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0] - m.x, sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1] - m.y, sc.y, sh.y);
+            pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2] - m.z, sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3] - m.w, sc.w, sh.w);
+          }
+        }
       }
       bf16x8 t0, t1, t2;
 #pragma unroll
@@ -428,17 +443,26 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // BatchNorm statistics of the output (p.stats): every lane accumulates the values it stores, per channel row, as deviations from
   // the FIRST value it sees for that row (sref): sum d, sum d^2 — a channel whose mean is large against its spread (mean / std = 100)
   // then loses nothing to cancellation, unlike raw sum / sum-of-squares partials in fp32
-  float ssum[WTM][4], ssq[WTM][4], sref[WTM][4], scnt[WTM][4];
+  constexpr int SW = F_STATS ? WTM : 1;
+  float ssum[SW][4], ssq[SW][4], sref[SW][4];
+  float scnt = 0.f;                 // values this lane has accumulated per channel row (the same for all its rows: validity depends on the image only)
 #pragma unroll
-  for (int i = 0; i < WTM; ++i)
+  for (int i = 0; i < SW; ++i)
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; sref[i][ps] = 0.f; scnt[i][ps] = 0.f; }
+    for (int ps = 0; ps < 4; ++ps) { ssum[i][ps] = 0.f; ssq[i][ps] = 0.f; sref[i][ps] = 0.f; }
 #pragma unroll
   for (int jt = 0; jt < WTN; ++jt) {
     const int j = wn * (BN / WNW) + 32 * jt + ec;
     const int ti = j / (TH * TW), r = j - ti * (TH * TW), py = r / TW, px = r - py * TW;
     const int img = img0 + ti;
     const long pbase = (long)img * p.Cout * OHW + (long)(ty0 + py) * p.OW + tx0 + px;
+    float4 scx[F_SC ? 4 : 1];      // the shortcut's input at this lane's four pixels, per input channel
+    if constexpr (F_SC) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        scx[c] = (p.sc_x && c < p.sc_cin && img < p.N) ? *reinterpret_cast<const float4*>(p.sc_x + ((long)img * p.sc_cin + c) * OHW + (long)(ty0 + py) * p.OW + tx0 + px)
+                                                       : float4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
 #pragma unroll
@@ -480,8 +504,17 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
               continue;
             }
             if (p.pos_mask) {
-              const f4u m0 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2);
-              const f4u m1 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2 + 4);
+              f4u m0, m1;
+              if (F_PMASK16 && p.mask_bf16) {      // eight bf16 in one 16-byte load (widened by a shift: sign and zero are the stored value's)
+                const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.pos_mask) + ob + (long)m * OHW2);
+                m0 = f4u{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                         __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+                m1 = f4u{__builtin_bit_cast(float, b.z << 16), __builtin_bit_cast(float, b.z & 0xffff0000u),
+                         __builtin_bit_cast(float, b.w << 16), __builtin_bit_cast(float, b.w & 0xffff0000u)};
+              } else {
+                m0 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2);
+                m1 = *reinterpret_cast<const f4u*>(p.pos_mask + ob + (long)m * OHW2 + 4);
+              }
               if (!(m0.x > 0.f)) lo.x = 0.f;
               if (!(m0.y > 0.f)) lo.y = 0.f;
               if (!(m0.z > 0.f)) lo.z = 0.f;
@@ -546,9 +579,9 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         continue;
       }
       float4 old[4], msk[4];
-      const bool add_old = p.accumulate || p.addend != nullptr;
+      const bool add_old = p.accumulate || (F_YOUT && p.addend != nullptr);
       if (add_old) {
-        const float* const src = p.addend ? p.addend : p.y;
+        const float* const src = (F_YOUT && p.addend) ? p.addend : p.y;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
@@ -585,34 +618,52 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             if (!(msk[ps].w > 0.f)) o.w = 0.f;
           }
           if (add_old) { o.x += old[ps].x; o.y += old[ps].y; o.z += old[ps].z; o.w += old[ps].w; }
+          if constexpr (F_SC) {
+            if (p.sc_x) {
+              float4 sv = {0.f, 0.f, 0.f, 0.f};
+              if (p.sc_b) { const float sb = p.sc_b[m]; sv = float4{sb, sb, sb, sb}; }
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (c < p.sc_cin) {
+                  const float wv = p.sc_w[m * p.sc_cin + c];
+                  sv.x = fmaf(wv, scx[c].x, sv.x); sv.y = fmaf(wv, scx[c].y, sv.y); sv.z = fmaf(wv, scx[c].z, sv.z); sv.w = fmaf(wv, scx[c].w, sv.w);
+                }
+              }
+              o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
+            }
+          }
           if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-          if (p.y_bf16) {      // four bf16 (round to nearest even) in one 8-byte store
+          if (F_YOUT && p.y_bf16) {      // four bf16 (round to nearest even) in one 8-byte store
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             const bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
             *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + pbase + (long)m * OHW) = __builtin_bit_cast(uint2, ob);
           } else {
             *reinterpret_cast<float4*>(p.y + pbase + (long)m * OHW) = o;
           }
-          if (p.stats) {
-            if (scnt[i][ps] == 0.f) sref[i][ps] = o.x;
-            const float rf = sref[i][ps];
-            const float d0 = o.x - rf, d1 = o.y - rf, d2 = o.z - rf, d3 = o.w - rf;
-            ssum[i][ps] += (d0 + d1) + (d2 + d3);
-            ssq[i][ps] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            scnt[i][ps] += 4.f;
+          if constexpr (F_STATS) {
+            if (p.stats) {
+              if (scnt == 0.f) sref[i][ps] = o.x;
+              const float rf = sref[i][ps];
+              const float d0 = o.x - rf, d1 = o.y - rf, d2 = o.z - rf, d3 = o.w - rf;
+              ssum[i][ps] += (d0 + d1) + (d2 + d3);
+              ssq[i][ps] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
           }
         }
       }
     }
+    if constexpr (F_STATS) {
+      if (p.stats && img < p.N) scnt += 4.f;      // (after ALL channel rows of this pixel quad: the first-value test above reads it)
+    }
   }
-  if constexpr (!PHS) {
+  if constexpr (!PHS && F_STATS) {
     if (p.stats) {      // the 8 lanes of a channel row hold its pixels: (count, mean, M2) per lane, merged pairwise within the octet
       float* const row = p.stats + ((long)bx * WNW + wn) * p.Cout * 3;      // (Chan's update: exact in real arithmetic, no cancellation)
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-          float n = scnt[i][ps];
+          float n = scnt;
           const float inv = n > 0.f ? 1.0f / n : 0.f;
           float mu = sref[i][ps] + ssum[i][ps] * inv;
           float m2 = fmaxf(ssq[i][ps] - ssum[i][ps] * ssum[i][ps] * inv, 0.f);
@@ -730,7 +781,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // TSUB: taps per pass.  When 4*RT*CT*KS^2 accumulator registers (x2 in split mode) do not fit, the taps are processed in
 // ceil(KS^2/TSUB) passes by different workgroups (blockIdx.y = channel block * passes + pass), each staging the same tiles.
-template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS>
+// AUX: the bf16 dy operand (WArgs::dy_bf16) and the input transform of x (WArgs::fold) compiled in — the 4x4 / stride-2 family only
+// (weight gradients of ConvTranspose2d(4, 2, 1) and of the folded encoder convolutions); see pconv_k's FEAT for why not everywhere.
+template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS, bool AUX = false>
 __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
@@ -800,7 +853,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   constexpr int NXI = NQ * (BC / 8), XR = (NXI + NT - 1) / NT;           // x items (channel octet, patch pixel)
   float4 pdy[DR][2];
   float px[XR][8];
-  bool pxin[XR];           // (fold) the staged patch pixel lies inside the map: padding must stay zero
+  bool pxin[AUX ? XR : 1];           // (fold) the staged patch pixel lies inside the map: padding must stay zero
   auto tile_origin = [&](int tile, int& img0, int& ty0, int& tx0) {
     if constexpr (TI == 1) {
       img0 = tile / tpi;
@@ -820,7 +873,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       // (16-byte buffer loads are not usable here: this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to ONE dword
       //  load; plain 16-byte global loads from a clamped, always-valid address + a select instead)
       const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px_) : 0;
-      if (p.dy_bf16) {      // eight bf16 in one 16-byte load (bf16 -> fp32 is a shift)
+      if (AUX && p.dy_bf16) {      // eight bf16 in one 16-byte load (bf16 -> fp32 is a shift)
         const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.dy) + idx);
         const float4 lo = {__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
                            __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
@@ -844,7 +897,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
       const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
       const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
-      pxin[sl] = ok;
+      if constexpr (AUX) pxin[sl] = ok;
       if (p.x_bf16) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
@@ -889,16 +942,18 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int e = tid + NT * r;
       if (NXI % NT != 0 && e >= NXI) return;
       const int oc = e / NQ, q = e - oc * NQ;
-      if (p.fold.scale && pxin[sl]) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS (see pconv_k)
-        const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
-        const float4* const mp = reinterpret_cast<const float4*>(p.fold.mean + ch);
-        const float4* const sp = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch);
-        const float4* const hp = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch);
-        const float4 m0 = mp[0], m1 = mp[1], s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
-        px[sl][0] = fmaf(px[sl][0] - m0.x, s0.x, h0.x); px[sl][1] = fmaf(px[sl][1] - m0.y, s0.y, h0.y);
-        px[sl][2] = fmaf(px[sl][2] - m0.z, s0.z, h0.z); px[sl][3] = fmaf(px[sl][3] - m0.w, s0.w, h0.w);
-        px[sl][4] = fmaf(px[sl][4] - m1.x, s1.x, h1.x); px[sl][5] = fmaf(px[sl][5] - m1.y, s1.y, h1.y);
-        px[sl][6] = fmaf(px[sl][6] - m1.z, s1.z, h1.z); px[sl][7] = fmaf(px[sl][7] - m1.w, s1.w, h1.w);
+      if constexpr (AUX) {
+        if (p.fold.scale && pxin[sl]) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS (see pconv_k)
+          const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const float4 m = reinterpret_cast<const float4*>(p.fold.mean + ch)[hq];
+            const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
+            const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
+            px[sl][4 * hq + 0] = fmaf(px[sl][4 * hq + 0] - m.x, sc.x, sh.x); px[sl][4 * hq + 1] = fmaf(px[sl][4 * hq + 1] - m.y, sc.y, sh.y);
+            px[sl][4 * hq + 2] = fmaf(px[sl][4 * hq + 2] - m.z, sc.z, sh.z); px[sl][4 * hq + 3] = fmaf(px[sl][4 * hq + 3] - m.w, sc.w, sh.w);
+          }
+        }
       }
       bf16x8 t0, t1, t2;
 #pragma unroll
@@ -921,7 +976,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   auto gload = [&](int tile) {
     int img0, ty0, tx0;
     tile_origin(tile, img0, ty0, tx0);
-    img0_staged = img0;
+    if constexpr (AUX) img0_staged = img0;
 #pragma unroll
     for (int r = 0; r < DR; ++r) gload_dy(img0, ty0, tx0, r, r);
 #pragma unroll
@@ -938,7 +993,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     } else {                                           // item by item through one register set
       int img0, ty0, tx0;
       tile_origin(tile, img0, ty0, tx0);
-      img0_staged = img0;
+      if constexpr (AUX) img0_staged = img0;
 #pragma unroll 2
       for (int r = 0; r < DR; ++r) { gload_dy(img0, ty0, tx0, r, 0); sstore_dy(r, 0); }
 #pragma unroll 2
@@ -1144,13 +1199,23 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const bool small_grid = ptiles * agl_cdiv(a.Cout, bm) * (pl.splits > 1 ? pl.splits : 1) < 512;
   const bool w8 = (a.w8 || small_grid) && a.nsplit == 3 && !s2 && (a.ks == 3 || a.ks == 5) && geo != 2 && geo != 3;
   const int wcols = w8 ? 4 : 2;                 // wave columns = statistic rows per pixel tile
-  if (pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 3 <= a.stats_floats) {
+  // features compiled into some instantiations only (pconv_k FEAT): input transform + statistics rows in the 4x4 / stride-2 family,
+  // statistics rows in the bf16 5x5 forms, bf16 output / addend in the bf16 3x3 stride-1 and 1x1 forms
+  const bool fam42 = s2 && a.ks == 4, fam5 = !s2 && a.ks == 5 && a.nsplit == 1, famy = !s2 && a.nsplit == 1 && (a.ks == 3 || a.ks == 1);
+  if (a.fold.scale && !fam42) return -1;
+  if ((a.y_bf16 || a.addend) && !famy) return -1;
+  if ((fam42 || fam5) && pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 3 <= a.stats_floats) {
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
   }
+  const int feat42 = (a.fold.scale || p.stats) ? 3 : 0, feat5 = p.stats ? 2 : 0, featy = (a.y_bf16 || a.addend) ? 4 : 0;
+  const bool featsc = a.sc_x != nullptr;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
   p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend;
+  p.sc_x = a.sc_x; p.sc_w = a.sc_w; p.sc_b = a.sc_b; p.sc_cin = a.sc_cin;
+  if (a.sc_x && !(a.ks == 3 && !s2 && a.nsplit == 1 && bm == 64 && geo != 2 && pl.splits == 1 && a.sc_cin >= 1 && a.sc_cin <= 4 && a.OW % 4 == 0))
+    return -1;                                                       // (compiled into the bf16 3x3 stride-1 instantiations with 64-channel tiles)
   if ((a.y_bf16 || a.addend) && pl.splits > 1) return -1;            // (... writes fp32 in place)
   if (a.y_bf16 && a.accumulate && !a.addend) return -1;              // (in-place accumulation reads y as fp32)
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
@@ -1162,18 +1227,21 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   }
 #define PC_LAUNCH(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_>), g, dim3(NT), 0, st, p)
+#define PC_LAUNCH_F(F_, KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
+  hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, false, 256, 0, false, F_>), g, dim3(NT), 0, st, p)
 #define PC_LAUNCH_DB(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, true>), g, dim3(NT), 0, st, p)
 #define PC_LAUNCH8(KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, DB_) \
   hipLaunchKernelGGL((pconv_k<KS_, S_, TW_, TH_, TI_, BM_, NS_, TG_, false, DB_, 512>), g, dim3(512), 0, st, p)
-#define PC_SHAPES1(KS_, BM_, TG_)                                                                        \
+#define PC_SHAPES1(KS_, BM_, TG_) PC_SHAPES1F(0, KS_, BM_, TG_)
+#define PC_SHAPES1F(F_, KS_, BM_, TG_)                                                                   \
   do {                                                                                                   \
-    if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, BM_, 1, TG_);                                               \
-    else if (geo == 0 && !wide) PC_LAUNCH(KS_, 1, 16, 8, 1, BM_, 1, TG_);                                \
-    else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 8, 1, BM_, 1, TG_);                                  \
-    else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 16, 1, BM_, 1, TG_);                                        \
-    else if (geo == 1 && !wide) PC_LAUNCH(KS_, 1, 8, 8, 2, BM_, 1, TG_);                                 \
-    else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 4, BM_, 1, TG_);                                          \
+    if (geo == 3) PC_LAUNCH_F(F_, KS_, 1, 8, 8, 1, BM_, 1, TG_);                                         \
+    else if (geo == 0 && !wide) PC_LAUNCH_F(F_, KS_, 1, 16, 8, 1, BM_, 1, TG_);                          \
+    else if (geo == 0 && w32) PC_LAUNCH_F(F_, KS_, 1, 32, 8, 1, BM_, 1, TG_);                            \
+    else if (geo == 0) PC_LAUNCH_F(F_, KS_, 1, 16, 16, 1, BM_, 1, TG_);                                  \
+    else if (geo == 1 && !wide) PC_LAUNCH_F(F_, KS_, 1, 8, 8, 2, BM_, 1, TG_);                           \
+    else if (geo == 1) PC_LAUNCH_F(F_, KS_, 1, 8, 8, 4, BM_, 1, TG_);                                    \
   } while (0)
 #define PC_SHAPES3(KS_, TG_)                                                                             \
   do {                                                                                                   \
@@ -1182,36 +1250,37 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 8, 1, 64, 3, TG_);                                          \
     else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 2, 64, 3, TG_);                                           \
   } while (0)
-#define PC_STRIDE2(KS_, TG_)                                                                             \
+#define PC_STRIDE2(F_, KS_, TG_)                                                                         \
   do {                                                                                                   \
     if (a.nsplit == 3) {                                                                                 \
-      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 4, 1, 64, 3, TG_);                                             \
-      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 1, 64, 3, TG_);                                         \
-      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 16, 64, 3, TG_);                                        \
-      else PC_LAUNCH(KS_, 2, 4, 4, 4, 64, 3, TG_);                                                       \
+      if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 4, 1, 64, 3, TG_);                                       \
+      else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 1, 64, 3, TG_);                                   \
+      else if (geo == 5) PC_LAUNCH_F(F_, KS_, 2, 2, 2, 16, 64, 3, TG_);                                  \
+      else PC_LAUNCH_F(F_, KS_, 2, 4, 4, 4, 64, 3, TG_);                                                 \
     } else if (bm == 128) {                                                                              \
-      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 128, 1, TG_);                                            \
-      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 128, 1, TG_);                                        \
-      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 32, 128, 1, TG_);                                       \
-      else PC_LAUNCH(KS_, 2, 4, 4, 8, 128, 1, TG_);                                                      \
+      if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 8, 1, 128, 1, TG_);                                      \
+      else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 2, 128, 1, TG_);                                  \
+      else if (geo == 5) PC_LAUNCH_F(F_, KS_, 2, 2, 2, 32, 128, 1, TG_);                                 \
+      else PC_LAUNCH_F(F_, KS_, 2, 4, 4, 8, 128, 1, TG_);                                                \
     } else {                                                                                             \
-      if (geo == 0) PC_LAUNCH(KS_, 2, 16, 8, 1, 64, 1, TG_);                                             \
-      else if (geo == 1) PC_LAUNCH(KS_, 2, 8, 8, 2, 64, 1, TG_);                                         \
-      else if (geo == 5) PC_LAUNCH(KS_, 2, 2, 2, 32, 64, 1, TG_);                                        \
-      else PC_LAUNCH(KS_, 2, 4, 4, 8, 64, 1, TG_);                                                       \
+      if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 8, 1, 64, 1, TG_);                                       \
+      else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 2, 64, 1, TG_);                                   \
+      else if (geo == 5) PC_LAUNCH_F(F_, KS_, 2, 2, 2, 32, 64, 1, TG_);                                  \
+      else PC_LAUNCH_F(F_, KS_, 2, 4, 4, 8, 64, 1, TG_);                                                 \
     }                                                                                                    \
   } while (0)
-#define PC_1X1(BM_, NS_)                                                                                 \
+#define PC_1X1(F_, BM_, NS_)                                                                             \
   do {                                                                                                   \
-    if (geo == 0) PC_LAUNCH(1, 1, 16, 8, 1, BM_, NS_, 1);                                                \
-    else if (geo == 1) PC_LAUNCH(1, 1, 8, 8, 2, BM_, NS_, 1);                                            \
-    else PC_LAUNCH(1, 1, 4, 4, 8, BM_, NS_, 1);                                                          \
+    if (geo == 0) PC_LAUNCH_F(F_, 1, 1, 16, 8, 1, BM_, NS_, 1);                                          \
+    else if (geo == 1) PC_LAUNCH_F(F_, 1, 1, 8, 8, 2, BM_, NS_, 1);                                      \
+    else PC_LAUNCH_F(F_, 1, 1, 4, 4, 8, BM_, NS_, 1);                                                    \
   } while (0)
   if (s2) {
-    if (a.ks == 4) PC_STRIDE2(4, 4); else PC_STRIDE2(3, 3);
+    if (a.ks == 4) { if (feat42) PC_STRIDE2(3, 4, 4); else PC_STRIDE2(0, 4, 4); } else PC_STRIDE2(0, 3, 3);
   } else if (a.ks == 1) {
-    if (a.nsplit == 3) { if (bm == 128) PC_1X1(128, 3); else PC_1X1(64, 3); }
-    else { if (bm == 128) PC_1X1(128, 1); else PC_1X1(64, 1); }
+    if (a.nsplit == 3) { if (bm == 128) PC_1X1(0, 128, 3); else PC_1X1(0, 64, 3); }
+    else if (featy) { if (bm == 128) PC_1X1(4, 128, 1); else PC_1X1(4, 64, 1); }
+    else { if (bm == 128) PC_1X1(0, 128, 1); else PC_1X1(0, 64, 1); }
   } else if (a.ablate > 0 && a.ks == 3 && a.nsplit == 3 && wide && w32) {      // diagnostic builds of ONE geometry (tools/ablate.sh)
 #define PC_ABL(A_) hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 3, 3, false, false, 256, A_>), g, dim3(256), 0, st, p)
     switch (a.ablate) {
@@ -1238,9 +1307,15 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   } else if (a.ks == 3) {
     if (geo == 2) {
       if (a.nsplit == 3) PC_LAUNCH_DB(3, 1, 4, 4, 8, 64, 3, 3);    // one kernel row per stage, two weight + two patch buffers
+      else if (featy) {
+        if (wide) { if (bm == 128) PC_LAUNCH_F(4, 3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH_F(4, 3, 1, 4, 4, 16, 64, 1, 9); }
+        else { if (bm == 128) PC_LAUNCH_F(4, 3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH_F(4, 3, 1, 4, 4, 8, 64, 1, 9); }
+      }
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
-    } else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
+    } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
+    else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
+    else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
     else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, 3, 3); else PC_LAUNCH(3, 1, 16, 16, 1, 64, 3, 3); }
     else if (bm == 128) {
       if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, 3, 3);
@@ -1250,7 +1325,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     }
     else PC_SHAPES3(3, 9);
   } else {
-    if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
+    if (a.nsplit == 1 && feat5) { if (bm == 128) PC_SHAPES1F(2, 5, 128, 5); else PC_SHAPES1F(2, 5, 64, 5); }
+    else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
     else if (geo == 3) PC_LAUNCH_DB(5, 1, 8, 8, 1, 64, 3, 5);
     else if (geo == 0 && w32) PC_LAUNCH_DB(5, 1, 32, 4, 1, 64, 3, 5);
     else if (geo == 0) PC_LAUNCH_DB(5, 1, 16, 8, 1, 64, 3, 5);
@@ -1259,6 +1335,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #undef PC_STRIDE2
 #undef PC_1X1
 #undef PC_SHAPES1
+#undef PC_SHAPES1F
+#undef PC_LAUNCH_F
 #undef PC_SHAPES3
 #undef PC_LAUNCH
 #undef PC_LAUNCH_DB
@@ -1366,7 +1444,7 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
-  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr;
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * (a.x_bf16 ? 2 : 4));
   if (a.x_bf16 && a.nsplit != 1) return -1;
   if (a.nsplit == 1) {
@@ -1417,6 +1495,11 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles, int*
   return 0;
 }
 bool pconvT_eligible(const PConvArgs& a) { int g, b; long t; return pconvT_plan(a, &g, &b, &t) == 0; }
+// ... and in the form that reads a bf16 pos_mask (bf16 arithmetic, even size, paired phases, no reduction split)
+bool pconvT_takes_bf16_mask(const PConvArgs& a) {
+  int g, b, sp; long t;
+  return pconvT_plan(a, &g, &b, &t, &sp) == 0 && sp == 1 && g != 3 && a.nsplit == 1 && a.OH == 2 * a.H && a.OW == 2 * a.W;
+}
 long pconvT_ws_bytes(int Cred, int Crow, int nsplit) {
   if (Cred % 16 != 0 || Crow < 48) return 0;
   return (long)nsplit * (Cred / 16) * 2 * 16 * round_up(Crow, 128) * 16;
@@ -1447,8 +1530,10 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
-  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr;
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
   if (a.x_bf16 && a.nsplit != 1) return -1;
+  // bf16 ReLU mask: the paired-phase epilogue of the bf16 instantiations (16-byte pieces of 8 mask elements), no reduction split, even size
+  if (a.mask_bf16 && (a.nsplit != 1 || !a.pos_mask || splits > 1 || geo == 3 || a.OH != 2 * a.H)) return -1;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4));
   dim3 g((unsigned)ptiles, agl_cdiv(a.Cout, bm), (geo == 3 ? 4 : 2) * splits);      // 2x2 maps: one workgroup per phase; else per row phase
   pconv_xcd_order(p, g, geo == 3 ? 4 : 2);
@@ -1460,9 +1545,20 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
     else if (geo == 2) PT_LAUNCH(4, 4, 8, BM_, NS_);              \
     else PT_LAUNCH(2, 2, 32, BM_, NS_);                           \
   } while (0)
-  if (a.nsplit == 3) PT_GEO(64, 3);
+#define PT_LAUNCH_M(TW_, TH_, TI_, BM_) \
+  hipLaunchKernelGGL((pconv_k<2, 1, TW_, TH_, TI_, BM_, 1, 4, true, false, 256, 0, false, 8>), g, dim3(NT), 0, st, p)
+#define PT_GEO_M(BM_)                                             \
+  do {                                                            \
+    if (geo == 0) PT_LAUNCH_M(16, 8, 1, BM_);                     \
+    else if (geo == 1) PT_LAUNCH_M(8, 8, 2, BM_);                 \
+    else PT_LAUNCH_M(4, 4, 8, BM_);                               \
+  } while (0)
+  if (a.mask_bf16) { if (bm == 128) PT_GEO_M(128); else PT_GEO_M(64); }
+  else if (a.nsplit == 3) PT_GEO(64, 3);
   else if (bm == 128) PT_GEO(128, 1);
   else PT_GEO(64, 1);
+#undef PT_GEO_M
+#undef PT_LAUNCH_M
 #undef PT_GEO
 #undef PT_LAUNCH
   AGL_CHECK_LAUNCH(name);
@@ -1578,6 +1674,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
   p.x_bf16 = a.x_bf16; p.dy_bf16 = a.dy_bf16; p.fold = a.fold;
   if (a.dy_bf16 && (a.nsplit != 1 || (a.OW % 8 != 0 && !(a.OW == 4 && a.OH == 4)))) return -1;      // (16-byte pieces of 8 bf16)
+  const bool aux = a.dy_bf16 || a.fold.scale != nullptr;
+  if (aux && !(a.ks == 4 && a.stride == 2)) return -1;      // (compiled into the 4x4 / stride-2 instantiations only)
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4)); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
@@ -1595,13 +1693,22 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);     \
     else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);                    \
   } while (0)
+#define PW_LAUNCH_AUX(KS_, S_, RT_, CT_, NS_)                                                                       \
+  do {                                                                                                              \
+    if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);           \
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);      \
+    else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);      \
+    else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);     \
+    else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);                    \
+  } while (0)
 #define PW_LAUNCH1(KS_, RT_, CT_, NS_)      /* 3x3, bf16 mode, <= 64 output channels: the 4 x 32 tile (shape 5) */              \
   do {                                                                                                              \
     if (half == 5) hipLaunchKernelGGL((pbww_k<KS_, 1, 32, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);            \
     else PW_LAUNCH(KS_, 1, RT_, CT_, NS_);                                                                          \
   } while (0)
   if (a.stride == 2) {
-    if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
+    if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH_AUX(4, 2, 2, 1, 1); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
+    else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
     else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 2, 1, 1);
            else if (ct == 2) PW_LAUNCH(3, 2, 1, 2, 1); else PW_LAUNCH(3, 2, 1, 1, 1); }
   } else if (a.ks == 1) {
@@ -1619,6 +1726,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
   }
 #undef PW_LAUNCH1
+#undef PW_LAUNCH_AUX
 #undef PW_LAUNCH
   AGL_CHECK_LAUNCH(name);
   if (with_bias && a.dbias_done) *a.dbias_done = 1;

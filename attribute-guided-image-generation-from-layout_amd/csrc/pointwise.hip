@@ -298,6 +298,62 @@ __global__ void avgpool2_bwd4_k(const float* __restrict__ dy, const float* __res
   *reinterpret_cast<float4*>(dx + o) = v;
 }
 
+// Forward with wide accesses and an fp32 or bf16 input (IN16): a thread owns two output rows' worth of one 8-column strip — it reads
+// 2 rows x 8 columns (fp32: two 16-byte loads per row; bf16: one) and writes 4 outputs (one 16-byte store).  W % 8 == 0, H even.
+template <bool IN16>
+__global__ void avgpool2_fwd_w_k(const void* __restrict__ xv, float* __restrict__ y, long NC, int H, int W, int in_relu) {
+  const unsigned OH = H / 2, OW = W / 2, Q = W / 8;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * OH * Q)) return;
+  const unsigned q = i % Q, t = i / Q, oh = t % OH, nc = t / OH;
+  const long base = (long)nc * H * W + (long)(2 * oh) * W + 8 * q;
+  float r[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if constexpr (IN16) {
+      const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(xv) + base + (long)k * W);
+      const unsigned u[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { r[k][2 * j] = __builtin_bit_cast(float, u[j] << 16); r[k][2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u); }
+    } else {
+      const float* p = reinterpret_cast<const float*>(xv) + base + (long)k * W;
+      const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+      r[k][0] = a.x; r[k][1] = a.y; r[k][2] = a.z; r[k][3] = a.w; r[k][4] = b.x; r[k][5] = b.y; r[k][6] = b.z; r[k][7] = b.w;
+    }
+  }
+  if (in_relu) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[k][j] = fmaxf(r[k][j], 0.f);
+  }
+  float4 o;      // (the same order of additions as avgpool2_fwd_k: a + b + c + d)
+  o.x = (r[0][0] + r[0][1] + r[1][0] + r[1][1]) * 0.25f; o.y = (r[0][2] + r[0][3] + r[1][2] + r[1][3]) * 0.25f;
+  o.z = (r[0][4] + r[0][5] + r[1][4] + r[1][5]) * 0.25f; o.w = (r[0][6] + r[0][7] + r[1][6] + r[1][7]) * 0.25f;
+  *reinterpret_cast<float4*>(y + (long)nc * OH * OW + (long)oh * OW + 4 * q) = o;
+}
+// avgpool2_bwd4_k with the ReLU mask read from a bf16 x (four elements per 8-byte load)
+__global__ void avgpool2_bwd4_m16_k(const float* __restrict__ dy, const unsigned short* __restrict__ x, float* __restrict__ dx, long NC, int H, int W,
+                                    int accumulate) {
+  const unsigned OW = W / 2, W4 = W / 4;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W4)) return;
+  const unsigned w4 = i % W4, t = i / W4, h = t % H, nc = t / H;
+  const float2 d = *reinterpret_cast<const float2*>(dy + (long)nc * (H / 2) * OW + (long)(h / 2) * OW + 2 * w4);
+  float4 v = {0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y};
+  const long o = 4L * i;
+  const uint2 b = *reinterpret_cast<const uint2*>(x + o);
+  if (!(__builtin_bit_cast(float, b.x << 16) > 0.f)) v.x = 0.f;
+  if (!(__builtin_bit_cast(float, b.x & 0xffff0000u) > 0.f)) v.y = 0.f;
+  if (!(__builtin_bit_cast(float, b.y << 16) > 0.f)) v.z = 0.f;
+  if (!(__builtin_bit_cast(float, b.y & 0xffff0000u) > 0.f)) v.w = 0.f;
+  if (accumulate) {
+    const float4 ov = *reinterpret_cast<const float4*>(dx + o);
+    v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+  }
+  *reinterpret_cast<float4*>(dx + o) = v;
+}
+
 // nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
 __global__ void upsample_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int k) {
   const unsigned OH = H << k, OW = W << k;
@@ -834,8 +890,27 @@ int agl_scatter_rows(const float* src, const long long* rows, float* out, long R
 
 int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream) {
   AGL_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2 && NC * H * W < (1L << 31), "agl_avgpool2_fwd: bad argument");
-  LAUNCH1D(avgpool2_fwd_k, NC * (H / 2) * (W / 2), x, y, NC, H, W, in_relu);
+  if (W % 8 == 0 && H % 2 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    LAUNCH1D(avgpool2_fwd_w_k<false>, NC * (H / 2) * (W / 8), (const void*)x, y, NC, H, W, in_relu);
+  else
+    LAUNCH1D(avgpool2_fwd_k, NC * (H / 2) * (W / 2), x, y, NC, H, W, in_relu);
   AGL_CHECK_LAUNCH("agl_avgpool2_fwd");
+  return AGL_OK;
+}
+
+// The same for an input stored as bf16 (the output of a discriminator block that only convolutions and this pool read): W % 8 == 0
+int agl_avgpool2_fwd_x16(const void* x_bf16, float* y, long NC, int H, int W, int in_relu, void* stream) {
+  AGL_REQUIRE(x_bf16 && y && NC > 0 && H >= 2 && H % 2 == 0 && W >= 8 && W % 8 == 0 && NC * H * W < (1L << 31) &&
+              (((uintptr_t)x_bf16 | (uintptr_t)y) & 15) == 0, "agl_avgpool2_fwd_x16: bad argument (W % 8 == 0, even H, 16-byte aligned)");
+  LAUNCH1D(avgpool2_fwd_w_k<true>, NC * (H / 2) * (W / 8), x_bf16, y, NC, H, W, in_relu);
+  AGL_CHECK_LAUNCH("agl_avgpool2_fwd_x16");
+  return AGL_OK;
+}
+// Backward of avg_pool2(relu(x)) with x stored as bf16 (read for the mask only): dx (+)= 0.25 * dy where x > 0.  W % 4 == 0, even H.
+int agl_avgpool2_bwd_x16(const float* dy, const void* x_bf16, float* dx, long NC, int H, int W, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && x_bf16 && dx && NC > 0 && H >= 2 && H % 2 == 0 && W % 4 == 0 && NC * H * W < (1L << 31), "agl_avgpool2_bwd_x16: bad argument");
+  LAUNCH1D(avgpool2_bwd4_m16_k, NC * H * (W / 4), dy, (const unsigned short*)x_bf16, dx, NC, H, W, accumulate);
+  AGL_CHECK_LAUNCH("agl_avgpool2_bwd_x16");
   return AGL_OK;
 }
 

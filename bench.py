@@ -44,7 +44,9 @@ DTYPE_NAME = {"f32": "f32", "f32x3": "f32x3", "bf16": "bf16"}
 PRODUCTS = {
     "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution",
     "f32x3": "bf16x3 split products: fp32 tensors, 6 bf16-MFMA products per fp32 multiply-add (fp32-accurate), fp32 accumulation",
-    "bf16": "bf16 MFMA operands (rounded once when staged), fp32 accumulation, fp32 tensors in HBM",
+    "bf16": "bf16 MFMA operands (rounded once when staged), fp32 accumulation; activations with convolution-only readers stored as bf16 "
+            "(SPADE outputs in front of the decoder's layers, box-filtered maps, first-convolution outputs of the flat D blocks), the "
+            "rest and all statistics / gradients fp32",
 }
 ARITHMETIC = {
     "f32": "fp32 tensors; every convolution on exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
@@ -53,10 +55,14 @@ ARITHMETIC = {
              "terms (exact to 2^-27) and six bf16-MFMA products are accumulated in fp32 — as accurate as the fp32 MFMA chain "
              "(tests: error vs fp64 <= 2x that of the exact kernel; whole step at this size vs the CPU oracle at the fp32 "
              "tolerances); exact fp32 MFMA in all other kernels",
-    "bf16": "fp32 tensors in HBM; convolution operands rounded to bf16 when staged, bf16 MFMA with fp32 accumulation",
+    "bf16": "convolution operands rounded to bf16 when staged (or stored as bf16 by their producer when only convolutions read them: "
+            "identical values), bf16 MFMA with fp32 accumulation; BatchNorm / ConditionalBatchNorm apply folded into the consuming "
+            "convolution's staging pass; statistics, spectral norm, losses, gradients and Adam fp32",
 }
-CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight")
-NORM_NAMES = ("agl_bn_stats", "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd")
+CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "agl_conv2d_bwd_weight", "agl_conv2d_fwd_fold",
+              "agl_conv2d_bwd_weight_fold", "agl_conv2d_fwd_addend", "agl_conv2d_fwd_shortcut")
+NORM_NAMES = ("agl_bn_stats", "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd", "agl_norm_bwd_fold", "agl_norm_apply_fwd_y16",
+              "agl_norm_bwd_y16")
 
 
 def parse_args(argv=None):
@@ -150,14 +156,18 @@ def cpu_baseline(max_seconds=30.0):
 
 
 def hbm_traffic(tag):
-    """HBM bytes per launch of the normalisation family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md §HBM prescribes; tools/hbm_table.py writes the file).  None if not collected."""
-    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(tag)
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per iteration of the normalisation family and of the convolution family from the committed rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/hbm_table.py writes the file).  The newest
+    round's file that has the tag; None if not collected."""
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f).get(tag)
+            if d:
+                return d
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
@@ -224,8 +234,16 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         with tr.serial():
             one_step()
             tr.finish()
-        fence()
-        log, L.EVENT_LOG = L.EVENT_LOG, None
+            fence()
+            log, L.EVENT_LOG = L.EVENT_LOG, None
+            # the same one-stream schedule without the per-launch events: its step time over the timed (concurrent) schedule's is the
+            # overlap the chains on several streams buy — what a kernel-stats profile, which serialises them, cannot show
+            t1 = time.perf_counter()
+            for _ in range(3):
+                one_step()
+            tr.finish()
+            fence()
+            serial_ms = 1e3 * (time.perf_counter() - t1) / 3
     if not a.no_roofline and rank == 0:
         conv = [e for e in log if e[0] in CONV_NAMES]
         conv_ms = sum(e[1].elapsed_time(e[2]) for e in conv)
@@ -262,15 +280,23 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             by_pipe[PIPE_NAME[pipe]] = {"launches": len(sel), "ms": round(ms, 3), "executed_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms else None,
                                         "peak_tflops": round(PIPE_PEAK[pipe], 1), "frac": round(fl / (PIPE_PEAK[pipe] * 1e12) / (ms * 1e-3), 4) if ms else None}
         frac = t_at_peak / (conv_ms * 1e-3)
-        # achieved / peak are quoted on the pipe where most of the convolution time is spent (bf16 MFMA unless --dtype f32)
+        # achieved = executed (fp32-equivalent) FLOPs over the launches' time — comparable from round to round and between arithmetic
+        # modes; peak = the FLOP-weighted harmonic mean of the peaks of the pipes the launches ran on, so that
+        # frac = achieved / peak = time at peak / time taken.  The bf16 issue rate (split products counted six times) is its own key.
+        achieved = executed / (conv_ms * 1e-3) / 1e12
         main_pipe = max(by_pipe.values(), key=lambda v: v["ms"])
         on_bf16 = main_pipe["peak_tflops"] != round(PEAK_F32_MFMA_TFLOPS, 1)
-        peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "achieved": round(frac * peak, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(frac, 4), "traffic": None,
-                "definition": "sum over conv launches of executed FLOPs / peak of the pipe the launch ran on (fp32 157.3, bf16 MFMA 2500, "
-                              "split-operand bf16 MFMA 2500/6 fp32-equivalent), divided by the launches' measured time; achieved = frac x peak "
-                              "of the pipe most of that time is spent on (" + ("bf16 MFMA issue rate: split products count 6x" if on_bf16 else "fp32 MFMA") + ")",
+        tr_conv = hbm_traffic(f"{res}_{dtype}")
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(achieved / frac, 1), "unit": "TFLOP/s",
+                "frac": round(frac, 4),
+                "traffic": round(tr_conv["conv_bytes_per_iteration"] / max(1, len(conv))) if tr_conv and "conv_bytes_per_iteration" in tr_conv else None,
+                "traffic_source": tr_conv.get("source") if tr_conv and "conv_bytes_per_iteration" in tr_conv else None,
+                "achieved_bf16_issue": round(frac * PEAK_BF16_MFMA_TFLOPS, 2) if on_bf16 else None,
+                "definition": "achieved = executed fp32-equivalent FLOPs of all convolution launches / their measured time (one stream, HIP events per "
+                              "launch); peak = FLOP-weighted harmonic mean of the peak of the pipe each launch ran on (fp32 157.3, bf16 MFMA 2500, "
+                              "split-operand bf16 MFMA 2500/6 fp32-equivalent); frac = achieved / peak = time at peak / time taken; "
+                              "achieved_bf16_issue = frac x 2500 (bf16 MFMA issue rate: split products count 6x); traffic = HBM bytes per "
+                              "launch of the family from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)",
                 "by_pipe": by_pipe,
                 "kernel": "convolution family: pconv_k / pbww_k (bf16 matrix cores) + igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + "
                           "few_bww_k / small_cout_conv incl. weight packing and slab / split-K reductions (all agl_conv2d_* launches of one step)",
@@ -298,6 +324,9 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
     torch.cuda.empty_cache()
     if rank != 0:
         return None
+    if roof is not None:
+        roof["serial_ms_per_step"] = round(serial_ms, 3)      # the same kernels on one stream in program order
+        roof["overlap_factor"] = round(serial_ms / (1e3 * dt / steps), 3)
     images = per_gpu * world * steps
     return {"value": round(images / dt, 3), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
             "dtype": DTYPE_NAME[dtype],

@@ -114,6 +114,7 @@ int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout
  * AGL_CONV_X_BF16 on agl_conv2d_bwd_data: dy holds bf16 (the bf16-stored input of a ConvTranspose2d, generator_obj_att.py:532-540,
  * whose forward IS this call): agl_conv2d_bwd_data_takes_bf16_dy;  AGL_CONV_DY_BF16 on agl_conv2d_bwd_weight: dy holds bf16 (the
  * same tensor in the weight gradient of that transposed convolution): agl_conv2d_bwd_weight_takes_bf16_dy. */
+int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
 int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int relu, int accumulate,
                                  int flags);
 int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
@@ -144,6 +145,14 @@ int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_
 int agl_conv2d_fwd_addend(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* addend,
                           float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int in_relu,
                           int relu, int flags, void* stream);
+/* y = conv3x3(x) + bias + [sc_bias[m] + sum_c sc_w[m][c] * sc_x[n][c][pixel]] (+ ReLU): the learnable 1x1 shortcut of the discriminators'
+ * first block (discriminator.py:43-44, :58-60: out = resi(x) + sc(x), x has 3 channels) evaluated in the 3x3 convolution's epilogue —
+ * one launch reads 3 input channels instead of a second launch adding a 64-channel tensor.  x may hold bf16 (AGL_CONV_X_BF16), y bf16
+ * (AGL_CONV_Y_BF16).  bf16 arithmetic, Cout <= 64 (agl_conv2d_fwd_shortcut_ok). */
+int agl_conv2d_fwd_shortcut_ok(int N, int Cin, int H, int W, int Cout, int ks, int pad, int flags);
+int agl_conv2d_fwd_shortcut(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, const float* sc_x,
+                            const float* sc_w, const float* sc_bias, int sc_cin, float* y, void* ws, long ws_bytes, int N, int Cin, int H, int W,
+                            int Cout, int ks, int pad, int in_relu, int relu, int flags, void* stream);
 /* dbias / dbias_done (optional, both NULL or both set): the bias gradient db[Cout] = sum over (n, oh, ow) of dy, added to dbias
  * when dbias_accumulate (its own flag: a spectrally normalised layer returns dw fresh but accumulates db in place).  The
  * matrix-core weight-gradient kernel forms it from the dy tiles it stages anyway; *dbias_done (host int) is 1 when the call did so
@@ -205,6 +214,16 @@ int agl_norm_bwd(const float* dy, const float* x, const float* y, const float* m
                  const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
                  float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
                  int W, int src_w, void* ws, long ws_bytes, void* stream);
+/* bf16-stored forward output (bf16 arithmetic): agl_norm_apply_fwd_y16 writes y as bf16 (round to nearest even) — for a tensor whose
+ * only readers are bf16-mode convolutions, which would round the fp32 tensor to these very values when staging it (AGL_CONV_X_BF16 /
+ * AGL_CONV_DY_BF16) — and agl_norm_bwd_y16 reads that tensor for the ReLU mask.  Same arguments as the fp32 forms otherwise. */
+int agl_norm_apply_fwd_y16(const float* x, const float* mean, const float* rstd, int mode, const float* p0, const float* p1,
+                           const long long* labels, const float* residual, int relu, void* y_bf16, int N, int C, int HW,
+                           const int* gb_map, int W, int src_w, void* stream);
+int agl_norm_bwd_y16(const float* dy, const float* x, const void* y_bf16, const float* mean, const float* rstd, int mode,
+                     const float* p0, const float* p1, const long long* labels, int relu, int batch_stats, float* dx,
+                     float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, const int* gb_map, const int* gb_lo,
+                     int W, int src_w, void* ws, long ws_bytes, void* stream);
 int agl_norm_bwd_fold(const float* dy, const float* x, const float* mean, const float* rstd, const float* fold_scale, const float* fold_shift,
                       int fold_per_n, int mode, const float* p0, const float* p1, const long long* labels, int relu, int batch_stats,
                       float* dx, float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,
@@ -252,6 +271,10 @@ int agl_grid_gather_bwd(const float* dy, const int* lo_y, const int* lo_x, float
 int agl_avgpool2_fwd(const float* x, float* y, long NC, int H, int W, int in_relu, void* stream);
 int agl_avgpool2_bwd(const float* dy, const float* x, float* dx, long NC, int H, int W, int in_relu, int accumulate,
                      void* stream);
+/* The same pair for an x stored as bf16 (a discriminator block output that only convolutions and this pool read, bf16 arithmetic):
+ * the forward reads 8 elements per 16-byte load (W % 8 == 0), the backward reads x for the ReLU mask only (always in_relu). */
+int agl_avgpool2_fwd_x16(const void* x_bf16, float* y, long NC, int H, int W, int in_relu, void* stream);
+int agl_avgpool2_bwd_x16(const float* dy, const void* x_bf16, float* dx, long NC, int H, int W, int accumulate, void* stream);
 int agl_upsample_nearest_fwd(const float* x, float* y, long NC, int H, int W, int log2_factor, void* stream);
 int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, int log2_factor, int accumulate,
                              void* stream);

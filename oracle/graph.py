@@ -10,8 +10,9 @@ every number on the hot path is produced by third-party PyTorch ops (SURVEY.md Â
 "Where the arithmetic really lives").  This file therefore restates the reference's
 *graph* (which op, on which operand, in which order, with which state side effects)
 as plain functions over one flat ``{state_dict key: tensor}`` dictionary, and calls
-the same torch CPU ops at the leaves.  Independent closed-form restatements of the
-non-trivial leaves (bilinear crop, spectral norm) live in `oracle/leaf_formulas.py`.
+the same torch CPU ops at the leaves.  The two non-trivial leaves are restated in
+closed form in this file: the bilinear crop (`crop_boxes`, models/bilinear.py:26-136)
+and the spectral-norm power iteration (`sn_weight`, torch.nn.utils.spectral_norm).
 
 Parity pin: `oracle/make_golden.py` imports the real reference from /root/reference
 in the build container, checks this restatement against it (max |diff| printed, must

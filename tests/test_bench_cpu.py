@@ -42,6 +42,19 @@ def test_four_rank_rehearsal_over_gloo():
     assert out["max_rank_seconds"] >= 0.04          # MAX over ranks: rank 3 sleeps 40 ms
 
 
+def test_eight_rank_rehearsal_over_gloo():
+    """the launch the driver uses on the 8-GPU node (`--gpus 8`, BASELINE configs 4 / 5), rehearsed on CPU
+    over gloo: eight ranks rendezvous on 127.0.0.1, barrier, MAX-over-ranks timing, one JSON line from rank 0 with dp8."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert out["max_rank_seconds"] >= 0.08          # MAX over ranks: rank 7 sleeps 80 ms
+
+
 def test_single_rank_dry_run_prints_one_line():
     r = subprocess.run([sys.executable, BENCH, "--dry-run"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -684,6 +684,155 @@ def test_loss_kernels_large_rows_and_bad_labels():
     close(da, ar.grad, 1e-6, "l1_rows gradient")
 
 
+NORM_FOLD_CASES = [  # (mode: 0 BN / 1 affine BN / 2 ConditionalBN), N, Cin, H, Cout, ks, stride, pad, relu
+    (2, 6, 64, 16, 128, 4, 2, 1, True), (2, 9, 32, 32, 64, 4, 2, 1, True), (1, 5, 32, 16, 64, 3, 1, 1, True), (0, 4, 48, 16, 96, 4, 2, 1, False),
+    (2, 3, 64, 33, 128, 4, 2, 1, True), (2, 7, 32, 8, 64, 5, 1, 2, False), (1, 17, 64, 8, 128, 4, 2, 1, True), (2, 2, 128, 64, 256, 4, 2, 1, True)]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
+@pytest.mark.parametrize("case", NORM_FOLD_CASES)
+def test_norm_folded_into_the_consuming_convolution(case, mode):
+    """BASELINE north_star / SURVEY a2: conv(relu(CondBN(x))) with the normalise-modulate applied while the convolution stages its
+    input (agl_norm_fold_table + agl_conv2d_fwd_fold + agl_conv2d_bwd_weight_fold + agl_norm_bwd_fold; F.norm_conv2d).  Against
+    torch on the CPU (BatchNorm in training mode with the module's own affine / class-table parameters, then ReLU, then conv2d):
+    output, input gradient, parameter gradients of the norm, weight gradient, running statistics; against the two-pass HIP form
+    (AGL_NORM_FOLD off: same kernels' arithmetic up to the order of one multiplication); and that the folded call left the
+    BatchNorm partial rows of ITS output for the next norm.  The transform is compiled into the 4x4 / stride-2 instantiations (every
+    normalise -> convolution pair of the crop, layout and global encoders): maps of 64 down to 8 pixels, an odd size (33), all three
+    norm kinds; the 3x3 / 5x5 stride-1 cases take F.norm_conv2d's two-pass fallback and must give the same numbers."""
+    from agl import functional as F
+    from agl import lib as L
+    from agl import nn as A
+    from agl.generator import ConditionalBatchNorm2d
+    kind, N, Cin, H, Cout, ks, stride, pad, relu = case
+    tol_y, tol_g = (2e-5, 2e-4) if mode == "split3" else (2e-2, 4e-2)
+    torch.manual_seed(3)
+    if kind == 2:
+        norm = ConditionalBatchNorm2d(Cin, 7)
+        norm.embed.weight.data[:, Cin:] = 0.3 * torch.randn(7, Cin)
+    else:
+        norm = A.BatchNorm2d(Cin, affine=kind == 1)
+        if kind == 1:
+            norm.weight.data = 1.0 + 0.3 * torch.randn(Cin)
+            norm.bias.data = 0.2 * torch.randn(Cin)
+    conv = A.Conv2d(Cin, Cout, kernel_size=ks, stride=stride, padding=pad, bias=kind != 2)
+    labels = torch.randint(0, 7, (N,))
+    x = rn(N, Cin, H, H) * 1.7 + 0.4
+    OH = (H + 2 * pad - ks) // stride + 1
+    gy = rn(N, Cout, OH, OH, seed=5)
+    # torch reference on the CPU
+    xr = x.clone().requires_grad_(True)
+    bnr = torch.nn.BatchNorm2d(Cin, affine=False)
+    xh = bnr(xr)
+    if kind == 2:
+        tab = norm.embed.weight.detach().clone().requires_grad_(True)
+        gb = tab[labels]
+        h = gb[:, :Cin].view(N, Cin, 1, 1) * xh + gb[:, Cin:].view(N, Cin, 1, 1)
+        pr = [tab]
+    elif kind == 1:
+        gw, gbias = norm.weight.detach().clone().requires_grad_(True), norm.bias.detach().clone().requires_grad_(True)
+        h = xh * gw.view(1, -1, 1, 1) + gbias.view(1, -1, 1, 1)
+        pr = [gw, gbias]
+    else:
+        h, pr = xh, []
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True) if conv.bias is not None else None
+    yr = TF.conv2d(torch.relu(h) if relu else h, wr, br, stride, pad)
+    yr.backward(gy)
+    flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
+    res = {}
+    for folded in (True, False):
+        nd, cd = __import__("copy").deepcopy(norm).to(DEV), __import__("copy").deepcopy(conv).to(DEV)
+        xd = dev(x).requires_grad_(True)
+        prev, F.NORM_FOLD = F.NORM_FOLD, folded
+        prev_e, F.EMIT_STATS = F.EMIT_STATS, True
+        try:
+            with L.conv_flags(flags):
+                if folded:      # (the transform is compiled into the 4x4 / stride-2 family: the other cases pin the two-pass fallback)
+                    assert L.conv_fold_ok(N, Cin, H, H, Cout, ks, stride, pad) == (ks == 4 and stride == 2), "4x4 / stride 2 must fold"
+                y = F.norm_conv2d(xd, nd, dev(labels) if kind == 2 else None, cd, relu=relu, training=True)
+                stats = F._LAST_STATS
+                y.backward(dev(gy))
+        finally:
+            F.NORM_FOLD, F.EMIT_STATS = prev, prev_e
+        torch.cuda.synchronize()
+        bn = getattr(nd, "bn", nd)
+        params = [nd.embed.weight.grad] if kind == 2 else ([nd.weight.grad, nd.bias.grad] if kind == 1 else [])
+        res[folded] = (y.detach(), xd.grad, params, cd.weight.grad, cd.bias.grad if cd.bias is not None else None, bn.running_mean.clone(),
+                       bn.running_var.clone(), int(bn.num_batches_tracked), stats)
+    for folded, tag in ((True, "folded"), (False, "two passes")):
+        y, dx, params, dw, db, rm, rv, nbt, stats = res[folded]
+        close(y, yr, tol_y, f"{tag}: y")
+        close(dx, xr.grad, tol_g, f"{tag}: dx")
+        for a, r in zip(params, pr):
+            close(a, r.grad, tol_g, f"{tag}: norm parameter gradient")
+        close(dw, wr.grad, tol_g, f"{tag}: dw")
+        if db is not None:
+            close(db, br.grad, tol_g, f"{tag}: db")
+        close(rm, bnr.running_mean, 1e-5, f"{tag}: running mean")
+        close(rv, bnr.running_var, 1e-5, f"{tag}: running var")
+        assert nbt == 1
+    close(res[True][0], res[False][0], 1e-5 if mode == "split3" else 1e-2, "folded vs two passes: y")
+    close(res[True][1], res[False][1], 1e-4 if mode == "split3" else 2e-2, "folded vs two passes: dx")
+    # the folded call leaves the partial rows of its own output (the next norm's statistics without a read of y)
+    y, stats = res[True][0], res[True][8]
+    if stats is not None:
+        m1, r1 = L.bn_stats_from_partials(stats[2], stats[3], Cout, y.numel() // Cout, 1e-5, 0.1)
+        m2, r2 = L.bn_stats(y, 1e-5, 0.1)
+        close(m1, m2, 2e-6, "partials of the folded call: mean"); close(r1, r2, 2e-5, "partials of the folded call: rstd")
+
+
+@pytest.mark.parametrize("consumer", ["convT", "conv5", "conv3"])
+def test_spade_output_stored_as_bf16_gives_identical_results(consumer):
+    """VERDICT r3 item 1: in bf16 arithmetic the SPADE-modulated tensor feeds ONE layer (a ConvTranspose2d(4,2,1) or a convolution);
+    as one graph node (F.spade_modulate_then) it is stored as bf16 between them.  Its readers — the consumer's forward (dy role of the
+    phase kernel / x role of the patch kernel), the consumer's weight gradient, the ReLU mask of the modulation's backward — round it
+    to bf16 when staging it anyway, so everything must be BIT-IDENTICAL to the fp32-stored form: output, input gradient, gradient
+    of the segmentation map, every parameter gradient, running statistics."""
+    import copy
+    from agl import functional as F
+    from agl import lib as L
+    from agl import nn as A
+    from agl.generator import SPADE
+    torch.manual_seed(5)
+    N, Cc, S = 6, 64, {"convT": 32, "conv5": 64, "conv3": 16}[consumer]      # (segmentation map 8x8: block-class grids with / without the folded gather, plain form)
+    sp = SPADE(Cc, 64)
+    layer = (A.ConvTranspose2d(Cc, 48, kernel_size=4, stride=2, padding=1, bias=False) if consumer == "convT" else
+             A.Conv2d(Cc, 64, kernel_size=5, padding=2, bias=False) if consumer == "conv5" else A.Conv2d(Cc, 128, kernel_size=3, padding=1))
+    x, seg = rn(N, Cc, S, S) * 1.3 + 0.2, rn(N, 64, 8, 8, seed=2)
+    res = []
+    for y16 in (True, False):
+        spd, ld = copy.deepcopy(sp).to(DEV), copy.deepcopy(layer).to(DEV)
+        xd, sd = dev(x).requires_grad_(True), dev(seg).requires_grad_(True)
+        prev, F.SPADE_Y16 = F.SPADE_Y16, y16
+        try:
+            with L.conv_flags(L.CONV_BF16 | L.CONV_ANY_GRID):
+                if y16:
+                    kind = "convT" if consumer == "convT" else "conv"
+                    co = ld.weight.shape[1] if kind == "convT" else ld.weight.shape[0]
+                    assert L.norm_output_as_bf16(N, Cc, S, S, kind, co, ld.kernel_size[0], 1, ld.padding[0]), "case must take the bf16 form"
+                out = spd(xd, sd, relu=True, then=ld)
+                out.backward(dev(rn(*out.shape, seed=7)))
+        finally:
+            F.SPADE_Y16 = prev
+        torch.cuda.synchronize()
+        res.append([out.detach(), xd.grad, sd.grad, ld.weight.grad] + [q.grad for q in spd.parameters()] +
+                   ([ld.bias.grad] if getattr(ld, "bias", None) is not None else []) + [spd.param_free_norm.running_mean, spd.param_free_norm.running_var])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (consumer, i, float((a - b).abs().max()))
+    # and the pair equals torch within the bf16 bars
+    xr = x.clone().requires_grad_(True)
+    spc, lc = copy.deepcopy(sp), copy.deepcopy(layer)
+    bn = torch.nn.BatchNorm2d(Cc, affine=False)
+    segu = TF.interpolate(seg, size=(S, S), mode="nearest")
+    actv = torch.relu(TF.conv2d(segu, spc.mlp_shared[0].weight, spc.mlp_shared[0].bias, padding=1))
+    gam = TF.conv2d(actv, spc.mlp_gamma.weight, spc.mlp_gamma.bias, padding=1)
+    bet = TF.conv2d(actv, spc.mlp_beta.weight, spc.mlp_beta.bias, padding=1)
+    h = torch.relu(bn(xr) * (1 + gam) + bet)
+    ref = TF.conv_transpose2d(h, lc.weight, None, 2, 1) if consumer == "convT" else TF.conv2d(h, lc.weight, lc.bias, 1, lc.padding[0])
+    close(res[0][0], ref, 3e-2, "SPADE + consumer vs torch (bf16 arithmetic)")
+
+
 def test_modules_vs_reference_op_fixtures(golden_dir):
     """The ConditionalBatchNorm2d / SPADE / spectrally-normalised discriminator-block vectors of tests/golden/ops_small.npz
     (outputs, input and parameter gradients, running statistics after 1 and 3 calls, spectral-norm u/v after k forwards —
@@ -832,22 +981,29 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
-@pytest.mark.parametrize("case", [(5, 32, 32, 64, 3, 1, 1), (9, 64, 8, 128, 3, 1, 1), (17, 32, 4, 64, 3, 1, 1), (3, 16, 24, 48, 5, 1, 2),
-                                  (6, 32, 16, 80, 1, 1, 0), (4, 64, 32, 128, 4, 2, 1), (3, 32, 17, 64, 3, 2, 0), (2, 48, 64, 200, 3, 1, 1)])
+@pytest.mark.parametrize("case", [(5, 32, 64, 64, 4, 2, 1), (9, 64, 16, 128, 4, 2, 1), (17, 32, 8, 64, 4, 2, 1), (3, 16, 24, 48, 5, 1, 2),
+                                  (37, 32, 4, 80, 4, 2, 1), (4, 64, 32, 128, 4, 2, 1), (3, 32, 33, 64, 4, 2, 1), (2, 48, 64, 200, 5, 1, 2),
+                                  (6, 32, 16, 64, 3, 1, 1)])
 def test_conv_emits_batchnorm_partials(case, mode):
-    """agl_conv2d_fwd_stats: the matrix-core convolution leaves per-channel (sum, sum of squares) rows of the output it stores;
+    """agl_conv2d_fwd_stats: the matrix-core convolution leaves per-channel (count, mean, M2) rows of the output it stores;
     agl_bn_stats_from_partials must then agree with agl_bn_stats run on that output (mean, rstd, running statistics, counter),
-    and the output itself must equal the plain forward."""
+    and the output itself must equal the plain forward.  The rows are compiled into the instantiations whose layers are followed by
+    a BatchNorm on the path — the 4x4 / stride-2 family (every tile geometry: 32 / 8 / 4 / 2-pixel output maps, an odd input) and the
+    bf16 5x5 forms; elsewhere (the 3x3 case, 5x5 in split mode) the call reports no rows and the caller uses agl_bn_stats."""
     from agl import lib as L
     N, Cin, H, Cout, ks, stride, pad = case
+    has_rows = (ks == 4 and stride == 2) or (ks == 5 and mode == "bf16")
     x, w, b = rn(N, Cin, H, H), rn(Cout, Cin, ks, ks, seed=1) * (1.0 / (Cin * ks * ks) ** 0.5), rn(Cout, seed=2) * 3.0
     flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3) | L.CONV_ANY_GRID
     xd, wd, bd = dev(x), dev(w), dev(b)
     with L.conv_flags(flags):
         y0 = L.conv2d_fwd(xd, wd, bd, stride, pad, in_relu=True)
         y, part, rows = L.conv2d_fwd_stats(xd, wd, bd, stride, pad, in_relu=True)
-    assert part is not None and rows > 0, "the matrix-core kernel did not take this shape"
     assert torch.equal(y, y0)
+    if not has_rows:
+        assert part is None and rows == 0
+        return
+    assert part is not None and rows > 0, "the matrix-core kernel did not take this shape"
     C_, cnt = y.shape[1], y.numel() // y.shape[1]
     rm = [dev(rn(C_, seed=4)).clone() for _ in range(2)]
     rv = [dev(rn(C_, seed=5).abs() + 0.5).clone() for _ in range(2)]
@@ -1175,12 +1331,12 @@ def test_conv_batchnorm_partials_with_a_large_channel_offset():
     or 1000 on unit-variance outputs the fused statistics agree with agl_bn_stats (double accumulation over the stored tensor) to
     1e-4 in rstd and 1e-6 of the mean; the same at mean/std = 3."""
     from agl import lib as L
-    N, Cin, H, Cout = 8, 32, 16, 64
-    x, w = rn(N, Cin, H, H), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5)
+    N, Cin, H, Cout = 8, 32, 32, 64
+    x, w = rn(N, Cin, H, H), rn(Cout, Cin, 4, 4, seed=1) * (1.0 / (Cin * 16) ** 0.5)
     for offset, tol_rstd in ((1000.0, 1e-4), (100.0, 1e-4), (3.0, 1e-4)):
         b = torch.full((Cout,), offset)
         with L.conv_flags(L.CONV_SPLIT3 | L.CONV_ANY_GRID):
-            y, part, rows = L.conv2d_fwd_stats(dev(x), dev(w), dev(b), 1, 1)
+            y, part, rows = L.conv2d_fwd_stats(dev(x), dev(w), dev(b), 2, 1)
         assert part is not None and rows > 0
         cnt = y.numel() // Cout
         m1, r1 = L.bn_stats_from_partials(part, rows, Cout, cnt, 1e-5, 0.1)

@@ -70,12 +70,21 @@ def main():
             if any(x in k for x in fam):
                 tot_b += (2 * fb + wb) * n
                 tot_n += n
+        conv_fam = ("pconv_k", "pbww_k", "igemm_f32", "patch_conv", "small_cout_conv", "few_bww_k", "few_cin_fwd_k", "splitk_epilogue",
+                    "slab_reduce", "pack_weights_k", "pack_vert_k", "vert_diag_sum_k", "phase_edge_k", "linear_bww_k", "linear_bwd_data_k",
+                    "tap_major_to_w_k", "flip_transpose_w", "transpose_in")
+        conv_b = conv_n = 0.0
+        for secs, k, n, us, fb, wb, raw, cor in rows:
+            if any(x in k for x in conv_fam):
+                conv_b += (2 * fb + wb) * n
+                conv_n += n
         data = {}
         if os.path.exists(out_json):
             data = json.load(open(out_json))
         # bench.py's HBM roofline object counts one "launch" per C-ABI call of the family (a call issues 2-3 kernels), so the
         # figure it needs is the family's HBM bytes per training iteration; it divides by its own calls-per-iteration count
         data[tag] = {"bytes_per_iteration": round(tot_b / iters), "kernel_launches_per_iteration": round(tot_n / iters),
+                     "conv_bytes_per_iteration": round(conv_b / iters), "conv_kernel_launches_per_iteration": round(conv_n / iters),
                      "source": os.path.relpath(out_csv, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
                      "note": "FETCH_SIZE x2 (16-byte reads) + WRITE_SIZE, KiB -> bytes, summed over the normalisation-family kernels"}
         json.dump(data, open(out_json, "w"), indent=1)
