@@ -15,6 +15,9 @@ from . import functional as F
 from . import nn as A
 from .convlstm import SequencePlan, layout_conv_lstm
 
+import os
+FRONT_STREAMS = os.environ.get("AGL_FRONT_STREAMS", "1") != "0"      # A/B switch: the rand / shift layout-encoder fronts on their branch streams
+
 
 def get_z_random(batch_size, z_dim, random_type="gauss"):
     """Reference helper (generator_obj_att.py:10-15): drawn on the CPU generator, like the reference."""
@@ -184,7 +187,7 @@ class LayoutEncoder(nn.Module):
         h = self.clstm(h, obj_to_img, plan=plan)
         return self.residual(h)
 
-    def forward_many(self, calls, obj_to_img, objs, residual=True):
+    def forward_many(self, calls, obj_to_img, objs, residual=True, branch=None):
         """Several forward calls [(objs_att, masks, z), ...] on the same object list, results identical to calling
         forward() once per entry in order: the stages that carry batch statistics (CondBN before the ConvLSTM, BN in
         the residual blocks) run per call in call order, so every normalisation layer sees the same sequence of
@@ -192,7 +195,38 @@ class LayoutEncoder(nn.Module):
         (k times the images per recurrence step: k times fewer launches, fuller grids, one backward).
         residual=False: stop before the residual blocks (the caller runs them per branch, possibly on separate streams)."""
         k = len(calls)
-        fronts = [self.front(a, m, z, objs) for (a, m, z) in calls]
+        if branch is None:
+            fronts = [self.front(a, m, z, objs) for (a, m, z) in calls]
+        else:
+            # branch = (streams, private gradient arenas, deferred-update lists), one entry per call: the fronts are independent chains
+            # of large-but-not-chip-filling kernels (per-object 4x4 / stride-2 convolutions and their ConditionalBatchNorms) and so are
+            # their backward passes — the tail of the G step's backward, where nothing else runs.  Each front on its branch's stream,
+            # with the branch's private gradient arena (the fronts share every parameter) and its BatchNorm updates deferred (applied
+            # by the caller in call order, as in the sequential schedule).
+            streams, arenas, deferred = branch
+            main = torch.cuda.current_stream()
+            # (the first stage updates bn1's running statistics inside its kernel: in call order on the caller's stream, private slots)
+            stage1 = []
+            for (a, m, z), ar in zip(calls, arenas):
+                prev_a, F.GRAD_ARENA = F.GRAD_ARENA, ar
+                try:
+                    stage1.append(self.front_a(a, m, z, objs))
+                finally:
+                    F.GRAD_ARENA = prev_a
+            fronts = []
+            for h1, st, ar, lst in zip(stage1, streams, arenas, deferred):
+                st.wait_stream(main)
+                prev, prev_a = F.BN_DEFER, F.GRAD_ARENA
+                F.BN_DEFER, F.GRAD_ARENA = lst, ar
+                try:
+                    with torch.cuda.stream(st):
+                        fronts.append(self.front_b(h1, objs))
+                finally:
+                    F.BN_DEFER, F.GRAD_ARENA = prev, prev_a
+                F.L.used_on(st, h1)
+            for st, f in zip(streams, fronts):
+                main.wait_stream(st)
+                F.L.used_on(main, f)
         ids = obj_to_img.detach().cpu()
         n_img = int(ids.max()) + 1
         # image ids must stay one run per image: offset every copy past the previous one's last id
@@ -202,6 +236,10 @@ class LayoutEncoder(nn.Module):
         return list(hs) if not residual else [self.residual(hh) for hh in hs]
 
     def front(self, objs_att, masks, z, objs):
+        return self.front_b(self.front_a(objs_att, masks, z, objs), objs)
+
+    def front_a(self, objs_att, masks, z, objs):
+        """c0 on the rank-1 input, bn1 + ReLU + c2 (closed form where the map allows): updates bn1's running statistics in place."""
         v = F.concat_channels(objs_att, z)
         assert self.c0.kernel_size == (1, 1) and self.c0.padding == (1, 1)
         u = F.linear(v, self.c0.weight.view(self.c0.out_channels, -1))   # c0 on the rank-1 tensor v (x) mask
@@ -211,6 +249,10 @@ class LayoutEncoder(nn.Module):
                                 bn.num_batches_tracked, self.training)
         else:
             h = self.c2(self.bn1(F.mask_outer(u, masks, 1), objs, relu=True))
+        return h
+
+    def front_b(self, h, objs):
+        """bn2 .. bn4 (+ the 128 px model's pool): every statistics call honours F.BN_DEFER."""
         h = F.norm_conv2d(h, self.bn2, objs, self.c3, relu=True, training=self.training)      # bn2 + ReLU folded into c3's staging pass
         h = F.norm_conv2d(h, self.bn3, objs, self.c4, relu=True, training=self.training)      # bn3 + ReLU into c4's
         h = self.bn4(h, objs)
@@ -466,13 +508,15 @@ class Generator(nn.Module):
             # residual blocks — and partial last rounds overlap), and so does their backward, which autograd runs on the forward's
             # streams.  The BatchNorm layers they share update their running statistics afterwards, rand first, then shift —
             # the order of the sequential schedule (F.BN_DEFER).
-            hs = self.layout_encoder.forward_many(calls, o2i, objs, residual=False)
-            main = torch.cuda.current_stream()
-            deferred = []
             arenas = self.__dict__.get("branch_grad_arenas") or [None, None]      # private gradient slots per branch (F.GRAD_ARENA)
+            deferred = [[], []]
+            fronts_on_streams = FRONT_STREAMS and arenas[0] is not None
+            hs = self.layout_encoder.forward_many(calls, o2i, objs, residual=False,
+                                                  branch=(streams[:2], arenas[:2], deferred) if fronts_on_streams else None)
+            main = torch.cuda.current_stream()
             for k, (st, h0, tag, boxes) in enumerate(((streams[0], hs[0], "rand", sh["boxes"]), (streams[1], hs[1], "shift", sh["boxes_shift"]))):
                 st.wait_stream(main)
-                lst, prev, prev_a = [], F.BN_DEFER, F.GRAD_ARENA
+                lst, prev, prev_a = deferred[k], F.BN_DEFER, F.GRAD_ARENA
                 F.BN_DEFER, F.GRAD_ARENA = lst, arenas[k]
                 try:
                     with torch.cuda.stream(st):
@@ -483,7 +527,6 @@ class Generator(nn.Module):
                 finally:
                     F.BN_DEFER, F.GRAD_ARENA = prev, prev_a
                 sh["img_" + tag], sh["crops_" + tag], sh["mu_" + tag], sh["lv_" + tag] = img, crops, mu, lv
-                deferred.append(lst)
             for st in streams[:2]:
                 main.wait_stream(st)
             for tag in ("rand", "shift"):      # produced on the branch streams, read on the caller's (and the discriminators') from here on

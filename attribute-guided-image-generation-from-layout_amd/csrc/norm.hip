@@ -213,7 +213,7 @@ struct NormArgs {
   // W-wide map reads cell (map[iy], map[ix]) — the expansion agl_grid_gather_fwd would write out is folded into the reads
   const int* map; int W, src_w;
   // backward of a FOLDED forward (agl_norm_fold_table + agl_conv2d_fwd_fold: the normalised tensor y was never stored): the ReLU mask
-  // is recomputed from x with the very expression the consumer's staging pass evaluated, fmaf(x - mean, fscale[r], fshift[r]) > 0
+  // is recomputed from x with the very expression the consumer's staging pass evaluated, fmaf(x, fscale[r], fshift[r]) > 0
   const float* fscale; const float* fshift; int f_per_n;
   int y_bf16;      // the forward output y holds bf16 elements (written by agl_norm_apply_fwd_y16 for consumers that are bf16-mode convolutions)
 };
@@ -223,7 +223,7 @@ __device__ __forceinline__ float bf16_at(const float* y, long idx) {      // ele
   return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(y)[idx] << 16);
 }
 __device__ __forceinline__ bool relu_dead(const NormArgs& a, const float* __restrict__ y, long idx, float x, float mu, float fs, float fh) {
-  if (!y) return !(fmaf(x - mu, fs, fh) > 0.f);
+  if (!y) return !(fmaf(x, fs, fh) > 0.f);
   return a.y_bf16 ? !(bf16_at(y, idx) > 0.f) : !(y[idx] > 0.f);
 }
 // four consecutive elements of y starting at element 4*i of the row at `base` (fp32 or bf16 storage)
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* _
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x - mu, fs, fh), fmaf(xv.y - mu, fs, fh), fmaf(xv.z - mu, fs, fh), fmaf(xv.w - mu, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)};
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -650,15 +650,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
 
 int pick_lpr(int HW) { return HW <= 4 ? 4 : (HW <= 16 ? 16 : (HW <= 512 ? 64 : 256)); }
 
-// Tables of the folded normalise-modulate (agl_norm_fold_table): scale[r][c] = rstd[c] * gamma(r, c), shift[r][c] = beta(r, c)
+// Tables of the folded normalise-modulate (agl_norm_fold_table): scale[r][c] = rstd[c] * gamma(r, c), shift[r][c] = beta(r, c) - mean[c] * scale[r][c]
 __global__ void norm_fold_table_k(NormArgs a, int rows, float* __restrict__ scale, float* __restrict__ shift) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * a.C) return;
   const int n = i / a.C, c = i - n * a.C;
   float g, b;
   row_affine(a, n, c, g, b);
-  scale[i] = a.rstd[c] * g;
-  shift[i] = b;
+  const double sc = (double)a.rstd[c] * (double)g;
+  scale[i] = (float)sc;
+  shift[i] = (float)((double)b - (double)a.mean[c] * sc);      // v = fma(x, scale, shift): ONE operation per staged element
 }
 
 }  // namespace

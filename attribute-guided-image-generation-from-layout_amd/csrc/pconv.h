@@ -4,8 +4,9 @@
 
 // Input transform applied while an operand is staged: the normalise-modulate of the BatchNorm2d / ConditionalBatchNorm2d that reads the
 // tensor (generator_obj_att.py:31-44, :433, :583) folded into the convolution that consumes its output —
-//   v = (x - mean[c]) * scale[r * C + c] + shift[r * C + c],  r = image index when per_n, else 0   (then the fused input ReLU)
-// with scale = rstd * gamma, shift = beta (agl_norm_fold_table).  Zero padding is applied AFTER the transform (padding stays 0).
+//   v = fma(x, scale[r * C + c], shift[r * C + c]),  r = image index when per_n, else 0   (then the fused input ReLU)
+// with scale = rstd * gamma, shift = beta - mean * rstd * gamma formed in double (agl_norm_fold_table).  Zero padding is applied AFTER
+// the transform (padding stays 0).  (`mean` is kept for the ABI's symmetry with the statistics; the kernels read scale / shift only.)
 struct InFold { const float* mean; const float* scale; const float* shift; int per_n; };
 
 struct PConvArgs {

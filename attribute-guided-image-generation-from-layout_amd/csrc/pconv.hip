@@ -289,12 +289,11 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
       if constexpr (F_FOLD) {
         if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {              // (four channels at a time: twelve table values live, not twenty-four)
-            const float4 m = reinterpret_cast<const float4*>(p.fold.mean + c_staged + (faff[r] & 8))[q];
+          for (int q = 0; q < 2; ++q) {              // (four channels at a time; one fused multiply-add per element)
             const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
             const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
-            pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0] - m.x, sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1] - m.y, sc.y, sh.y);
-            pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2] - m.z, sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3] - m.w, sc.w, sh.w);
+            pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0], sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1], sc.y, sh.y);
+            pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2], sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3], sc.w, sh.w);
           }
         }
       }
@@ -947,11 +946,10 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
           const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
 #pragma unroll
           for (int hq = 0; hq < 2; ++hq) {
-            const float4 m = reinterpret_cast<const float4*>(p.fold.mean + ch)[hq];
             const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
             const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
-            px[sl][4 * hq + 0] = fmaf(px[sl][4 * hq + 0] - m.x, sc.x, sh.x); px[sl][4 * hq + 1] = fmaf(px[sl][4 * hq + 1] - m.y, sc.y, sh.y);
-            px[sl][4 * hq + 2] = fmaf(px[sl][4 * hq + 2] - m.z, sc.z, sh.z); px[sl][4 * hq + 3] = fmaf(px[sl][4 * hq + 3] - m.w, sc.w, sh.w);
+            px[sl][4 * hq + 0] = fmaf(px[sl][4 * hq + 0], sc.x, sh.x); px[sl][4 * hq + 1] = fmaf(px[sl][4 * hq + 1], sc.y, sh.y);
+            px[sl][4 * hq + 2] = fmaf(px[sl][4 * hq + 2], sc.z, sh.z); px[sl][4 * hq + 3] = fmaf(px[sl][4 * hq + 3], sc.w, sh.w);
           }
         }
       }

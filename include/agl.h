@@ -122,8 +122,8 @@ int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, 
 /* ---- normalise-modulate folded into the consuming convolution (BASELINE north_star; SURVEY a2 "apply+ReLU into next conv prologue").
  * conv(relu(CondBN(x))) — generator_obj_att.py:395-416 (CropEncoder), :494-504 (LayoutEncoder), :437-446 (GlobalEncoder) — without
  * ever storing the normalised tensor: agl_norm_fold_table turns (mean, rstd, affine / class-table parameters) into per-(row, channel)
- * tables scale = rstd * gamma, shift = beta (row = object for ConditionalBatchNorm2d, one row otherwise); agl_conv2d_fwd_fold applies
- * v = (x - mean[c]) * scale[r][c] + shift[r][c] (then the ReLU, then the zero padding) while it stages its input patch — forms of
+ * tables scale = rstd * gamma, shift = beta - mean * scale (row = object for ConditionalBatchNorm2d, one row otherwise); agl_conv2d_fwd_fold
+ * applies v = fma(x, scale[r][c], shift[r][c]) (then the ReLU, then the zero padding) while it stages its input patch — forms of
  * the matrix-core patch kernel (agl_conv2d_fwd_fold_ok), optionally leaving the BatchNorm partial rows of its own output like
  * agl_conv2d_fwd_stats; agl_conv2d_bwd_weight_fold applies the same transform to the raw x in the weight gradient; agl_norm_bwd_fold
  * is agl_norm_bwd for a y that does not exist: the ReLU mask is recomputed from x with the staging pass's expression. */
