@@ -17,6 +17,10 @@ from .convlstm import SequencePlan, layout_conv_lstm
 
 import os
 FRONT_STREAMS = os.environ.get("AGL_FRONT_STREAMS", "1") != "0"      # A/B switch: the rand / shift layout-encoder fronts on their branch streams
+# opt-in: the reconstruction branch's front + ConvLSTM on the third branch stream, so that its backward recurrence overlaps the batched
+# rand / shift one.  Measured on one box, alternating (profiles/r04_ab_switches.txt): 466 / 472 images/s with it against 483 / 483 without
+# at 64 px — two compute-bound recurrences beside each other run slower than one after the other — so the default keeps it off.
+REC_CLSTM_STREAM = os.environ.get("AGL_REC_CLSTM_STREAM", "0") == "1"
 
 
 def get_z_random(batch_size, z_dim, random_type="gauss"):
@@ -462,7 +466,26 @@ class Generator(nn.Module):
     @_with_conv_stats.__func__
     def part_rec(self, sh, eps0):
         z_rec = self.crop_encoder.sample(sh["mu"], sh["logvar"], eps0)
-        h_rec = self.layout_encoder(sh["objs_att_est"], sh["masks"], sh["obj_to_img"], z_rec, sh["objs"], sh["plan"])
+        streams, arenas = self.__dict__.get("branch_streams"), self.__dict__.get("branch_grad_arenas")
+        if REC_CLSTM_STREAM and streams is not None and len(streams) >= 3 and arenas is not None and torch.is_grad_enabled() and self.training:
+            # The reconstruction branch's layout-encoder front and ConvLSTM on the third branch stream (private gradient arena): the
+            # forward order is unchanged (the caller's stream waits for the result), but autograd runs their BACKWARD on that stream —
+            # the recurrence's chain of small per-step kernels then overlaps the batched rand / shift recurrence's chain instead of
+            # queueing behind it in the tail of the G step's backward, where nothing else runs.
+            main, g2 = torch.cuda.current_stream(), streams[2]
+            g2.wait_stream(main)
+            prev_a, F.GRAD_ARENA = F.GRAD_ARENA, arenas[2]
+            try:
+                with torch.cuda.stream(g2):
+                    le = self.layout_encoder
+                    h0 = le.clstm(le.front(sh["objs_att_est"], sh["masks"], z_rec, sh["objs"]), sh["obj_to_img"], plan=sh["plan"])
+            finally:
+                F.GRAD_ARENA = prev_a
+            main.wait_stream(g2)
+            F.L.used_on(main, h0)
+            h_rec = self.layout_encoder.residual(h0)
+        else:
+            h_rec = self.layout_encoder(sh["objs_att_est"], sh["masks"], sh["obj_to_img"], z_rec, sh["objs"], sh["plan"])
         img_rec = self.decoder(h_rec, self.global_encoder(h_rec))
         crops_input_rec = F.crop_boxes(img_rec, sh["boxes"], sh["o2i_dev"], self.obj_size)
         return img_rec, crops_input_rec
