@@ -24,8 +24,8 @@ class GradSync:
         return 1.0 / self.world
 
     def side_stream(self, device):
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=device)
+        if self._stream is None:      # high priority: the exchange + Adam sit on the step's critical path, the chains beside them do not
+            self._stream = torch.cuda.Stream(device=device, priority=-1)
         return self._stream
 
     def all_reduce_(self, flat: torch.Tensor):

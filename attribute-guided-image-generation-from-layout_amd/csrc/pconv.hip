@@ -138,7 +138,7 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // loads leaves the matrix pipe to three others instead of one.
 // ABL (diagnostic builds only, results are wrong), a bit mask: 1 no MFMAs, 2 no operand conversion (one rounding, the other planes
 // are copies), 4 no LDS fragment reads inside the tap loop (tap 0's fragments for every tap), 8 no global loads after the first
-// stage, 16 no LDS stores after the first stage
+// stage, 16 no LDS stores after the first stage, 32 no output stores (plain epilogue)
 // VERT: a KS x 1 window (vertical taps only, no horizontal padding): the first half of the few-channel 7x7 layers (pconv_vert_try)
 // FEAT (bit mask): features compiled into an instantiation — every one costs registers in ALL its launches (82 of 224 kernels lost a
 // workgroup per CU when they were runtime switches), so only the shapes that use them are instantiated with them:
@@ -632,7 +632,8 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             }
           }
           if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-          if (F_YOUT && p.y_bf16) {      // four bf16 (round to nearest even) in one 8-byte store
+          if constexpr ((ABL & 32) != 0) { asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); }      // (diagnostic: no output store)
+          else if (F_YOUT && p.y_bf16) {      // four bf16 (round to nearest even) in one 8-byte store
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             const bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
             *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + pbase + (long)m * OHW) = __builtin_bit_cast(uint2, ob);
@@ -734,15 +735,16 @@ __global__ __launch_bounds__(128) void phase_edge_k(const float* __restrict__ dy
   const float sc = out_div ? 1.0f / *out_div : 1.0f;
   const int cnt = col ? OW - 1 : OW;            // (the corner belongs to the row pass)
 #pragma unroll
-  for (int i = 0; i < OW; ++i) {
-    if (i >= cnt) break;
-    const int Y = col ? i : OW - 1, X = col ? OW - 1 : i;
-    const long o = (((long)n * M + m) * OW + Y) * OW + X;
-    float v = acc[i] * sc;
-    if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
-    if (accumulate) v += dx[o];
-    if (relu) v = fmaxf(v, 0.f);
-    dx[o] = v;
+  for (int i = 0; i < OW; ++i) {      // (no early exit: the loop must unroll completely, or acc[] is indexed at run time and lives in scratch)
+    if (i < cnt) {
+      const int Y = col ? i : OW - 1, X = col ? OW - 1 : i;
+      const long o = (((long)n * M + m) * OW + Y) * OW + X;
+      float v = acc[i] * sc;
+      if (pos_mask && !(pos_mask[o] > 0.f)) v = 0.f;
+      if (accumulate) v += dx[o];
+      if (relu) v = fmaxf(v, 0.f);
+      dx[o] = v;
+    }
   }
 }
 
@@ -1285,6 +1287,13 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       case 1: PC_ABL(1); break; case 2: PC_ABL(2); break; case 4: PC_ABL(4); break; case 8: PC_ABL(8); break;
       case 14: PC_ABL(14); break; case 30: PC_ABL(30); break; case 31: PC_ABL(31); break; case 16: PC_ABL(16); break;
       default: PC_ABL(6); break;
+    }
+#undef PC_ABL
+  } else if (a.ablate > 0 && a.ks == 3 && a.nsplit == 1 && geo == 0 && w32 && bm == 64 && !featy && !featsc) {      // the same for the bf16 form
+#define PC_ABL(A_) hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 1, 9, false, false, 256, A_>), g, dim3(256), 0, st, p)
+    switch (a.ablate) {      // (the flag field holds 5 bits: code 2 stands for bit 32, "no output store")
+      case 1: PC_ABL(1); break; case 8: PC_ABL(8); break; case 24: PC_ABL(24); break; case 2: PC_ABL(32); break;
+      case 3: PC_ABL(33); break; default: PC_ABL(57); break;
     }
 #undef PC_ABL
   } else if (w8 && a.ks == 3) {

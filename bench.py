@@ -387,7 +387,15 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL's own stream at high priority: its kernels then do not queue behind the compute chains of the step's other streams
+            # (the arena exchange sits between the D step's backward and the G step's discriminator passes: its latency is exposed)
+            kw = {}
+            try:
+                from torch.distributed import ProcessGroupNCCL
+                kw["pg_options"] = ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                kw = {}
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 

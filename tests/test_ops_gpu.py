@@ -1286,6 +1286,32 @@ def test_pconv_stride2_input_gradient_odd_sized_input(case, mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
+def test_odd_sized_input_gradient_on_concurrent_streams(mode):
+    """The training step runs the three generator branches' layout encoders on three streams, so three of these launches (paired-phase
+    kernel + phase_edge_k, sharing one cached weight pack) overlap on the chip.  A build of phase_edge_k that read its taps from a
+    pre-packed edge table gave different edge rows under this overlap (and only then: alone it matched torch), so the overlap itself is
+    tested: 20 rounds of three concurrent calls must reproduce, bit for bit, what each call gives alone."""
+    from agl import lib as L
+    flags = (L.CONV_BF16 if mode == "bf16" else L.CONV_SPLIT3)
+    w = torch.nn.Parameter(dev(rn(256, 128, 4, 4, seed=1) * 0.05))
+    ws = L.WeightSrc(w, lambda: 0)
+    dys = [dev(rn(n, 256, 16, 16, seed=3 + i)) for i, n in enumerate((33, 66, 33))]
+    with L.conv_flags(flags):
+        ref = [L.conv2d_bwd_data(d, w, (33, 33), 2, 1, wsrc=ws) for d in dys]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in dys]
+        for it in range(20):
+            outs = []
+            for d, st in zip(dys, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    outs.append(L.conv2d_bwd_data(d, w, (33, 33), 2, 1, wsrc=ws))
+            torch.cuda.synchronize()
+            for k, (o, r) in enumerate(zip(outs, ref)):
+                assert torch.equal(o, r), (it, k, float((o - r).abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split3"])
 @pytest.mark.parametrize("case", [(3, 64, 32, 32, 3), (2, 128, 64, 64, 3), (5, 48, 16, 32, 1), (2, 32, 8, 64, 4)])
 def test_few_channel_7x7_as_vertical_conv_plus_diagonal_sum(case, mode):
     """Decoder c4 / c7 (64|128 -> 3, 7x7, generator_obj_att.py:544, generator_obj_att128.py:557) and the input gradients of the
