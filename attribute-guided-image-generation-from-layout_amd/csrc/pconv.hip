@@ -1620,8 +1620,13 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
-  *rt = (a.nsplit == 1 && a.ks != 5 && a.Cout > 64) ? 2 : 1;
-  *ct = ((a.nsplit == 1 && a.ks == 3) || a.ks == 1) && a.Cin % 32 == 0 ? 2 : 1;   // (1x1: staging-bound — dy is read once per 32 input channels)
+  // One 64 x 16 fragment block per workgroup (RT = CT = 1) also in bf16 mode: only that form has the registers to fetch the next tile
+  // while the matrix cores work on this one (pbww_k PREF).  The 128 x 16 / 64 x 32 / 128 x 32 blocks stage fewer bytes per product
+  // but load item by item, every load's latency exposed — measured (profiles/r04_pbww_blocks.txt, tools/one_conv.py, bf16): 3x3
+  // 221 -> 166 us (210 x 64 x 64^2), 198 -> 160 (210 x 128 x 32^2), 149 -> 98 (32 x 512 x 16^2), never slower; 4x4 stride 2
+  // 585 -> 532, 691 -> 659, 620 -> 470 us.
+  *rt = 1;
+  *ct = (a.ks == 1 && a.Cin % 32 == 0) ? 2 : 1;   // (1x1: staging-bound — dy is read once per 32 input channels)
   // (5x5 in split mode: 25 taps x 2 accumulator sets = 200 registers — one workgroup per CU with the accumulators in AGPRs, all
   //  taps in one pass: 2.43 -> 1.87 ms on the ConvLSTM layer against two passes of 13 + 12 taps that stage every tile twice)
   const int npass = 1;
@@ -1713,18 +1718,16 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     if (half == 5) hipLaunchKernelGGL((pbww_k<KS_, 1, 32, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);            \
     else PW_LAUNCH(KS_, 1, RT_, CT_, NS_);                                                                          \
   } while (0)
+  // (bf16 mode launches the 64 x 16 block only — pbww_plan; 1x1 keeps its 64 x 32 block)
   if (a.stride == 2) {
-    if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH_AUX(4, 2, 2, 1, 1); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
-    else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else if (rt == 2) PW_LAUNCH(4, 2, 2, 1, 1); else PW_LAUNCH(4, 2, 1, 1, 1); }
-    else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else if (rt == 2 && ct == 2) PW_LAUNCH(3, 2, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 2, 2, 1, 1);
-           else if (ct == 2) PW_LAUNCH(3, 2, 1, 2, 1); else PW_LAUNCH(3, 2, 1, 1, 1); }
+    if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, 3); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
+    else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else PW_LAUNCH(4, 2, 1, 1, 1); }
+    else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else PW_LAUNCH(3, 2, 1, 1, 1); }
   } else if (a.ks == 1) {
     if (a.nsplit == 3) { if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 3); else PW_LAUNCH(1, 1, 1, 1, 3); }
-    else if (rt == 2 && ct == 2) PW_LAUNCH(1, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(1, 1, 2, 1, 1);
     else if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 1); else PW_LAUNCH(1, 1, 1, 1, 1);
   } else if (a.ks == 3 && a.nsplit == 1) {
-    if (rt == 2 && ct == 2) PW_LAUNCH(3, 1, 2, 2, 1); else if (rt == 2) PW_LAUNCH(3, 1, 2, 1, 1);
-    else if (ct == 2) PW_LAUNCH1(3, 1, 2, 1); else PW_LAUNCH1(3, 1, 1, 1);
+    PW_LAUNCH1(3, 1, 1, 1);
   } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
   else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
   else {
