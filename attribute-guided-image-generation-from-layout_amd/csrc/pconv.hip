@@ -1293,7 +1293,11 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
 #define PC_ABL(A_) hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 1, 9, false, false, 256, A_>), g, dim3(256), 0, st, p)
     switch (a.ablate) {      // (the flag field holds 5 bits: code 2 stands for bit 32, "no output store")
       case 1: PC_ABL(1); break; case 8: PC_ABL(8); break; case 24: PC_ABL(24); break; case 2: PC_ABL(32); break;
-      case 3: PC_ABL(33); break; default: PC_ABL(57); break;
+      case 3: PC_ABL(33); break;
+      // occupancy probes: the unmodified kernel with idle dynamic LDS on top of its 29 KB, so that two / one workgroups fit a CU instead of three
+      case 11: hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 1, 9>), g, dim3(256), 40 * 1024, st, p); break;
+      case 12: hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 1, 9>), g, dim3(256), 90 * 1024, st, p); break;
+      default: PC_ABL(57); break;
     }
 #undef PC_ABL
   } else if (w8 && a.ks == 3) {
