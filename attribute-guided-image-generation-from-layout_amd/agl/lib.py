@@ -66,6 +66,7 @@ SIGNATURES = {
     "agl_conv2d_bwd_data_takes_bf16_mask": (_I, [_I] * 11),
     "agl_conv2d_fwd_writes_bf16_y": (_I, [_I] * 12),
     "agl_conv2d_fwd_takes_bf16_x": (_I, [_I] * 9),
+    "agl_conv2d_fwd_takes_blocked": (_I, [_I] * 9),
     "agl_conv2d_bwd_data_takes_bf16_dy": (_I, [_I] * 11),
     "agl_conv2d_bwd_weight_takes_bf16_dy": (_I, [_I] * 11),
     "agl_norm_fold_table": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
@@ -131,7 +132,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 5     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 6     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -173,6 +174,7 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_W8, CONV_PRIO = 128, 256
 CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
+CONV_BLOCKED = 1 << 21      # prototype: channel-blocked bf16 x and y of conv2d_fwd_blocked
 CONV_Y_BF16, CONV_MASK_BF16, CONV_DY_BF16 = 1 << 18, 1 << 19, 1 << 20      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
 CONV_FLAGS = 0
 
@@ -425,6 +427,40 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
          ptr(out, out.dtype if yb16 else torch.float32), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
          N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), int(relu), int(accumulate),
          CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0), stream())
+    return out
+
+
+def to_blocked(x):
+    """(N, C, H, W) fp32 / bf16 -> channel-blocked bf16 (N, C/8, H, W, 8)."""
+    N, C, H, W = x.shape
+    assert C % 8 == 0
+    return x.to(torch.bfloat16).view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_blocked(xb):
+    """Channel-blocked (N, C/8, H, W, 8) -> (N, C, H, W), same dtype."""
+    N, G, H, W, _ = xb.shape
+    return xb.permute(0, 1, 4, 2, 3).reshape(N, G * 8, H, W).contiguous()
+
+
+def conv2d_fwd_blocked(xb, w, bias=None, in_relu=False, relu=False, wsrc=None):
+    """PROTOTYPE: 3x3 stride-1 "same" convolution on channel-blocked bf16 tensors (include/agl.h AGL_CONV_BLOCKED): xb (N, Cin/8, H, W, 8)
+    bf16 -> (N, Cout/8, H, W, 8) bf16.  bf16 arithmetic only; raises when the kernel does not take the extents."""
+    N, G, H, W, e = xb.shape
+    Cin = G * 8
+    Cout, Cin_w, ks, _ = w.shape
+    assert e == 8 and Cin_w == Cin and xb.dtype == torch.bfloat16 and xb.is_contiguous()
+    pad = (ks - 1) // 2
+    flags = CONV_FLAGS | CONV_X_BF16 | CONV_Y_BF16 | CONV_BLOCKED
+    if not load().agl_conv2d_fwd_takes_blocked(N, Cin, H, W, Cout, ks, 1, pad, flags):
+        raise ValueError(f"conv2d_fwd_blocked: extents not taken ({N}, {Cin}, {H}, {W}) -> {Cout}, ks {ks}")
+    out = torch.empty((N, Cout // 8, H, W, 8), dtype=torch.bfloat16, device=xb.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, 1, pad, 0)
+    ws = workspace(need, xb.device) if need else None
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, 1, pad, 0)
+    call("agl_conv2d_fwd", ptr(xb, torch.bfloat16), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
+         ptr(out, torch.bfloat16), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+         N, Cin, H, W, Cout, ks, 1, pad, 0, int(in_relu), int(relu), 0, flags, stream())
     return out
 
 

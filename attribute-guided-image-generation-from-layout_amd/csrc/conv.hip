@@ -990,6 +990,7 @@ struct ConvOpts {
   bool y_bf16;       // AGL_CONV_Y_BF16 (1 << 18): agl_conv2d_fwd writes y as bf16 (few-input-channel stream kernel only)
   bool mask_bf16;    // AGL_CONV_MASK_BF16 (1 << 19): agl_conv2d_bwd_data reads pos_mask as bf16 ("same" patch kernel without a reduction split)
   bool dy_bf16;      // AGL_CONV_DY_BF16 (1 << 20): agl_conv2d_bwd_weight reads dy as bf16 (matrix-core kernel, bf16 arithmetic)
+  bool blocked;      // AGL_CONV_BLOCKED (1 << 21): the bf16 x and y of agl_conv2d_fwd are channel-blocked [N][C/8][H][W][8] (prototype)
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -1008,6 +1009,7 @@ static ConvOpts conv_opts(int flags) {
   o.y_bf16 = (flags & (1 << 18)) != 0;
   o.mask_bf16 = (flags & (1 << 19)) != 0;
   o.dy_bf16 = (flags & (1 << 20)) != 0;
+  o.blocked = (flags & (1 << 21)) != 0;
   return o;
 }
 constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, 0, 0, false, false, false, false};
@@ -1693,6 +1695,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1; a.y_bf16 = co.y_bf16;
+    a.blocked = co.blocked;
+    AGL_REQUIRE(!co.blocked || co.y_bf16, "agl_conv2d_fwd: AGL_CONV_BLOCKED needs AGL_CONV_X_BF16 and AGL_CONV_Y_BF16 (ask agl_conv2d_fwd_takes_blocked)");
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, bf16 input)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd: AGL_CONV_X_BF16 on a shape the patch kernel does not take");
     g_last_pipe = 1;
@@ -2317,6 +2321,15 @@ int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, 
   if (Cout <= 4)
     return (stride == 1 && 2 * pad == ks - 1 && pconv_vert_ws_bytes(N, Cin, H, W, Cout, ks, 1) > 0) ? 1 : 0;
   return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
+}
+// 1 when agl_conv2d_fwd takes AGL_CONV_BLOCKED (with AGL_CONV_BF16 | AGL_CONV_X_BF16 | AGL_CONV_Y_BF16) for these extents
+int agl_conv2d_fwd_takes_blocked(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || 2 * pad != ks - 1) return 0;
+  PConvArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = H; a.OW = W; a.ks = ks; a.stride = stride; a.pad = pad; a.up = 0;
+  a.nsplit = 1; a.any_grid = co.any_grid; a.x_bf16 = 1; a.y_bf16 = 1; a.blocked = 1;
+  return pconv_takes_blocked(a) ? 1 : 0;
 }
 // 1 when agl_conv2d_bwd_data with AGL_CONV_BF16 | AGL_CONV_X_BF16 (dy stored as bf16) runs these extents on a matrix-core kernel
 int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {

@@ -28,6 +28,8 @@ struct PConvArgs {
   InFold fold;                      // optional (scale != NULL): transform of x while it is staged (stride-1 / stride-2 forward forms)
   int y_bf16;                       // y points to bf16 elements (AGL_CONV_Y_BF16; launches without a reduction split only)
   const float* addend;              // optional fp32 tensor shaped like y, added before the output ReLU (no reduction split)
+  int blocked;                      // x and y are CHANNEL-BLOCKED bf16 tensors [N][C/8][H][W][8] (AGL_CONV_BLOCKED; with x_bf16 and y_bf16; the 3x3
+                                    // stride-1 32 x 8-tile forms only: pconv_takes_blocked)
   const float* sc_x; const float* sc_w; const float* sc_b; int sc_cin;   // optional few-channel 1x1 shortcut added in the epilogue:
                                     // y += sc_b[m] + sum_c sc_w[m*sc_cin + c] * sc_x[n][c][pixel] (bf16 3x3 stride-1 forms, <= 64-channel tiles)
 };
@@ -45,6 +47,8 @@ long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
 long pconv_ws_bytes_split(int Cin, int Cout, int ks, int nsplit, long out_numel);
 // True when pconv_try would launch for these extents (given enough workspace).
 bool pconv_eligible(const PConvArgs& a);
+// True when pconv_try takes these extents with a.blocked (channel-blocked bf16 x and y)
+bool pconv_takes_blocked(const PConvArgs& a);
 // Reduction splits pconv_try would use for these extents (1: none), -1 when the shape is not eligible.
 int pconv_plan_splits(const PConvArgs& a);
 // Returns AGL_OK when launched, -1 when the shape is not eligible (caller falls back), or an error code.

@@ -50,6 +50,7 @@ struct PArgs {
                      // spectrally normalised layer: packed W_orig, divisor sigma)
   InFold fold;       // optional input transform of the staged patch (pconv.h): the normalise-modulate of the BatchNorm that reads x
   int y_bf16;        // y points to bf16 elements (plain epilogue only: no phases, no reduction split)
+  int blk;           // FEAT 64: x and y are channel-blocked bf16 tensors [N][C/8][H][W][8]
   const float* addend;   // optional fp32 tensor shaped like y, added to the result before the output ReLU (out-of-place accumulate)
   // optional few-channel 1x1 shortcut evaluated in the epilogue (FEAT 16): y += sc_b[m] + sum_c sc_w[m * sc_cin + c] * sc_x[img][c][pixel],
   // sc_x an (N, sc_cin <= 4, OH, OW) fp32 tensor — the learnable shortcut of the discriminators' first block (discriminator.py:43-44, :58-60)
@@ -153,6 +154,11 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   constexpr bool F_FOLD = (FEAT & 1) != 0, F_STATS = (FEAT & 2) != 0, F_YOUT = (FEAT & 4) != 0;
   constexpr bool F_SC = (FEAT & 16) != 0;          // 16: few-channel 1x1 shortcut added in the plain epilogue (PArgs::sc_x)
   constexpr bool F_PMASK16 = (FEAT & 8) != 0;      // 8: bf16 pos_mask in the paired-phase epilogue (the bf16-stored h of a discriminator block)
+  // 64: channel-blocked bf16 tensors, x and y as [N][C/8][H][W][8] (PROTOTYPE, one family: DESIGN §3.3).  A staged piece — the 8 channels
+  // of a pixel — is ONE aligned 16-byte load that goes to LDS as it is (no conversion, no per-channel element loads: a 16-channel chunk
+  // of the 34 x 10 patch is 100 cache-line visits instead of 320), and the epilogue stores 8 channels of a pixel as one 16-byte piece.
+  constexpr bool BLK = (FEAT & 64) != 0;
+  static_assert(!BLK || (NSPL == 1 && !PHS && !VERT && S == 1 && FEAT == 64), "blocked layout: plain bf16 stride-1 form");
   constexpr int KSW = VERT ? 1 : KS;           // window columns
   static_assert(!VERT || (S == 1 && !PHS && TG == KS), "vertical window");
   constexpr int NT = NTH;                      // (shadows the file-level 256)
@@ -241,7 +247,8 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     const int img = img0 + ti, ly = S * ty0 - pad_y + yy, lx = S * tx0 - pad_x + xx;
     const bool in = e < NB;
     const bool ok = in && img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-    bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
+    if constexpr (BLK) bsrc[r] = ok ? (unsigned)(((img * (p.Cin >> 3) + h) * p.H + ly) * p.W + lx) * 16u : OOB31;      // the piece of channel group h
+    else bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
     bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
     if constexpr (F_FOLD) faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // row offset of this item's 8 channels in the scale / shift tables
   }
@@ -255,12 +262,19 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     asrc[r] = (unsigned)((((plane * p.nch) * 2 + h) * KKW + t) * p.mpad + bm0 + row);
   }
 
-  float pb[BR][8];
+  float pb[BLK ? 1 : BR][8];
+  u32x4 pq[BLK ? BR : 1];      // blocked layout: the pieces as they are stored
   u32x4 pa[AR];
   int c_staged = 0;    // first channel of the chunk in pb
   auto gload_b = [&](int c0) {
     if ((ABL & 8) && c0 != 16 * (p.slabs ? zsplit * p.cps : 0)) return;
     if constexpr (F_FOLD) c_staged = c0;
+    if constexpr (BLK) {      // one 16-byte load per piece, from a clamped address (an out-of-window piece is zeroed when it is stored)
+      const char* const xb = reinterpret_cast<const char*>(p.x) + (size_t)(c0 >> 3) * (size_t)(p.H * p.W) * 16u;
+#pragma unroll
+      for (int r = 0; r < BR; ++r) pq[r] = *reinterpret_cast<const u32x4*>(xb + (bsrc[r] == OOB31 ? 0u : bsrc[r]));
+      return;
+    }
     if (p.x_bf16) {      // (a bf16 value is the upper half of its fp32 form: the conversion at the LDS store is then exact)
 #pragma unroll
       for (int r = 0; r < BR; ++r)
@@ -286,6 +300,15 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       if (bdst[r] < 0) continue;
+      if constexpr (BLK) {
+        u32x4 v = pq[r];
+        if (p.in_relu) {      // ReLU on the stored bf16 pairs: a set sign bit clears its 16-bit half
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] &= ~(((v[q] >> 15) & 0x00010001u) * 0xFFFFu);
+        }
+        Pl[bdst[r]] = bsrc[r] != OOB31 ? v : u32x4{0u, 0u, 0u, 0u};
+        continue;
+      }
       if constexpr (F_FOLD) {
         if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
 #pragma unroll
@@ -464,6 +487,28 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
+      if constexpr (BLK) {
+        const int jq = wn * (BN / WNW) + 32 * jt + l31;
+        const int tiq = jq / (TH * TW), rq = jq - tiq * (TH * TW), pyq = rq / TW, pxq = rq - pyq * TW;
+        const int imq = img0 + tiq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int mch = bm0 + wm * (BM / 2) + 32 * i + 8 * g;      // first channel of the piece
+          if (mch < p.Cout && imq < p.N) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 ob;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float t = acc[0][i][jt][4 * g + q] * osc + (p.bias ? p.bias[mch + 4 * lh + q] : 0.f);
+              if (p.relu) t = fmaxf(t, 0.f);
+              ob[q] = (__bf16)t;
+            }
+            const long piece = ((long)(imq * (p.Cout >> 3) + (mch >> 3)) * p.OH + ty0 + pyq) * p.OW + tx0 + pxq;
+            reinterpret_cast<uint2*>(p.y)[2 * piece + lh] = __builtin_bit_cast(uint2, ob);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int r2 = 0; r2 < 16; ++r2) ep[((r2 & 3) + 8 * (r2 >> 2) + 4 * lh) * EP_PITCH + l31] = acc[0][i][jt][r2];
       // (one wave writes and reads its own scratch: the LDS accesses of a wave are ordered, no barrier needed)
@@ -1153,6 +1198,12 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 }
 
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
+bool pconv_takes_blocked(const PConvArgs& a) {      // prototype: 3x3 stride-1 "same", bf16 arithmetic, maps of >= 8 x 8 pixels, no reduction split
+  PConvPlan pl;
+  if (pconv_plan(a, pl) != 0) return false;
+  return a.nsplit == 1 && a.ks == 3 && a.stride == 1 && a.up == 0 && a.x_bf16 && a.y_bf16 && !a.accumulate && !a.pos_mask && !a.addend && !a.sc_x &&
+         !a.fold.scale && !a.stats && pl.splits == 1 && pl.geo != 2 && a.Cin % 16 == 0 && a.Cout % 8 == 0;
+}
 int pconv_plan_splits(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0 ? pl.splits : -1; }
 long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
 long pconv_stat_row_floats(int Cout) { return 3L * Cout; }      // a partial row: [Cout][{count, mean, M2}]
@@ -1212,7 +1263,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const bool featsc = a.sc_x != nullptr;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
-  p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend;
+  p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend; p.blk = a.blocked;
+  if (a.blocked && !pconv_takes_blocked(a)) return -1;
   p.sc_x = a.sc_x; p.sc_w = a.sc_w; p.sc_b = a.sc_b; p.sc_cin = a.sc_cin;
   if (a.sc_x && !(a.ks == 3 && !s2 && a.nsplit == 1 && bm == 64 && geo != 2 && pl.splits == 1 && a.sc_cin >= 1 && a.sc_cin <= 4 && a.OW % 4 == 0))
     return -1;                                                       // (compiled into the bf16 3x3 stride-1 instantiations with 64-channel tiles)
@@ -1324,6 +1376,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       }
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
+    } else if (a.nsplit == 1 && a.blocked) {      // (pconv_takes_blocked)
+      if (bm == 128) PC_SHAPES1F(64, 3, 128, 9); else PC_SHAPES1F(64, 3, 64, 9);
     } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
     else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 5
+#define AGL_ABI_VERSION 6
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -115,6 +115,13 @@ int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout
  * whose forward IS this call): agl_conv2d_bwd_data_takes_bf16_dy;  AGL_CONV_DY_BF16 on agl_conv2d_bwd_weight: dy holds bf16 (the
  * same tensor in the weight gradient of that transposed convolution): agl_conv2d_bwd_weight_takes_bf16_dy. */
 int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
+/* PROTOTYPE (ABI 6): channel-blocked bf16 activations.  With AGL_CONV_BLOCKED (and AGL_CONV_BF16 | AGL_CONV_X_BF16 | AGL_CONV_Y_BF16)
+ * agl_conv2d_fwd reads x and writes y as [N][C/8][H][W][8] bf16 tensors: the 8 channels of a pixel are one 16-byte piece, which is what
+ * the matrix-core kernel stages and what its epilogue can store whole (the NCHW staging pass is bound by the cache lines
+ * it visits).  One family so far — 3x3 stride-1 "same" on maps of >= 8 x 8 pixels, Cin % 16 == 0, Cout % 8 == 0, bias / ReLU / input
+ * ReLU; no network uses it yet.  Reference counterpart: the same nn.Conv2d call (models/discriminator.py:70-79) on a permuted tensor. */
+#define AGL_CONV_BLOCKED (1 << 21)
+int agl_conv2d_fwd_takes_blocked(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
 int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int relu, int accumulate,
                                  int flags);
 int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);

@@ -1285,6 +1285,30 @@ def test_pconv_stride2_input_gradient_odd_sized_input(case, mode):
     close(dx2, base + ref * (mask > 0), 5e-5, "with ReLU mask and accumulation")
 
 
+@pytest.mark.parametrize("case", [(3, 64, 32, 64, 64), (2, 32, 16, 128, 128), (5, 128, 64, 32, 64), (2, 64, 64, 64, 72)])
+@pytest.mark.parametrize("in_relu,relu,bias", [(False, False, False), (True, True, True)])
+def test_channel_blocked_bf16_convolution_prototype(case, in_relu, relu, bias):
+    """AGL_CONV_BLOCKED (include/agl.h, prototype): a 3x3 "same" convolution whose bf16 x and y are channel-blocked [N][C/8][H][W][8].
+    The kernel stages and stores 16-byte pieces of 8 channels; products, accumulation order and the final rounding are those of the
+    NCHW bf16-in / bf16-out call, so the two must agree bit for bit — and both with torch on the bf16-rounded operands."""
+    from agl import lib as L
+    N, Cin, H, W, Cout = case
+    x, w, b = rn(N, Cin, H, W), rn(Cout, Cin, 3, 3, seed=1) * (1.0 / (Cin * 9) ** 0.5), (rn(Cout, seed=2) if bias else None)
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ref = TF.conv2d(torch.relu(r(x)) if in_relu else r(x), r(w), b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    with L.conv_flags(L.CONV_BF16 | L.CONV_ANY_GRID):
+        xb = L.to_blocked(dev(x))
+        assert torch.equal(L.from_blocked(xb), dev(x).to(torch.bfloat16))
+        assert L.load().agl_conv2d_fwd_takes_blocked(N, Cin, H, W, Cout, 3, 1, 1, L.CONV_FLAGS | L.CONV_X_BF16 | L.CONV_Y_BF16 | L.CONV_BLOCKED)
+        yb = L.conv2d_fwd_blocked(xb, dev(w), dev(b) if bias else None, in_relu=in_relu, relu=relu)
+        y16 = L.conv2d_fwd(dev(x).to(torch.bfloat16), dev(w), dev(b) if bias else None, 1, 1, in_relu=in_relu, relu=relu, out_bf16=True)
+    assert tuple(yb.shape) == (N, Cout // 8, H, W, 8) and yb.dtype == torch.bfloat16
+    assert torch.equal(L.from_blocked(yb), y16), float((L.from_blocked(yb).float() - y16.float()).abs().max())
+    close(L.from_blocked(yb).float(), ref, 1e-2, "blocked bf16 convolution vs torch on bf16-rounded operands")
+
+
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
 def test_odd_sized_input_gradient_on_concurrent_streams(mode):
     """The training step runs the three generator branches' layout encoders on three streams, so three of these launches (paired-phase
