@@ -229,9 +229,15 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         # The timed steps run the discriminator / generator-branch / weight-gradient chains on several streams; here every launch
         # is timed on its own — one stream, program order (Trainer.serial) — so that a launch's duration is the kernel's, not the
         # kernel's share of a GPU it divides with two other chains.
-        L.EVENT_LOG = [] if rank == 0 else None
-        packs0 = L.PACK_STATS["packs"]
         with tr.serial():
+            # Two ordinary steps first, not waited for: the host is then a step and a half ahead of the GPU when it issues the
+            # instrumented one, every kernel is already queued when its start event executes, and an event pair brackets the
+            # kernel(s) of its call — not the host's latency between recording the event and launching (with the GPU waiting on
+            # the host, a slower host inflated the family's time by a third: 104 vs 136 ms for the same 1365 launches).
+            one_step()
+            one_step()
+            L.EVENT_LOG = [] if rank == 0 else None
+            packs0 = L.PACK_STATS["packs"]
             one_step()
             tr.finish()
             fence()
