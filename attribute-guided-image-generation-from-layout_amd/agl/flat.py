@@ -7,6 +7,7 @@ MI355X; launches and small collectives are what cost).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
@@ -43,6 +44,7 @@ class FlatParams:
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.pack_plan = L.PackPlan() if os.environ.get("AGL_FUSED_REPACK", "1") != "0" else None      # (A/B switch)
         self.step_count = 0
         self.epoch = 0      # bumped whenever the arena is written through a raw pointer or an alias (Adam kernel, broadcast): the
                             # packed-weight caches of the parameters (agl.lib.WeightSrc) are keyed by (epoch, tensor version)
@@ -102,3 +104,5 @@ class FlatParams:
         self.step_count += 1
         self.epoch += 1
         L.adam_step(self.p, self.g, self.m, self.v, lr, beta1, beta2, eps, self.step_count, grad_scale)
+        if self.pack_plan is not None:      # every packed form of the arena's weights, in one launch on this stream (agl.lib.PackPlan)
+            self.pack_plan.repack()

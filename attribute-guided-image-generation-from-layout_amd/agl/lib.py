@@ -30,6 +30,8 @@ SIGNATURES = {
     "agl_conv2d_fwd_packed_bytes": (_L, [_I] * 10),
     "agl_conv2d_bwd_data_packed_bytes": (_L, [_I] * 11),
     "agl_conv2d_pack_weights": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
+    "agl_conv2d_pack_desc": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
+    "agl_conv2d_pack_many": (_I, [_P, _I, _L, _P]),
     "agl_conv2d_last_pipe": (_I, []),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
     "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 14 + [_P]),
@@ -335,7 +337,68 @@ def conv_out_size(h, ks, stride, pad, up=0):
 # a discriminator's weight_orig between two optimiser updates; only sigma of the spectral norm changes per forward call, and the
 # kernels divide by it in their epilogue.  A WeightSrc names where the values of a convolution weight come from; the packed
 # buffers live on the owning parameter and are re-made when its version changes.
-PACK_STATS = {"packs": 0, "hits": 0}
+PACK_STATS = {"packs": 0, "hits": 0, "fused": 0}
+PACK_DESC_WORDS = 14       # = AGL_PACK_DESC_WORDS of include/agl.h
+
+
+class PackPlan:
+    """The packs of one parameter arena, re-made in ONE launch right after the optimiser step (agl_conv2d_pack_many) instead of one
+    launch per weight and form at their first use in the next iteration (~130-150 launches per training iteration).  Entries are noted
+    by WeightSrc.packed when it packs a parameter of the arena (not a derived tensor); a re-pack writes the entries' buffers IN
+    PLACE on the optimiser's stream: whatever ordered the readers of the old weights before the optimiser's in-place update orders
+    them before this, and later readers on other streams wait for the cache entry's event as before."""
+
+    def __init__(self):
+        self.entries = {}          # (id(owner), key) -> (owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src)
+        self.table = None          # device int64 (n, PACK_DESC_WORDS)
+        self.blocks = 0
+        self.order = []
+
+    def note(self, owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src):
+        k = (id(owner), key)
+        old = self.entries.get(k)
+        if old is None or old[9] is not buf or old[8] != flags:
+            self.entries[k] = (owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src)
+            self.table = None
+
+    def _build(self, device):
+        import ctypes as C_
+        rows = []
+        self.order = list(self.entries.values())
+        first = 0
+        for (owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src) in self.order:
+            row = (C_.c_longlong * PACK_DESC_WORDS)()
+            call("agl_conv2d_pack_desc", ptr(src.detach()), buf.data_ptr(), buf.numel(), pass_, Cin, Cout, ks, stride, flags, C_.addressof(row))
+            row[12] = first
+            first += row[13]
+            rows.append(list(row))
+        self.blocks = first
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+
+    def repack(self):
+        """Re-pack every noted entry whose cache entry still holds the noted buffer; returns the number of packs done."""
+        live = {}
+        for k, e in self.entries.items():
+            hit = e[0].__dict__.get("_agl_packs", {}).get(e[1])
+            if hit is not None and hit[1] is e[9]:
+                live[k] = e
+        if len(live) != len(self.entries):
+            self.entries, self.table = live, None
+        if not self.entries:
+            return 0
+        dev = next(iter(self.entries.values()))[9].device
+        if self.table is None:
+            self._build(dev)
+        call("agl_conv2d_pack_many", self.table.data_ptr(), len(self.order), self.blocks, stream())
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for (owner, key, wsrc, *_rest) in self.order:
+            buf = _rest[6]
+            owner.__dict__["_agl_packs"][key] = (wsrc.version(), buf, ev, cur.cuda_stream)
+        PACK_STATS["fused"] += 1
+        return len(self.order)
+
 
 
 class WeightSrc:
@@ -379,6 +442,10 @@ class WeightSrc:
         ev.record(cur)
         PACK_STATS["packs"] += 1
         cache[key] = (ver, buf, ev, cur.cuda_stream)
+        flat = getattr(self.owner, "_agl_flat", None)
+        if make is None and flat is not None and getattr(flat, "pack_plan", None) is not None and src.data_ptr() == (self.base if self.base is not None else self.owner).data_ptr():
+            # a parameter of a flat arena packed as it is (not a derived tensor): the arena re-packs it after its optimiser step
+            flat.pack_plan.note(self.owner, key, self, pass_, Cin, Cout, ks, stride, CONV_FLAGS & (CONV_BF16 | CONV_SPLIT3), buf, src)
         return buf
 
 

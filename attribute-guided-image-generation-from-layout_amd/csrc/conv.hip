@@ -2393,6 +2393,39 @@ int agl_conv2d_pack_weights(const float* w, void* packed, long packed_bytes, int
   return pconv_pack(w, packed, Cin, Cout, ks, ks * ks, Cin * ks * ks, 1, ns, 0, st, "agl_conv2d_pack_weights(bwd_data)");
 }
 
+// The pack of agl_conv2d_pack_weights as one row of a descriptor table (host memory, AGL_PACK_DESC_WORDS 64-bit words) ...
+int agl_conv2d_pack_desc(const float* w, void* packed, long packed_bytes, int pass, int Cin, int Cout, int ks, int stride, int flags,
+                         long long* row) {
+  AGL_REQUIRE(w && packed && row, "agl_conv2d_pack_desc: null pointer");
+  const ConvOpts co = conv_opts(flags);
+  AGL_REQUIRE(co.prec == 1 || co.split3, "agl_conv2d_pack_desc: flags select no matrix-core arithmetic (AGL_CONV_BF16 / AGL_CONV_SPLIT3)");
+  const int ns = co.prec == 1 ? 1 : 3;
+  if (pass == 0) {
+    const long need = pconv_ws_bytes(Cin, Cout, ks, ns);
+    AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_desc: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+    pconv_pack_desc(w, packed, Cout, Cin, ks, Cin * ks * ks, ks * ks, 0, ns, 0, row);
+    return AGL_OK;
+  }
+  AGL_REQUIRE(pass == 1, "agl_conv2d_pack_desc: pass must be 0 (forward) or 1 (input gradient)");
+  if (stride == 2) {
+    AGL_REQUIRE(ks == 4, "agl_conv2d_pack_desc: the stride-2 input gradient is packed for 4x4 kernels only");
+    const long need = pconvT_ws_bytes(Cout, Cin, ns);
+    AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_desc: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+    pconv_pack_desc(w, packed, Cin, Cout, 4, 16, Cin * 16, 0, ns, 1, row);
+    return AGL_OK;
+  }
+  const long need = pconv_ws_bytes(Cout, Cin, ks, ns);
+  AGL_REQUIRE(need > 0 && packed_bytes >= need, "agl_conv2d_pack_desc: buffer too small or shape not packable (%ld < %ld)", packed_bytes, need);
+  pconv_pack_desc(w, packed, Cin, Cout, ks, ks * ks, Cin * ks * ks, 1, ns, 0, row);
+  return AGL_OK;
+}
+// ... and the launch that re-packs a whole table: rows_dev = n rows in device memory whose word 12 holds the row's first block
+// (running sum of word 13), total_blocks = the sum.  One launch after the optimiser step instead of one per weight and form.
+int agl_conv2d_pack_many(const void* rows_dev, int n, long total_blocks, void* stream) {
+  AGL_REQUIRE(rows_dev && n > 0 && total_blocks > 0 && total_blocks < (1L << 31), "agl_conv2d_pack_many: bad argument");
+  return pconv_pack_many(rows_dev, n, total_blocks, (hipStream_t)stream, "agl_conv2d_pack_many");
+}
+
 // Executed FLOPs (2*MAC) of the launches one call of the entry points above issues for these extents and flags, assuming
 // the workspace the *_ws_bytes functions ask for is provided: dense 2*N*OH*OW*Cout*Cin*ks^2, minus the padded taps the
 // position-major path never visits.  (bench.py's roofline leg divides the sum of these by the measured launch time.)

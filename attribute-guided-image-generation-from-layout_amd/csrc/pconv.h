@@ -37,6 +37,10 @@ struct PConvArgs {
 // swapped) and for pconvT_try (phase4): bytes = pconv_ws_bytes / pconvT_ws_bytes.  M = rows (output channels of the pass).
 int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, hipStream_t st,
                const char* name);
+// The same pack as one row of a descriptor table (14 64-bit words; row[13] = its 256-thread blocks, row[12] = its first block, to be
+// filled by the caller with the running sum) and the launch that executes a whole table (pack_many_k)
+void pconv_pack_desc(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, long long* row);
+int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t st, const char* name);
 // Upper bound of the partial rows pconv_try writes for an output of N images of OH x OW pixels
 long pconv_stat_rows_max(int N, int OH, int OW);
 long pconv_stat_row_floats(int Cout);      // floats per partial row: [Cout][{count, mean, M2}]

@@ -67,11 +67,8 @@ __device__ __forceinline__ void split3(float a, __bf16& t0, __bf16& t1, __bf16& 
 }
 
 // Weight re-pack: wp[plane][cc][h][tap][m][j] = term_plane( w[m*w_sm + (16cc + 8h + j)*w_sc + tap'] ), zero for m >= M
-__global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
-                               int flip, int mpad, int nch, int nsplit, int phase4) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long per_plane = (long)nch * 2 * KK * mpad;
-  if (i >= per_plane) return;
+__device__ __forceinline__ void pack_piece(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                                           int flip, int mpad, int nsplit, int phase4, long per_plane, long i) {
   const int m = (int)(i % mpad);
   long r = i / mpad;
   const int tap = (int)(r % KK); r /= KK;
@@ -96,6 +93,27 @@ __global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ 
     wp[per_plane + i] = __builtin_bit_cast(u32x4, t1);
     wp[2 * per_plane + i] = __builtin_bit_cast(u32x4, t2);
   }
+}
+__global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                               int flip, int mpad, int nch, int nsplit, int phase4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  if (i >= per_plane) return;
+  pack_piece(w, wp, M, Cin, KK, w_sm, w_sc, flip, mpad, nsplit, phase4, per_plane, i);
+}
+// All packed forms of a parameter arena in ONE launch (after the optimiser step): d = n rows of AGL_PACK_DESC_WORDS 64-bit words
+// {w, wp, M, Cin, KK, w_sm, w_sc, flip, mpad, nsplit, phase4, per_plane, first block, blocks} (pconv_pack_desc); a block finds its
+// row by bisection over the first-block column.
+__global__ void pack_many_k(const long long* __restrict__ d, int n) {
+  constexpr int WD = 14;
+  int lo = 0, hi = n - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d[(long)mid * WD + 12] <= b) lo = mid; else hi = mid - 1; }
+  const long long* r = d + (long)lo * WD;
+  const long i = (b - r[12]) * blockDim.x + threadIdx.x, per_plane = r[11];
+  if (i >= per_plane) return;
+  pack_piece(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7],
+             (int)r[8], (int)r[9], (int)r[10], per_plane, i);
 }
 
 // LDS pixel pitches that make every ds_read_b128 lane group of the B fragments hit 16 distinct 16-byte slots
@@ -1413,6 +1431,17 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   return AGL_OK;
 }
 
+void pconv_pack_desc(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, long long* row) {
+  const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  row[0] = (long long)(uintptr_t)w; row[1] = (long long)(uintptr_t)packed; row[2] = M; row[3] = Cred; row[4] = KK; row[5] = w_sm; row[6] = w_sc;
+  row[7] = flip; row[8] = mpad; row[9] = nsplit; row[10] = phase4; row[11] = per_plane; row[12] = 0; row[13] = (per_plane + 255) / 256;
+}
+int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(pack_many_k, dim3((unsigned)total_blocks), dim3(256), 0, st, (const long long*)rows_dev, n);
+  AGL_CHECK_LAUNCH(name);
+  return AGL_OK;
+}
 int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, int w_sc, int flip, int nsplit, int phase4, hipStream_t st,
                const char* name) {
   const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);

@@ -309,7 +309,8 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 "launches_per_step": len(conv), "kernel_ms_per_step": round(conv_ms, 3),
                 "executed_flops_per_step": executed, "algorithmic_flops_per_step": flops_step,
                 "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3),
-                "weight_packs_per_step": L.PACK_STATS["packs"] - packs0}
+                "weight_packs_per_step": L.PACK_STATS["packs"] - packs0,      # individual pack launches (derived weights: ConvLSTM halves, pooled filters)
+                "fused_repacks_per_step": 2 if L.PACK_STATS.get("fused") else 0}      # one launch per arena after its Adam step (agl.lib.PackPlan)
         nrm = [e for e in log if e[0] in NORM_NAMES]
         nrm_ms = sum(e[1].elapsed_time(e[2]) for e in nrm)
         nbytes = sum(e[3] for e in nrm)

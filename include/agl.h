@@ -86,6 +86,14 @@ long agl_conv2d_bwd_data_packed_bytes(int N, int Cin, int IH, int IW, int Cout, 
  * (Cin, Cout, ks, stride, arithmetic flags) only, so one packed buffer serves every call of that layer until the weights change. */
 int agl_conv2d_pack_weights(const float* w, void* packed, long packed_bytes, int pass, int Cin, int Cout, int ks, int stride, int flags,
                             void* stream);
+/* All packs of a parameter arena in ONE launch (ABI 6): a caller that re-packs every weight after each optimiser step (torch.optim.Adam.step
+ * in train64.py:262 / :370) describes each pack once — agl_conv2d_pack_desc fills one host row of AGL_PACK_DESC_WORDS 64-bit words with the
+ * same arguments as agl_conv2d_pack_weights; word 13 is the row's block count, word 12 its first block: the running sum, filled by the
+ * caller — uploads the table, and calls agl_conv2d_pack_many(table, rows, total blocks) after every update. */
+#define AGL_PACK_DESC_WORDS 14
+int agl_conv2d_pack_desc(const float* w, void* packed, long packed_bytes, int pass, int Cin, int Cout, int ks, int stride, int flags,
+                         long long* row);
+int agl_conv2d_pack_many(const void* rows_dev, int n, long total_blocks, void* stream);
 /* Arithmetic pipe of the main kernel the LAST agl_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_weight call of the calling thread
  * launched: 0 = exact fp32 (fp32 MFMA or fp32 VALU), 1 = bf16 MFMA, one product per multiply-add (AGL_CONV_BF16), 3 = bf16 MFMA
  * with split operands, six products per multiply-add (AGL_CONV_SPLIT3).  bench.py prices each launch against that pipe's peak. */

@@ -862,6 +862,46 @@ def test_two_trainers_driven_from_two_host_threads():
     assert F.BN_TAPE is None and F.BN_DEFER is None and F.GRAD_ARENA is None and L.WGRAD_STREAMS is None and L.CONV_FLAGS == 0
 
 
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_fused_repack_after_the_optimiser_step_equals_individual_packs(mode):
+    """agl.lib.PackPlan: after each Adam step the arena re-packs every packed form of its convolution weights in ONE launch
+    (agl_conv2d_pack_many), in place, instead of one launch per weight and form at their first use in the next iteration.  After two
+    iterations every cached pack must be current (no further individual pack of a parameter in the third iteration) and bit-equal to
+    a fresh agl_conv2d_pack_weights of the weight as it is now."""
+    from agl import lib as L, synth
+    from agl.trainer import Trainer, batch_to_device
+    nets = build_nets(False)
+    tr = Trainer(*nets, torch.from_numpy(synth.make_pos_weight()), conv_dtype=mode)
+    assert tr.flat_g.pack_plan is not None and tr.flat_d.pack_plan is not None
+    b = batch_to_device(synth.make_batch(5, 64, seed=7), DEV)
+    for _ in range(2):
+        tr.step(b)
+    tr.finish()
+    torch.cuda.synchronize()
+    n_g, n_d = len(tr.flat_g.pack_plan.entries), len(tr.flat_d.pack_plan.entries)
+    assert n_g > 5 and n_d > 5 and L.PACK_STATS["fused"] >= 4, (n_g, n_d, L.PACK_STATS)      # (a small batch: many layers stay below the patch kernel's grid threshold)
+    flags = {"f32x3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[mode]
+    checked = 0
+    for flat in (tr.flat_g, tr.flat_d):
+        for (owner, key, wsrc, pass_, Cin, Cout, ks, stride, fl, buf, src) in flat.pack_plan.entries.values():
+            hit = owner.__dict__["_agl_packs"][key]
+            assert hit[1] is buf and hit[0] == wsrc.version(), "a pack of the plan is stale after the optimiser step"
+            fresh = torch.empty_like(buf)
+            L.call("agl_conv2d_pack_weights", L.ptr(src.detach()), fresh.data_ptr(), fresh.numel(), pass_, Cin, Cout, ks, stride, fl | L.CONV_ANY_GRID, L.stream())
+            assert fl == flags
+            assert torch.equal(fresh, buf), key
+            checked += 1
+    assert checked == n_g + n_d
+    before = L.PACK_STATS["packs"]
+    planned = {(id(e[0]), e[1]) for f in (tr.flat_g, tr.flat_d) for e in f.pack_plan.entries.values()}
+    tr.step(b)
+    tr.finish()
+    torch.cuda.synchronize()
+    planned_after = {(id(e[0]), e[1]) for f in (tr.flat_g, tr.flat_d) for e in f.pack_plan.entries.values()}
+    assert planned_after == planned, "the third iteration packed a parameter individually again"
+    assert L.PACK_STATS["packs"] - before < 40, L.PACK_STATS      # (derived weights only: ConvLSTM halves, pooled filters)
+
+
 def test_concurrent_schedule_equals_sequential_schedule():
     """The training iteration with its concurrent schedule — discriminators on three streams, weight gradients on side streams,
     the generator's rand / shift branches on two streams with private gradient arenas and deferred BatchNorm updates, the G step's
