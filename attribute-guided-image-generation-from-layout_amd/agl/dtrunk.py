@@ -157,6 +157,9 @@ class _DTrunk(torch.autograd.Function):
             metas.append((kind, in_relu))
             o = out
         ctx.metas, ctx.srcs, ctx.nparams = metas, srcs, len(params)
+        # arena gradient slots of the leaf parameters (the biases: the weights are spectral-norm outputs, their gradients go on to that
+        # node): the kernels add into them and the node returns None — no autograd add launch per bias and call
+        ctx.slots = [F._slot(p) for p in params]
         ctx.save_for_backward(*([t for t in saved if t is not None] + [p for p in params if p is not None]))
         ctx.layout = ([t is not None for t in saved], [p is not None for p in params])
         return o
@@ -177,14 +180,15 @@ class _DTrunk(torch.autograd.Function):
             w1, b1, w2, b2, wsc, bsc = params[6 * k: 6 * k + 6]
             s1, s2, ssc = ctx.srcs[6 * k], ctx.srcs[6 * k + 2], ctx.srcs[6 * k + 4]
             nw = [need[3 + 6 * k + j] for j in range(6)]
+            sl = ctx.slots[6 * k: 6 * k + 6]
             need_in = k > 0 or need[0]
             H, W = o.shape[2], o.shape[3]
             if kind == "first_flat":
                 # out = c2(h) + sc(x): the shortcut's gradients from (d, x), the residual branch through h
                 dh = L.conv2d_bwd_data(d, w2, (H, W), 1, 1, pos_mask=h16, wsrc=s2)
-                grads[6 * k + 2], grads[6 * k + 3] = F._conv_param_grads((None, None), nw[2], b2 is not None and nw[3], d, h16, w2, 1, 1, 0, False)
-                grads[6 * k + 4], grads[6 * k + 5] = F._conv_param_grads((None, None), nw[4], bsc is not None and nw[5], d, o, wsc, 1, 0, 0, False)
-                grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((None, None), nw[0], b1 is not None and nw[1], dh, o, w1, 1, 1, 0, False)
+                grads[6 * k + 2], grads[6 * k + 3] = F._conv_param_grads((sl[2], sl[3]), nw[2], b2 is not None and nw[3], d, h16, w2, 1, 1, 0, False)
+                grads[6 * k + 4], grads[6 * k + 5] = F._conv_param_grads((sl[4], sl[5]), nw[4], bsc is not None and nw[5], d, o, wsc, 1, 0, 0, False)
+                grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((sl[0], sl[1]), nw[0], b1 is not None and nw[1], dh, o, w1, 1, 1, 0, False)
                 if need_in:
                     do = L.conv2d_bwd_data(dh, w1, (H, W), 1, 1, wsrc=s1)
                     L.conv2d_bwd_data(d, wsc, (H, W), 1, 0, out=do, accumulate=True, wsrc=ssc)
@@ -193,20 +197,24 @@ class _DTrunk(torch.autograd.Function):
             C, Cout = o.shape[1], w2.shape[0]
             # shortcut: out = hp + sc(s)
             ds = L.conv2d_bwd_data(d, wsc, (H // 2, W // 2), 1, 0, wsrc=ssc)
-            grads[6 * k + 4], grads[6 * k + 5] = F._conv_param_grads((None, None), nw[4], bsc is not None and nw[5], d, s, wsc, 1, 0, 0, False)
+            grads[6 * k + 4], grads[6 * k + 5] = F._conv_param_grads((sl[4], sl[5]), nw[4], bsc is not None and nw[5], d, s, wsc, 1, 0, 0, False)
             # residual branch: hp = conv4x4s2(h; pooled w2): input gradient masked by h > 0 (bf16 mask), weight gradient on the 4x4
             # form and back to the 3x3 filter
             dh = L.conv2d_bwd_data(d, None, (H, W), 2, 1, pos_mask=h16, wsrc=s2.derived("pool4") if s2 is not None else None,
                                    w_shape=(Cout, C, 4, 4), make_w=lambda w2=w2: _pooled(w2), make_base=lambda w2=w2, s2=s2: _pooled_src(w2, s2))
+            want_b2 = b2 is not None and nw[3]
             if nw[2]:
-                db2 = torch.empty(Cout, dtype=torch.float32, device=d.device) if (b2 is not None and nw[3]) else None
-                dw4 = L.conv2d_bwd_weight(d, h16, 4, 2, 1, dbias=db2, dbias_accumulate=False)
+                db2 = sl[3] if (want_b2 and sl[3] is not None) else (torch.empty(Cout, dtype=torch.float32, device=d.device) if want_b2 else None)
+                dw4 = L.conv2d_bwd_weight(d, h16, 4, 2, 1, dbias=db2, dbias_accumulate=want_b2 and sl[3] is not None)
                 dw3 = torch.empty((Cout, C, 3, 3), dtype=torch.float32, device=d.device)
                 L.call("agl_pool_fuse_weight_bwd", L.ptr(dw4), L.ptr(dw3), Cout * C, L.stream())
-                grads[6 * k + 2], grads[6 * k + 3] = dw3, db2
-            elif b2 is not None and nw[3]:
-                grads[6 * k + 3] = L.channel_sum(d)
-            grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((None, None), nw[0], b1 is not None and nw[1], dh, o, w1, 1, 1, 0, in_relu)
+                grads[6 * k + 2], grads[6 * k + 3] = dw3, (None if sl[3] is not None else db2)
+            elif want_b2:
+                if sl[3] is not None:
+                    L.channel_sum(d, out=sl[3], accumulate=True)
+                else:
+                    grads[6 * k + 3] = L.channel_sum(d)
+            grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((sl[0], sl[1]), nw[0], b1 is not None and nw[1], dh, o, w1, 1, 1, 0, in_relu)
             if need_in:
                 do = L.avgpool2_bwd(ds, o if in_relu else tuple(o.shape), in_relu)
                 L.conv2d_bwd_data(dh, w1, (H, W), 1, 1, pos_mask=o if in_relu else None, out=do, accumulate=True, wsrc=s1)

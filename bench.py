@@ -230,12 +230,18 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         # is timed on its own — one stream, program order (Trainer.serial) — so that a launch's duration is the kernel's, not the
         # kernel's share of a GPU it divides with two other chains.
         with tr.serial():
-            # Two ordinary steps first, not waited for: the host is then a step and a half ahead of the GPU when it issues the
-            # instrumented one, every kernel is already queued when its start event executes, and an event pair brackets the
-            # kernel(s) of its call — not the host's latency between recording the event and launching (with the GPU waiting on
-            # the host, a slower host inflated the family's time by a third: 104 vs 136 ms for the same 1365 launches).
+            # The instrumented step must run with the GPU BEHIND the host: every kernel already queued when its start event
+            # executes, so that an event pair brackets the kernel(s) of its call and not the host's latency between recording the
+            # event and launching (with the GPU waiting on the host, the same 1365 launches read 104 ms or 136 ms depending on the
+            # box's host).  One ordinary step (the one-stream schedule's allocations), then a spin kernel of about 2.5 step times
+            # (torch.cuda._sleep, calibrated here) holds the stream while the host enqueues the whole instrumented step behind it.
             one_step()
-            one_step()
+            tr.finish()
+            fence()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(); torch.cuda._sleep(2_000_000); c1.record(); torch.cuda.synchronize()
+            cycles_per_ms = 2_000_000 / max(1e-3, c0.elapsed_time(c1))
+            torch.cuda._sleep(int(min(800.0, 2.5 * 1e3 * dt / steps) * cycles_per_ms))
             L.EVENT_LOG = [] if rank == 0 else None
             packs0 = L.PACK_STATS["packs"]
             one_step()
