@@ -9,13 +9,14 @@ from agl.trainer import Trainer, batch_to_device
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mode = sys.argv[2] if len(sys.argv) > 2 else "f32x3"          # conv arithmetic: f32 | f32x3 | bf16
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 48        # images per iteration (object counts change every iteration)
+res = int(sys.argv[4]) if len(sys.argv) > 4 else 64           # 64 | 128
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-nets, _ = build_nets(64, dev)
+nets, _ = build_nets(res, dev)
 tr = Trainer(*nets, torch.from_numpy(synth.make_pos_weight()), conv_dtype=mode)
 mem = []
 for i in range(steps):
-    b = batch_to_device(synth.make_batch(batch - (i % 5), 64, seed=1000 + i), dev)      # a new batch (new image / object counts) every iteration
+    b = batch_to_device(synth.make_batch(batch - (i % 5), res, seed=1000 + i), dev)      # a new batch (new image / object counts) every iteration
     tr.step(b)
     tr.finish()
     if i % 5 == 0 or i == steps - 1:
