@@ -33,6 +33,7 @@ SIGNATURES = {
     "agl_conv2d_pack_desc": (_I, [_P, _P, _L] + [_I] * 6 + [_P]),
     "agl_conv2d_pack_many": (_I, [_P, _I, _L, _P]),
     "agl_conv2d_last_pipe": (_I, []),
+    "agl_conv2d_split_products": (_I, []),
     "agl_conv2d_bwd_weight_ws_bytes": (_L, [_I] * 6),
     "agl_conv2d_bwd_weight": (_I, [_P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 14 + [_P]),
     "agl_conv2d_fwd_flops": (C.c_double, [_I] * 10),
@@ -134,7 +135,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 6     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 7     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:

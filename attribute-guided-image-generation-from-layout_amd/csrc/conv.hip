@@ -2293,6 +2293,7 @@ static int conv2d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
 }
 
 int agl_conv2d_last_pipe(void) { return g_last_pipe; }
+int agl_conv2d_split_products(void) { return pconv_split_products(); }
 
 // 1 when agl_conv2d_fwd with AGL_CONV_BF16 | AGL_CONV_Y_BF16 would write these extents as bf16: the few-input-channel stream kernel
 // (Cin <= 4, 1x1 / 3x3 "same") or the matrix-core patch kernel without a reduction split (the two kernels that have that store).

@@ -45,6 +45,8 @@ int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t 
 long pconv_stat_rows_max(int N, int OH, int OW);
 long pconv_stat_row_floats(int Cout);      // floats per partial row: [Cout][{count, mean, M2}]
 
+// Matrix-core products per fp32 multiply-add of the split arithmetic (nsplit 3) of this build: 3 (fp16 hi / lo planes) or 6 (bf16 x3)
+int pconv_split_products();
 // Bytes of workspace pconv needs for these extents (packed weights), 0 when the shape is not eligible.
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
 // ... plus the slabs of a reduction split when the output (out_numel floats) is small enough for one

@@ -25,12 +25,53 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Planes of the split (fp32-accurate) arithmetic, AGL_CONV_SPLIT3 at the ABI:
+//   3  three bf16 terms per operand, six products per multiply-add (rounds 2-4);
+//   2  fp16 hi / lo terms, THREE products (hi*hi into the main accumulator, hi*lo' + lo'*hi into a second one that is scaled back by
+//      2^-11 once): a = hi + lo' * 2^-11 with hi = fp16(a * 2^-s), lo' = fp16((a * 2^-s - hi) * 2^11) — 22-23 significant bits; the
+//      dropped lo*lo term is <= 2^-22 |ab| (rms 2^-24.6).  fp16 has 5 exponent bits, so every staged operand block carries a
+//      power-of-two scale: weights per 16-channel chunk (found when they are packed, stored behind the packed planes), activations
+//      per staged chunk / tile of a workgroup (absolute maximum of the registers it is about to convert, reduced over the workgroup);
+//      the accumulators live at a running scale that only grows (a rescale multiplies them by a power of two: exact).
+#ifndef AGL_SPLIT_PLANES
+#define AGL_SPLIT_PLANES 2
+#endif
+constexpr int SPL = AGL_SPLIT_PLANES;
+static_assert(SPL == 2 || SPL == 3, "split arithmetic: 2 (fp16 hi/lo, three products) or 3 (bf16 terms, six products) planes");
+int pconv_split_products() { return SPL == 2 ? 3 : 6; }
 
 namespace {
 
 constexpr int NT = 256;
 constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int H16_TOP = 14;      // a scaled block's absolute maximum lies in [2^14, 2^15): below fp16's 65504 with a binade to spare
+constexpr int H16_SMAX = 120;    // shifts are clamped to +-120 so that 2^-shift is a normal fp32
+
+// 2^e as a float, e in [-126, 127]
+__device__ __forceinline__ float exp2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+// shift s of a block whose largest magnitude has the bits `mbits` (sign cleared): block * 2^-s has its maximum in [2^14, 2^15)
+__device__ __forceinline__ int h16_shift(unsigned mbits) {
+  const int s = (int)(mbits >> 23) - 127 - H16_TOP;
+  return s < -H16_SMAX ? -H16_SMAX : (s > H16_SMAX ? H16_SMAX : s);
+}
+// v (already scaled) -> fp16 hi, fp16 lo' = (v - hi) * 2^11 (v - hi is exact in fp32)
+__device__ __forceinline__ void split_h16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+// maximum over the wave of an unsigned value (DPP within rows of 16 lanes, then the four row values through the scalar unit)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));    // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
 
 struct PArgs {
   const float* x; const u32x4* wp; const float* bias; const float* pos_mask; float* y;
@@ -55,6 +96,7 @@ struct PArgs {
   // optional few-channel 1x1 shortcut evaluated in the epilogue (FEAT 16): y += sc_b[m] + sum_c sc_w[m * sc_cin + c] * sc_x[img][c][pixel],
   // sc_x an (N, sc_cin <= 4, OH, OW) fp32 tensor — the learnable shortcut of the discriminators' first block (discriminator.py:43-44, :58-60)
   const float* sc_x; const float* sc_w; const float* sc_b; int sc_cin;
+  const int* wexp;       // NSPL 2 (fp16 hi / lo planes): shift of every 16-channel chunk of the packed weights (behind the planes)
 };
 
 // a = t0 + t1 + t2 with bf16 terms (each step's remainder is exact in fp32)
@@ -94,6 +136,61 @@ __device__ __forceinline__ void pack_piece(const float* __restrict__ w, u32x4* _
     wp[2 * per_plane + i] = __builtin_bit_cast(u32x4, t2);
   }
 }
+// fp16 hi / lo form (SPL == 2): ONE workgroup packs one 16-channel chunk cc — all its 2 * KK * mpad pieces — so that the chunk's scale
+// needs no second launch: pass 1 finds the largest magnitude of the chunk, pass 2 writes wp[plane][i] = {hi, lo'} of w * 2^-shift and
+// the shift goes to wexp[cc] (behind the planes; read by the consumer as a scalar per stage).  Source element of piece i as in pack_piece.
+__device__ __forceinline__ void pack_chunk_h16(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                                               int flip, int mpad, int phase4, long per_plane, int cc, unsigned* red) {
+  const long per_chunk = 2L * KK * mpad, i0 = (long)cc * per_chunk;
+  auto src_of = [&](long i, int& m, int& c0, int& st) {
+    m = (int)(i % mpad);
+    long r = i / mpad;
+    const int tap = (int)(r % KK); r /= KK;
+    c0 = 16 * (int)(r >> 1) + 8 * (int)(r & 1);
+    st = flip ? KK - 1 - tap : tap;
+    if (phase4) {
+      const int phase = tap >> 2, thp = (tap >> 1) & 1, twp = tap & 1;
+      st = ((((phase >> 1) + 1) & 1) + 2 * (1 - thp)) * 4 + (((phase & 1) + 1) & 1) + 2 * (1 - twp);
+    }
+  };
+  unsigned tm = 0;
+  for (long i = i0 + threadIdx.x; i < i0 + per_chunk; i += blockDim.x) {
+    int m, c0, st;
+    src_of(i, m, c0, st);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < Cin) tm = max(tm, __builtin_bit_cast(unsigned, w[(long)m * w_sm + (long)(c0 + j) * w_sc + st]) & 0x7fffffffu);
+  }
+  tm = wave_umax(tm);
+  __syncthreads();      // (red may still be read by the previous chunk of this workgroup: none today, one chunk per workgroup)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tm;
+  __syncthreads();
+  unsigned mx = 0;
+  for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mx = max(mx, red[q]);
+  const int sh = h16_shift(mx);
+  const float fac = exp2i(-sh);
+  if (threadIdx.x == 0) reinterpret_cast<int*>(wp + 2 * per_plane)[cc] = sh;
+  for (long i = i0 + threadIdx.x; i < i0 + per_chunk; i += blockDim.x) {
+    int m, c0, st;
+    src_of(i, m, c0, st);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (m < M && c0 + j < Cin) ? w[(long)m * w_sm + (long)(c0 + j) * w_sc + st] * fac : 0.f;
+      _Float16 a, b;
+      split_h16(v, a, b);
+      hi[j] = a; lo[j] = b;
+    }
+    wp[i] = __builtin_bit_cast(u32x4, hi);
+    wp[per_plane + i] = __builtin_bit_cast(u32x4, lo);
+  }
+}
+__global__ __launch_bounds__(256) void pack_weights_h16_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm,
+                                                          int w_sc, int flip, int mpad, int nch, int phase4) {
+  __shared__ unsigned red[4];
+  pack_chunk_h16(w, wp, M, Cin, KK, w_sm, w_sc, flip, mpad, phase4, (long)nch * 2 * KK * mpad, (int)blockIdx.x, red);
+}
 __global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
                                int flip, int mpad, int nch, int nsplit, int phase4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,6 +207,12 @@ __global__ void pack_many_k(const long long* __restrict__ d, int n) {
   const long b = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d[(long)mid * WD + 12] <= b) lo = mid; else hi = mid - 1; }
   const long long* r = d + (long)lo * WD;
+  if (r[9] == 2) {      // fp16 hi / lo planes: one workgroup per 16-channel chunk (row[13] = chunks)
+    __shared__ unsigned red[4];
+    pack_chunk_h16(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6],
+                   (int)r[7], (int)r[8], (int)r[10], r[11], (int)(b - r[12]), red);
+    return;
+  }
   const long i = (b - r[12]) * blockDim.x + threadIdx.x, per_plane = r[11];
   if (i >= per_plane) return;
   pack_piece(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7],
@@ -131,6 +234,10 @@ template <int NSPL> struct Pitch<4, 2, NSPL> { static constexpr int PWP = 8; sta
 template <int NSPL> struct Pitch<4, 1, NSPL> { static constexpr int PWP = 4; static constexpr int IMG_EXTRA = 0; };   // 1x1: pixels are consecutive pieces
 template <> struct Pitch<2, 2, 1> { static constexpr int PWP = 6; static constexpr int IMG_EXTRA = 2; };
 template <> struct Pitch<2, 2, 3> { static constexpr int PWP = 3; static constexpr int IMG_EXTRA = 0; };   // 2-way, fits two workgroups
+// (two fp16 planes leave room for the conflict-free pitches of the one-plane mode)
+template <int KS> struct Pitch<16, KS, 2> : Pitch<16, KS, 1> {};
+template <int KS> struct Pitch<8, KS, 2> : Pitch<8, KS, 1> {};
+template <> struct Pitch<2, 2, 2> : Pitch<2, 2, 1> {};
 
 // Stride 2: the patch is split by column parity ([half][parity][row][column/2]) so that a lane group again reads 16 distinct slots;
 // PWH = pitch of a parity plane row.
@@ -203,7 +310,8 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   constexpr int NA = NSPL * A_PLANE, AR = (NA + NT - 1) / NT;
   constexpr int WTM = BM / 64, WTN = BN / (32 * WNW);   // 32x32 accumulator tiles per wave (a wave covers BM/2 channels x BN/WNW pixels)
   static_assert(WTN >= 1, "tile too small for this many waves");
-  constexpr int NACC = NSPL == 3 ? 2 : 1;      // split mode: the five small products go to their own accumulator
+  constexpr int NACC = NSPL >= 2 ? 2 : 1;      // split modes: the small products go to their own accumulator
+  constexpr bool H16 = NSPL == 2;              // fp16 hi / lo planes with dynamic power-of-two scales (see SPL)
   constexpr int EP_PITCH = 36;                 // floats per row of the epilogue transpose tile (16-byte aligned rows)
   // DB: double buffering (where it does not cost a workgroup per CU).  With a second weight buffer the stores of stage s+1 need
   // no barrier of their own (one barrier per stage); a second patch buffer does the same for the once-per-chunk patch stores.
@@ -215,6 +323,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   constexpr bool DBA = DB && PB + 2 * AB <= LDS_CAP, DBB = DBA && 2 * PB + 2 * AB <= LDS_CAP;
   constexpr int STAGE_PIECES = (DBB ? 2 : 1) * PB + (DBA ? 2 : 1) * AB, EP_PIECES = (NTH / 64) * 32 * EP_PITCH / 4;   // 16-byte pieces
   __shared__ u32x4 lds[STAGE_PIECES > EP_PIECES ? STAGE_PIECES : EP_PIECES];
+  __shared__ unsigned wmax_s[H16 ? NTH / 64 : 1];      // H16: the waves' maxima of the chunk about to be converted
   u32x4* const Pl = lds;
   u32x4* const Al = lds + (DBB ? 2 : 1) * PB;
 
@@ -313,11 +422,51 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
   };
+  // H16: the input transform and the fused input ReLU are applied to the registers first, so that the chunk's maximum is that of the values
+  // that get converted; every wave publishes its maximum (sign bit cleared: magnitudes order like unsigned integers)
+  auto prep_b = [&]() {
+    if constexpr (H16) {
+      unsigned tm = 0;
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        if constexpr (F_FOLD) {
+          if (p.fold.scale && bsrc[r] != OOB31) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
+              const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
+              pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0], sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1], sc.y, sh.y);
+              pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2], sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3], sc.w, sh.w);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (p.in_relu) pb[r][j] = fmaxf(pb[r][j], 0.f);
+          tm = max(tm, __builtin_bit_cast(unsigned, pb[r][j]) & 0x7fffffffu);
+        }
+      }
+      tm = wave_umax(tm);
+      if (lane == 0) wmax_s[wave] = tm;
+    }
+  };
+  // H16: running shift of the accumulators (acc = sum x * w * 2^-S_run, workgroup-uniform, never decreases) and the factor 2^-sx the chunk
+  // being staged is converted with, sx = S_run - wexp[chunk] >= its own shift.  Called by every thread after the barrier that follows prep_b.
+  int S_run = -(1 << 20);
+  float bfac = 1.f;
   auto sstore_b = [&](int buf) {
     u32x4* const Pl = lds + buf;
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       if (bdst[r] < 0) continue;
+      if constexpr (H16) {      // (transform and ReLU already applied by prep_b)
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 a, b; split_h16(pb[r][j] * bfac, a, b); hi[j] = a; lo[j] = b; }
+        Pl[bdst[r]] = __builtin_bit_cast(u32x4, hi);
+        Pl[P_PLANE + bdst[r]] = __builtin_bit_cast(u32x4, lo);
+        continue;
+      }
       if constexpr (BLK) {
         u32x4 v = pq[r];
         if (p.in_relu) {      // ReLU on the stored bf16 pairs: a set sign bit clears its 16-bit half
@@ -383,6 +532,66 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] = 0.f;
   auto& acc = accs[0];
+  // H16, tiles of <= 2 accumulator blocks per wave: the hi*hi accumulator is emptied into a total (plain fp32 additions, round to nearest)
+  // after every channel chunk.  The matrix unit aligns the 16 products and the accumulator of an instruction to the largest of them and cuts
+  // every addend 3 bits below that one's last place (tools/probe/mfma_f16_numerics.hip): a 22-bit fp16 product loses bits against a large
+  // accumulator where a 16-bit bf16 product does not, and on long reductions (Cin * taps >= 2000) that error, not the operand split,
+  // decided the distance to fp64 (2.2-3.3x the exact fp32 kernel's; 0.3-1.1x with short chains).  The cross-term accumulator may run
+  // long: its errors are scaled by 2^-11.
+  // (Only where the total fits the register budget: <= 2 blocks at 256 threads, 1 at 512 — the four-block tiles spill with it, and
+  // pconv_plan keeps long reductions off them.)
+  constexpr bool FLUSH = H16 && NPW * WTM * WTN * (NTH / 256) <= 2;
+  constexpr int FLUSH_EVERY = (PHS ? 4 : KK) >= 32 ? 1 : 32 / (PHS ? 4 : KK);      // chunks per flush: chains of <= ~32-36 instructions
+  f32x16 tot[FLUSH ? NPW : 1][FLUSH ? WTM : 1][FLUSH ? WTN : 1];
+  if constexpr (FLUSH) {
+#pragma unroll
+    for (int w = 0; w < NPW; ++w)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[w][i][j][r] = 0.f;
+  }
+  auto scale_b = [&](int chunk) {
+    if constexpr (H16) {
+      unsigned m = wmax_s[0];
+#pragma unroll
+      for (int q = 1; q < NTH / 64; ++q) m = max(m, wmax_s[q]);
+      m = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+      const int sw = p.wexp[chunk];
+      int Sn = max(S_run, h16_shift(m) + sw), sx = Sn - sw;
+      if (sx < -H16_SMAX) { sx = -H16_SMAX; Sn = sx + sw; }      // (everything so far is tiny: a larger shift than needed, still consistent)
+      bfac = sx > H16_SMAX ? 0.f : exp2i(-sx);                    // (a chunk 2^-100 below the running scale contributes nothing)
+      if (Sn != S_run) {
+        if (S_run > -(1 << 19)) {      // the accumulators hold products at the old scale: *= 2^(old - new), exact
+          const int d = S_run - Sn;
+          const float f = d < -126 ? 0.f : exp2i(d);
+#pragma unroll
+          for (int w = 0; w < NPW; ++w)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+              for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) accs[w][a][i][j][r] *= f;
+          if constexpr (FLUSH) {
+#pragma unroll
+            for (int w = 0; w < NPW; ++w)
+#pragma unroll
+              for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) tot[w][i][j][r] *= f;
+          }
+        }
+        S_run = Sn;
+      }
+    }
+  };
 
   // Stagger (speed only): the two workgroups that share a CU start together, run the same program for the same time and so
   // stay in lockstep — both in their matrix segment (sharing the pipe), then both in their staging segment (pipe idle).  The
@@ -403,6 +612,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   const int nstage = nchunk * NTG;     // stage s = (channel chunk s / NTG, tap group s % NTG)
   gload_b(16 * c_lo);
   gload_a(c_lo, PHS ? phase : 0);
+  if constexpr (H16) { prep_b(); __syncthreads(); scale_b(c_lo); }
   sstore_b(0);
   sstore_a(0);
   __syncthreads();
@@ -440,6 +650,15 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             if constexpr (NSPL == 3) asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][jt]), "v"(fa[2][i]), "v"(fb[2][jt]));
             continue;
           }
+          if constexpr (H16) {      // hi*hi; the two cross terms (2^11 too large: scaled back once at the end) accumulate apart
+            const f16x8 ah = __builtin_bit_cast(f16x8, fa[0][i]), al = __builtin_bit_cast(f16x8, fa[1][i]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, fb[0][jt]), bl = __builtin_bit_cast(f16x8, fb[1][jt]);
+            accs[pw][0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accs[pw][0][i][jt], 0, 0, 0);
+            f32x16& lo = accs[pw][1][i][jt];
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, lo, 0, 0, 0);
+            continue;
+          }
           accs[pw][0][i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][jt], accs[pw][0][i][jt], 0, 0, 0);
           if constexpr (NSPL == 3) {      // the small terms (<= 2^-8 of the leading one) accumulate apart: their rounding errors
             f32x16& lo = accs[pw][NACC - 1][i][jt];   // are 2^-8 smaller and the leading chain sees one rounding per K-step
@@ -452,8 +671,24 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         }
     }
     // a buffer that is about to be overwritten may still be read by a slower wave unless it is the other one of a pair
+    const bool stb = H16 && last_tg && s + 1 < nstage;      // H16: the next chunk's patch is converted at the end of this stage
+    if constexpr (FLUSH) {
+      if (last_tg && (FLUSH_EVERY == 1 || (cc + 1) % FLUSH_EVERY == 0)) {
+#pragma unroll
+        for (int w = 0; w < NPW; ++w)
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { tot[w][i][j][r] += accs[w][0][i][j][r]; accs[w][0][i][j][r] = 0.f; }
+      }
+    }
+    if (stb) prep_b();
     if constexpr (!DBA) __syncthreads();
     else if constexpr (!DBB) { if (last_tg) __syncthreads(); }
+    else { if (stb) __syncthreads(); }                       // (the waves' maxima cross the workgroup)
+    if (stb) scale_b(c_lo + cc + 1);
     if (s + 1 < nstage && !(ABL & 16)) {      // (the last stage's prefetch is a dummy: nothing to convert or store)
       if (last_tg) sstore_b(DBB ? ((cc + 1) & 1) * PB : 0);
       sstore_a(DBA ? ((s + 1) & 1) * AB : 0);
@@ -469,6 +704,19 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) accs[w][0][i][j][r] += accs[w][1][i][j][r];
+  }
+  if constexpr (H16) {
+#pragma unroll
+    for (int w = 0; w < NPW; ++w)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (FLUSH) accs[w][0][i][j][r] += tot[w][i][j][r];
+            accs[w][0][i][j][r] = fmaf(accs[w][1][i][j][r], 1.0f / 2048.0f, accs[w][0][i][j][r]);
+          }
   }
 
   // ---- epilogue.  D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel) — a lane holds 16
@@ -535,6 +783,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
       for (int ps = 0; ps < 4; ++ps) {
         v[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
         v[ps].x *= osc; v[ps].y *= osc; v[ps].z *= osc; v[ps].w *= osc;
+        if constexpr (H16) {      // back from the accumulators' running scale
+          v[ps].x = __builtin_ldexpf(v[ps].x, S_run); v[ps].y = __builtin_ldexpf(v[ps].y, S_run);
+          v[ps].z = __builtin_ldexpf(v[ps].z, S_run); v[ps].w = __builtin_ldexpf(v[ps].w, S_run);
+        }
       }
       const int mb = bm0 + wm * (BM / 2) + 32 * i + er;
       if constexpr (PAIR) {       // both column phases: pixel (a, b..b+3) -> row 2a+ph, columns 2b .. 2b+7 — two 16-byte stores
@@ -545,6 +797,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         for (int ps = 0; ps < 4; ++ps) {
           v1[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * EP_PITCH + ec);
           v1[ps].x *= osc; v1[ps].y *= osc; v1[ps].z *= osc; v1[ps].w *= osc;
+          if constexpr (H16) {
+            v1[ps].x = __builtin_ldexpf(v1[ps].x, S_run); v1[ps].y = __builtin_ldexpf(v1[ps].y, S_run);
+            v1[ps].z = __builtin_ldexpf(v1[ps].z, S_run); v1[ps].w = __builtin_ldexpf(v1[ps].w, S_run);
+          }
         }
         // (odd-sized outputs — 33 x 33, 65 x 65 — have rows that are only 4-byte aligned: under-aligned vector type)
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -848,7 +1104,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // AUX: the bf16 dy operand (WArgs::dy_bf16) and the input transform of x (WArgs::fold) compiled in — the 4x4 / stride-2 family only
 // (weight gradients of ConvTranspose2d(4, 2, 1) and of the folded encoder convolutions); see pconv_k's FEAT for why not everywhere.
 template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS, bool AUX = false>
-__global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
+__global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
   static_assert((NPX == 128 || NPX == 64) && TW >= 4, "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy pieces are two full rows)
@@ -856,8 +1112,10 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
   constexpr int XROW = 2 * BC;                          // bytes per patch pixel
   constexpr int D_PLANE = BMCO * DPITCH, X_PLANE = NQ * XROW;
-  constexpr int NACC = NSPL == 3 ? 2 : 1;
+  constexpr int NACC = NSPL >= 2 ? 2 : 1;
+  constexpr bool H16 = NSPL == 2;      // fp16 hi / lo planes, three products, power-of-two scales per staged tile (see SPL)
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSPL * (D_PLANE + X_PLANE)];
+  __shared__ unsigned wmax_s[H16 ? 2 * (NT / 64) : 1];      // H16: the waves' maxima of the dy tile and of the x patch about to be converted
   unsigned char* const Dl = lds;
   unsigned char* const Xl = lds + NSPL * D_PLANE;
   // bias gradient (sum of dy over the pixels, per output channel): the 16 consecutive lanes that stage the 8-pixel pieces of one
@@ -973,6 +1231,9 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       }
     }
   };
+  // H16: conversion factors of the tile being staged and the running shift of the accumulators (acc = sum dy * x * 2^-S_run; workgroup-uniform)
+  float dfac = 1.f, xfac = 1.f;
+  int S_run = -(1 << 20);
   auto sstore_dy = [&](int r, int sl) {
     {
       const int e = tid + NT * r;
@@ -986,13 +1247,21 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
         for (int o = 1; o < NPX / 8; o <<= 1) sm += __shfl_xor(sm, o);
         if (oc == 0) lbias[co] += sm;
       }
+      unsigned char* dst = Dl + co * DPITCH + oc * 16;
+      if constexpr (H16) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { _Float16 a, b; split_h16(v[q] * dfac, a, b); hi[q] = a; lo[q] = b; }
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(dst + D_PLANE) = __builtin_bit_cast(u32x4, lo);
+        return;
+      }
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if constexpr (NSPL == 1) { t0[q] = (__bf16)v[q]; }
         else { __bf16 a, b, d; split3(v[q], a, b, d); t0[q] = a; t1[q] = b; t2[q] = d; }
       }
-      unsigned char* dst = Dl + co * DPITCH + oc * 16;
       *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, t0);
       if constexpr (NSPL == 3) {
         *reinterpret_cast<u32x4*>(dst + D_PLANE) = __builtin_bit_cast(u32x4, t1);
@@ -1006,6 +1275,15 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int e = tid + NT * r;
       if (NXI % NT != 0 && e >= NXI) return;
       const int oc = e / NQ, q = e - oc * NQ;
+      if constexpr (H16) {      // (input transform and ReLU already applied to the registers by prep_tile)
+        f16x8 hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { _Float16 a, b; split_h16(px[sl][jj] * xfac, a, b); hi[jj] = a; lo[jj] = b; }
+        unsigned char* dst = Xl + q * XROW + oc * 16;
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(dst + X_PLANE) = __builtin_bit_cast(u32x4, lo);
+        return;
+      }
       if constexpr (AUX) {
         if (p.fold.scale && pxin[sl]) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS (see pconv_k)
           const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
@@ -1035,7 +1313,71 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     }
   };
 
-  constexpr bool PREF = NSPL == 3 || RT * CT == 1;     // (the 2x2-fragment bf16 variants have no registers to spare)
+  constexpr bool PREF = NSPL >= 2 || RT * CT == 1;
+  static_assert(!H16 || PREF, "the fp16 split form converts from the prefetch registers");
+  // H16: fold / ReLU on the prefetched x registers, then the maxima of the dy tile and the x patch (per wave; combined by scale_tile after
+  // the barrier that follows)
+  auto prep_tile = [&]() {
+    if constexpr (H16) {
+      unsigned md = 0, mx = 0;
+#pragma unroll
+      for (int r = 0; r < DR; ++r) {
+        const float v[8] = {pdy[r][0].x, pdy[r][0].y, pdy[r][0].z, pdy[r][0].w, pdy[r][1].x, pdy[r][1].y, pdy[r][1].z, pdy[r][1].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) md = max(md, __builtin_bit_cast(unsigned, v[q]) & 0x7fffffffu);
+      }
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        if constexpr (AUX) {
+          if (p.fold.scale && pxin[r]) {
+            const int e = min(tid + NT * r, NXI - 1), oc = e / NQ, q = e - oc * NQ;
+            const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
+              const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
+              px[r][4 * hq + 0] = fmaf(px[r][4 * hq + 0], sc.x, sh.x); px[r][4 * hq + 1] = fmaf(px[r][4 * hq + 1], sc.y, sh.y);
+              px[r][4 * hq + 2] = fmaf(px[r][4 * hq + 2], sc.z, sh.z); px[r][4 * hq + 3] = fmaf(px[r][4 * hq + 3], sc.w, sh.w);
+            }
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          if (p.in_relu) px[r][jj] = fmaxf(px[r][jj], 0.f);
+          mx = max(mx, __builtin_bit_cast(unsigned, px[r][jj]) & 0x7fffffffu);
+        }
+      }
+      md = wave_umax(md); mx = wave_umax(mx);
+      if (lane == 0) { wmax_s[wave] = md; wmax_s[NT / 64 + wave] = mx; }
+    }
+  };
+  auto scale_tile = [&]() {
+    if constexpr (H16) {
+      unsigned md = 0, mx = 0;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) { md = max(md, wmax_s[q]); mx = max(mx, wmax_s[NT / 64 + q]); }
+      md = (unsigned)__builtin_amdgcn_readfirstlane((int)md); mx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+      const int sd = h16_shift(md);
+      const int Sn = max(S_run, sd + h16_shift(mx)), sx = Sn - sd;
+      dfac = exp2i(-sd);
+      xfac = sx > H16_SMAX ? 0.f : exp2i(-sx);      // (a tile 2^-100 below the running scale contributes nothing)
+      if (Sn != S_run) {
+        if (S_run > -(1 << 19)) {
+          const int d = S_run - Sn;
+          const float f = d < -126 ? 0.f : exp2i(d);
+#pragma unroll
+          for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+              for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int t = 0; t < TSUB; ++t) acc[a][i][j][t] *= f;
+        }
+        S_run = Sn;
+      }
+    }
+  };     // (the 2x2-fragment bf16 variants have no registers to spare)
   auto gload = [&](int tile) {
     int img0, ty0, tx0;
     tile_origin(tile, img0, ty0, tx0);
@@ -1047,7 +1389,9 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   };
   if (PREF && t_beg < t_end) gload(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
+    prep_tile();
     __syncthreads();                                   // everyone is done reading the previous tile
+    scale_tile();
     if constexpr (PREF) {
 #pragma unroll
       for (int r = 0; r < DR; ++r) sstore_dy(r, r);
@@ -1092,6 +1436,15 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
           }
 #pragma unroll
           for (int i = 0; i < RT; ++i) {
+            if constexpr (H16) {
+              const f16x8 ah = __builtin_bit_cast(f16x8, fa[0][i]), al = __builtin_bit_cast(f16x8, fa[1][i]);
+              const f16x8 bh = __builtin_bit_cast(f16x8, fb[0]), bl = __builtin_bit_cast(f16x8, fb[1]);
+              acc[0][i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[0][i][j][t], 0, 0, 0);
+              f32x4& lo = acc[1][i][j][t];
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, lo, 0, 0, 0);
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, lo, 0, 0, 0);
+              continue;
+            }
             acc[0][i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0], acc[0][i][j][t], 0, 0, 0);
             if constexpr (NSPL == 3) {
               f32x4& lo = acc[NACC - 1][i][j][t];
@@ -1128,6 +1481,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
             if (tap0 + t >= KK) break;
             float v = acc[0][i][j][t][r];
             if constexpr (NSPL == 3) v += acc[1][i][j][t][r];
+            if constexpr (H16) v = __builtin_ldexpf(fmaf(acc[1][i][j][t][r], 1.0f / 2048.0f, v), S_run);
             o[tap0 + t] = acc_out ? o[tap0 + t] + v : v;
           }
         }
@@ -1136,9 +1490,12 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
 
 }  // namespace
 
+// planes of a packed weight buffer for the ABI-level nsplit (1 or 3), and the bytes behind them (H16: one shift per 16-channel chunk)
+static inline int pack_planes(int nsplit) { return nsplit == 3 ? SPL : 1; }
+static inline long pack_tail_bytes(int nch, int nsplit) { return (nsplit == 3 && SPL == 2) ? (long)round_up(nch * 4, 16) : 0; }
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
   if (!(ks == 1 || ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
-  return (long)nsplit * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16;
+  return (long)pack_planes(nsplit) * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16 + pack_tail_bytes(Cin / 16, nsplit);
 }
 constexpr int kPconvMaxSplits = 8;
 // ... plus room for the slabs of a reduction split of a small output (out_numel floats per slab)
@@ -1179,14 +1536,17 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   // without work; nsplit 3: 64 x 128 (three LDS planes).  Stride 2 (patch = 4x the tile): 128 pixels, 64 in split mode.
   const long px128 = geo == 0 ? (long)a.N * (oh / 8) * (ow / 16) : (geo == 1 ? agl_cdiv(a.N, 2) : (geo == 5 ? agl_cdiv(a.N, 32) : agl_cdiv(a.N, 8)));
   int bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
+  // fp16 hi / lo split form: reductions of more than 64 (chunk, tap) steps stay on the two-block tiles, whose hi*hi accumulator is emptied
+  // into an fp32 total every ~32 steps (pconv_k FLUSH) — on a long chain the matrix unit's addend truncation would decide the error
+  const bool long_k = a.nsplit == 3 && SPL == 2 && (long)(a.Cin / 16) * a.ks * a.ks > 64;
   // 1x1: bandwidth-bound — read the input once per 128 output channels where that still leaves a workgroup per CU
   if (a.ks == 1 && a.Cout > 64 && px128 * agl_cdiv(a.Cout, 128) >= 256) bm = 128;
   // 3x3 split mode: 128 output channels per workgroup (one kernel row of weights per stage) halve the conversions and patch
   // reads per MFMA where the grid stays full: -3..-13 % per layer
-  if (a.nsplit == 3 && !s2 && a.ks == 3 && geo != 2 && a.Cout >= 128 && px128 * agl_cdiv(a.Cout, 128) >= 512) bm = 128;
+  if (a.nsplit == 3 && !s2 && a.ks == 3 && geo != 2 && a.Cout >= 128 && px128 * agl_cdiv(a.Cout, 128) >= 512 && !long_k) bm = 128;
   const bool w32 = ow % 32 == 0 && a.ks != 1;                 // geo 0: 8 x 32 (wide) / 4 x 32 tiles; else 16 x 16 (wide) / 8 x 16
   // 256-pixel tiles: bf16 mode, and the 64-channel 3x3 layers of the split mode (one kernel row of weights per stage; -2..-12 %)
-  bool wide = !s2 && geo != 3 && a.ks != 1 && (a.nsplit == 1 || (a.ks == 3 && bm == 64 && geo == 0)) && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512;
+  bool wide = !s2 && geo != 3 && a.ks != 1 && (a.nsplit == 1 || (a.ks == 3 && bm == 64 && geo == 0)) && (px128 / 2) * agl_cdiv(a.Cout, bm) >= 512 && !long_k;
   if (geo == 0 && wide && !w32 && oh % 16 != 0) wide = false;
   const bool half = s2 && a.nsplit == 3;           // 64-pixel tiles
   long ptiles;
@@ -1284,6 +1644,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend; p.blk = a.blocked;
   if (a.blocked && !pconv_takes_blocked(a)) return -1;
   p.sc_x = a.sc_x; p.sc_w = a.sc_w; p.sc_b = a.sc_b; p.sc_cin = a.sc_cin;
+  p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * KK * mpad);      // (read by the H16 instantiations only)
   if (a.sc_x && !(a.ks == 3 && !s2 && a.nsplit == 1 && bm == 64 && geo != 2 && pl.splits == 1 && a.sc_cin >= 1 && a.sc_cin <= 4 && a.OW % 4 == 0))
     return -1;                                                       // (compiled into the bf16 3x3 stride-1 instantiations with 64-channel tiles)
   if ((a.y_bf16 || a.addend) && pl.splits > 1) return -1;            // (... writes fp32 in place)
@@ -1315,18 +1676,18 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   } while (0)
 #define PC_SHAPES3(KS_, TG_)                                                                             \
   do {                                                                                                   \
-    if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, 64, 3, TG_);                                                \
-    else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 4, 1, 64, 3, TG_);                                   \
-    else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 8, 1, 64, 3, TG_);                                          \
-    else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 2, 64, 3, TG_);                                           \
+    if (geo == 3) PC_LAUNCH(KS_, 1, 8, 8, 1, 64, SPL, TG_);                                                \
+    else if (geo == 0 && w32) PC_LAUNCH(KS_, 1, 32, 4, 1, 64, SPL, TG_);                                   \
+    else if (geo == 0) PC_LAUNCH(KS_, 1, 16, 8, 1, 64, SPL, TG_);                                          \
+    else if (geo == 1) PC_LAUNCH(KS_, 1, 8, 8, 2, 64, SPL, TG_);                                           \
   } while (0)
 #define PC_STRIDE2(F_, KS_, TG_)                                                                         \
   do {                                                                                                   \
     if (a.nsplit == 3) {                                                                                 \
-      if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 4, 1, 64, 3, TG_);                                       \
-      else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 1, 64, 3, TG_);                                   \
-      else if (geo == 5) PC_LAUNCH_F(F_, KS_, 2, 2, 2, 16, 64, 3, TG_);                                  \
-      else PC_LAUNCH_F(F_, KS_, 2, 4, 4, 4, 64, 3, TG_);                                                 \
+      if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 4, 1, 64, SPL, TG_);                                       \
+      else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 1, 64, SPL, TG_);                                   \
+      else if (geo == 5) PC_LAUNCH_F(F_, KS_, 2, 2, 2, 16, 64, SPL, TG_);                                  \
+      else PC_LAUNCH_F(F_, KS_, 2, 4, 4, 4, 64, SPL, TG_);                                                 \
     } else if (bm == 128) {                                                                              \
       if (geo == 0) PC_LAUNCH_F(F_, KS_, 2, 16, 8, 1, 128, 1, TG_);                                      \
       else if (geo == 1) PC_LAUNCH_F(F_, KS_, 2, 8, 8, 2, 128, 1, TG_);                                  \
@@ -1348,10 +1709,10 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   if (s2) {
     if (a.ks == 4) { if (feat42) PC_STRIDE2(3, 4, 4); else PC_STRIDE2(0, 4, 4); } else PC_STRIDE2(0, 3, 3);
   } else if (a.ks == 1) {
-    if (a.nsplit == 3) { if (bm == 128) PC_1X1(0, 128, 3); else PC_1X1(0, 64, 3); }
+    if (a.nsplit == 3) { if (bm == 128) PC_1X1(0, 128, SPL); else PC_1X1(0, 64, SPL); }
     else if (featy) { if (bm == 128) PC_1X1(4, 128, 1); else PC_1X1(4, 64, 1); }
     else { if (bm == 128) PC_1X1(0, 128, 1); else PC_1X1(0, 64, 1); }
-  } else if (a.ablate > 0 && a.ks == 3 && a.nsplit == 3 && wide && w32) {      // diagnostic builds of ONE geometry (tools/ablate.sh)
+  } else if (SPL == 3 && a.ablate > 0 && a.ks == 3 && a.nsplit == 3 && wide && w32) {      // diagnostic builds of ONE geometry (tools/ablate.sh)
 #define PC_ABL(A_) hipLaunchKernelGGL((pconv_k<3, 1, 32, 8, 1, 64, 3, 3, false, false, 256, A_>), g, dim3(256), 0, st, p)
     switch (a.ablate) {
       case 1: PC_ABL(1); break; case 2: PC_ABL(2); break; case 4: PC_ABL(4); break; case 8: PC_ABL(8); break;
@@ -1371,23 +1732,23 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     }
 #undef PC_ABL
   } else if (w8 && a.ks == 3) {
-    if (wide) { if (w32) PC_LAUNCH8(3, 1, 32, 8, 1, 64, 3, 3, false); else PC_LAUNCH8(3, 1, 16, 16, 1, 64, 3, 3, false); }
+    if (wide) { if (w32) PC_LAUNCH8(3, 1, 32, 8, 1, 64, SPL, 3, false); else PC_LAUNCH8(3, 1, 16, 16, 1, 64, SPL, 3, false); }
     else if (bm == 128) {
-      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 128, 3, 3, false);
-      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 128, 3, 3, false);
-      else PC_LAUNCH8(3, 1, 8, 8, 2, 128, 3, 3, false);
+      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 128, SPL, 3, false);
+      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 128, SPL, 3, false);
+      else PC_LAUNCH8(3, 1, 8, 8, 2, 128, SPL, 3, false);
     } else {
-      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 64, 3, 9, false);
-      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 64, 3, 9, false);
-      else PC_LAUNCH8(3, 1, 8, 8, 2, 64, 3, 9, false);
+      if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 64, SPL, 9, false);
+      else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 64, SPL, 9, false);
+      else PC_LAUNCH8(3, 1, 8, 8, 2, 64, SPL, 9, false);
     }
   } else if (w8 && a.ks == 5) {
-    if (geo == 0 && w32) PC_LAUNCH8(5, 1, 32, 4, 1, 64, 3, 5, true);
-    else if (geo == 0) PC_LAUNCH8(5, 1, 16, 8, 1, 64, 3, 5, true);
-    else PC_LAUNCH8(5, 1, 8, 8, 2, 64, 3, 5, true);
+    if (geo == 0 && w32) PC_LAUNCH8(5, 1, 32, 4, 1, 64, SPL, 5, true);
+    else if (geo == 0) PC_LAUNCH8(5, 1, 16, 8, 1, 64, SPL, 5, true);
+    else PC_LAUNCH8(5, 1, 8, 8, 2, 64, SPL, 5, true);
   } else if (a.ks == 3) {
     if (geo == 2) {
-      if (a.nsplit == 3) PC_LAUNCH_DB(3, 1, 4, 4, 8, 64, 3, 3);    // one kernel row per stage, two weight + two patch buffers
+      if (a.nsplit == 3) PC_LAUNCH_DB(3, 1, 4, 4, 8, 64, SPL, 3);    // one kernel row per stage, two weight + two patch buffers
       else if (featy) {
         if (wide) { if (bm == 128) PC_LAUNCH_F(4, 3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH_F(4, 3, 1, 4, 4, 16, 64, 1, 9); }
         else { if (bm == 128) PC_LAUNCH_F(4, 3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH_F(4, 3, 1, 4, 4, 8, 64, 1, 9); }
@@ -1399,21 +1760,21 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
     else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
-    else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, 3, 3); else PC_LAUNCH(3, 1, 16, 16, 1, 64, 3, 3); }
+    else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, SPL, 3); else PC_LAUNCH(3, 1, 16, 16, 1, 64, SPL, 3); }
     else if (bm == 128) {
-      if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, 3, 3);
-      else if (geo == 0 && w32) PC_LAUNCH(3, 1, 32, 4, 1, 128, 3, 3);
-      else if (geo == 0) PC_LAUNCH(3, 1, 16, 8, 1, 128, 3, 3);
-      else PC_LAUNCH(3, 1, 8, 8, 2, 128, 3, 3);
+      if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, SPL, 3);
+      else if (geo == 0 && w32) PC_LAUNCH(3, 1, 32, 4, 1, 128, SPL, 3);
+      else if (geo == 0) PC_LAUNCH(3, 1, 16, 8, 1, 128, SPL, 3);
+      else PC_LAUNCH(3, 1, 8, 8, 2, 128, SPL, 3);
     }
     else PC_SHAPES3(3, 9);
   } else {
     if (a.nsplit == 1 && feat5) { if (bm == 128) PC_SHAPES1F(2, 5, 128, 5); else PC_SHAPES1F(2, 5, 64, 5); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
-    else if (geo == 3) PC_LAUNCH_DB(5, 1, 8, 8, 1, 64, 3, 5);
-    else if (geo == 0 && w32) PC_LAUNCH_DB(5, 1, 32, 4, 1, 64, 3, 5);
-    else if (geo == 0) PC_LAUNCH_DB(5, 1, 16, 8, 1, 64, 3, 5);
-    else if (geo == 1) PC_LAUNCH_DB(5, 1, 8, 8, 2, 64, 3, 5);
+    else if (geo == 3) PC_LAUNCH_DB(5, 1, 8, 8, 1, 64, SPL, 5);
+    else if (geo == 0 && w32) PC_LAUNCH_DB(5, 1, 32, 4, 1, 64, SPL, 5);
+    else if (geo == 0) PC_LAUNCH_DB(5, 1, 16, 8, 1, 64, SPL, 5);
+    else if (geo == 1) PC_LAUNCH_DB(5, 1, 8, 8, 2, 64, SPL, 5);
   }
 #undef PC_STRIDE2
 #undef PC_1X1
@@ -1435,7 +1796,8 @@ void pconv_pack_desc(const float* w, void* packed, int M, int Cred, int ks, int 
   const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
   const long per_plane = (long)nch * 2 * KK * mpad;
   row[0] = (long long)(uintptr_t)w; row[1] = (long long)(uintptr_t)packed; row[2] = M; row[3] = Cred; row[4] = KK; row[5] = w_sm; row[6] = w_sc;
-  row[7] = flip; row[8] = mpad; row[9] = nsplit; row[10] = phase4; row[11] = per_plane; row[12] = 0; row[13] = (per_plane + 255) / 256;
+  row[7] = flip; row[8] = mpad; row[9] = pack_planes(nsplit); row[10] = phase4; row[11] = per_plane; row[12] = 0;
+  row[13] = pack_planes(nsplit) == 2 ? nch : (per_plane + 255) / 256;      // (fp16 hi / lo form: one workgroup per 16-channel chunk)
 }
 int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t st, const char* name) {
   hipLaunchKernelGGL(pack_many_k, dim3((unsigned)total_blocks), dim3(256), 0, st, (const long long*)rows_dev, n);
@@ -1446,8 +1808,11 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
                const char* name) {
   const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
   const long per_plane = (long)nch * 2 * KK * mpad;
-  hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
-                     flip, mpad, nch, nsplit, phase4);
+  if (pack_planes(nsplit) == 2)
+    hipLaunchKernelGGL(pack_weights_h16_k, dim3((unsigned)nch), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc, flip, mpad, nch, phase4);
+  else
+    hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
+                       flip, mpad, nch, nsplit, phase4);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
 }
@@ -1539,6 +1904,7 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
+  p.wexp = nullptr; p.blk = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * (a.x_bf16 ? 2 : 4));
   if (a.x_bf16 && a.nsplit != 1) return -1;
   if (a.nsplit == 1) {
@@ -1596,7 +1962,7 @@ bool pconvT_takes_bf16_mask(const PConvArgs& a) {
 }
 long pconvT_ws_bytes(int Cred, int Crow, int nsplit) {
   if (Cred % 16 != 0 || Crow < 48) return 0;
-  return (long)nsplit * (Cred / 16) * 2 * 16 * round_up(Crow, 128) * 16;
+  return (long)pack_planes(nsplit) * (Cred / 16) * 2 * 16 * round_up(Crow, 128) * 16 + pack_tail_bytes(Cred / 16, nsplit);
 }
 long pconvT_ws_bytes_split(int Cred, int Crow, int nsplit, long out_numel) {
   const long packed = pconvT_ws_bytes(Cred, Crow, nsplit);
@@ -1624,6 +1990,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.pad = 0; p.up = 0; p.in_relu = 0; p.relu = a.relu; p.accumulate = a.accumulate; p.nch = nch; p.mpad = mpad; p.stats = nullptr;
   p.slabs = nullptr; p.cps = nch; p.out_numel = out_numel; p.oh2 = a.OH; p.ow2 = a.OW;
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
+  p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * 16 * mpad);
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
   if (a.x_bf16 && a.nsplit != 1) return -1;
   // bf16 ReLU mask: the paired-phase epilogue of the bf16 instantiations (16-byte pieces of 8 mask elements), no reduction split, even size
@@ -1648,7 +2015,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
     else PT_LAUNCH_M(4, 4, 8, BM_);                               \
   } while (0)
   if (a.mask_bf16) { if (bm == 128) PT_GEO_M(128); else PT_GEO_M(64); }
-  else if (a.nsplit == 3) PT_GEO(64, 3);
+  else if (a.nsplit == 3) PT_GEO(64, SPL);
   else if (bm == 128) PT_GEO(128, 1);
   else PT_GEO(64, 1);
 #undef PT_GEO_M
@@ -1807,20 +2174,20 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   } while (0)
   // (bf16 mode launches the 64 x 16 block only — pbww_plan; 1x1 keeps its 64 x 32 block)
   if (a.stride == 2) {
-    if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, 3); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
-    else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, 3); else PW_LAUNCH(4, 2, 1, 1, 1); }
-    else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, 3); else PW_LAUNCH(3, 2, 1, 1, 1); }
+    if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, SPL); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
+    else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, SPL); else PW_LAUNCH(4, 2, 1, 1, 1); }
+    else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, SPL); else PW_LAUNCH(3, 2, 1, 1, 1); }
   } else if (a.ks == 1) {
-    if (a.nsplit == 3) { if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 3); else PW_LAUNCH(1, 1, 1, 1, 3); }
+    if (a.nsplit == 3) { if (ct == 2) PW_LAUNCH(1, 1, 1, 2, SPL); else PW_LAUNCH(1, 1, 1, 1, SPL); }
     else if (ct == 2) PW_LAUNCH(1, 1, 1, 2, 1); else PW_LAUNCH(1, 1, 1, 1, 1);
   } else if (a.ks == 3 && a.nsplit == 1) {
     PW_LAUNCH1(3, 1, 1, 1);
-  } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, 3);
+  } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, SPL);
   else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
   else {
-    if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
-    else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 3, 25>), g, dim3(NT), 0, st, p);
+    if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);
   }
 #undef PW_LAUNCH1
 #undef PW_LAUNCH_AUX

@@ -257,6 +257,10 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             fence()
             serial_ms = 1e3 * (time.perf_counter() - t1) / 3
     if not a.no_roofline and rank == 0:
+        from agl import lib as _L
+        sp = _L.load().agl_conv2d_split_products()      # matrix-core products per fp32 multiply-add of the split arithmetic of this build
+        PIPE_PEAK[3] = PEAK_BF16_MFMA_TFLOPS / sp
+        PIPE_NAME[3] = ("fp16 MFMA, hi/lo split operands (3 products per MAC)" if sp == 3 else "bf16 MFMA, split operands (6 products per MAC)")
         conv = [e for e in log if e[0] in CONV_NAMES]
         conv_ms = sum(e[1].elapsed_time(e[2]) for e in conv)
         executed = sum(e[3] for e in conv)

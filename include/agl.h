@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 6
+#define AGL_ABI_VERSION 7
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -40,11 +40,16 @@ const char* agl_last_error(void);
  *   AGL_CONV_NO_PATCH    never use the LDS-patch kernel (A/B tests);  AGL_CONV_NO_PATCH_S2: not its stride-2 form
  *   AGL_CONV_NO_POS      never use the position-major path on <= 8x8 maps (A/B tests)
  *   AGL_CONV_POS_ALL_KS  experiments: position-major path also for 3x3 / 4x4 kernels
- *   AGL_CONV_SPLIT3      fp32 tensors, fp32-accurate products on the bf16 matrix cores: every operand is carried as three
- *                        bf16 terms (a = a1+a2+a3 to 2^-27) and six of the nine partial products are accumulated in fp32
- *                        (the dropped ones are <= 2^-27 |ab|); used by the LDS-patch kernel of csrc/pconv.hip where it
- *                        applies (1x1 / 3x3 / 5x5 stride 1, 4x4 / 3x3 stride 2 and their gradients on 4/8/16n-wide
- *                        maps), exact fp32 MFMA elsewhere
+ *   AGL_CONV_SPLIT3      fp32 tensors, fp32-accurate products on the 16-bit matrix cores (the name is historical): every
+ *                        operand is carried as several 16-bit terms and the partial products that matter are accumulated
+ *                        in fp32.  agl_conv2d_split_products() says which form the library was built with:
+ *                          3  fp16 hi / lo terms (a = hi + lo' * 2^-11 to ~2^-23) under power-of-two block scales found
+ *                             when the operand is staged / packed; hi*hi, hi*lo', lo'*hi (dropped: <= 2^-22 |ab|);
+ *                          6  three bf16 terms (a = a1+a2+a3 to 2^-27), six of the nine partial products.
+ *                        Used by the LDS-patch kernels of csrc/pconv.hip where they apply (1x1 / 3x3 / 5x5 stride 1,
+ *                        4x4 / 3x3 stride 2 and their gradients on 4/8/16n-wide maps), exact fp32 MFMA elsewhere.  The
+ *                        accuracy class is tested, not assumed: error against fp64 <= 2x that of the exact fp32 MFMA
+ *                        kernel on the same problem (tests/test_ops_gpu.py)
  *   AGL_CONV_ANY_GRID    take the matrix-core kernels of csrc/pconv.hip also for grids below their occupancy threshold
  *                        (by default a launch of < 200 workgroups falls back to the split-K fp32 kernels, which are
  *                        faster there); lets unit tests exercise those kernels on small tensors                       */
@@ -96,8 +101,12 @@ int agl_conv2d_pack_desc(const float* w, void* packed, long packed_bytes, int pa
 int agl_conv2d_pack_many(const void* rows_dev, int n, long total_blocks, void* stream);
 /* Arithmetic pipe of the main kernel the LAST agl_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_weight call of the calling thread
  * launched: 0 = exact fp32 (fp32 MFMA or fp32 VALU), 1 = bf16 MFMA, one product per multiply-add (AGL_CONV_BF16), 3 = bf16 MFMA
- * with split operands, six products per multiply-add (AGL_CONV_SPLIT3).  bench.py prices each launch against that pipe's peak. */
+ * with split operands (AGL_CONV_SPLIT3), agl_conv2d_split_products() products per multiply-add.  bench.py prices each launch
+ * against that pipe's peak. */
 int agl_conv2d_last_pipe(void);
+/* Matrix-core products per fp32 multiply-add of the AGL_CONV_SPLIT3 arithmetic this library was built with: 3 (fp16 hi / lo
+ * terms) or 6 (three bf16 terms).  The few-channel 7x7 vertical form always uses the six-product form. */
+int agl_conv2d_split_products(void);
 /* The same forward (no output ReLU, no accumulate) that may also leave the BatchNorm partial sums of its output in
  * `stats` — the statistics pass of the nn.BatchNorm2d that follows the convolution (generator_obj_att.py:54-57, 433, 583;
  * normalization.py:77-78 + 97) then needs no read of y.  stats: stats_floats floats (agl_conv2d_fwd_stats_floats());
