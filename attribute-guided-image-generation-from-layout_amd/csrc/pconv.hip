@@ -42,6 +42,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SPL = AGL_SPLIT_PLANES;
 static_assert(SPL == 2 || SPL == 3, "split arithmetic: 2 (fp16 hi/lo, three products) or 3 (bf16 terms, six products) planes");
 int pconv_split_products() { return SPL == 2 ? 3 : 6; }
+// taps per weight stage of the 64-channel x 256-pixel 3x3 split tiles: one kernel row (3) keeps three planes within two workgroups per
+// CU; two fp16 planes have room for the whole window (9: a third of the barriers)
+#ifndef AGL_SPLIT_WIDE_TG
+#define AGL_SPLIT_WIDE_TG 3
+#endif
+constexpr int STG = AGL_SPLIT_WIDE_TG;
 
 namespace {
 
@@ -61,6 +67,12 @@ __device__ __forceinline__ int h16_shift(unsigned mbits) {
 __device__ __forceinline__ void split_h16(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+// ... with lo at its true scale (one accumulator for all three products).  An element more than 2^-18 below its block's maximum then has a
+// subnormal lo — an absolute error <= 2^-40 of the block maximum, far below the accumulation's own rounding.
+__device__ __forceinline__ void split_h16_unscaled(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
 }
 // maximum over the wave of an unsigned value (DPP within rows of 16 lanes, then the four row values through the scalar unit)
 __device__ __forceinline__ unsigned wave_umax(unsigned v) {
@@ -136,60 +148,87 @@ __device__ __forceinline__ void pack_piece(const float* __restrict__ w, u32x4* _
     wp[2 * per_plane + i] = __builtin_bit_cast(u32x4, t2);
   }
 }
-// fp16 hi / lo form (SPL == 2): ONE workgroup packs one 16-channel chunk cc — all its 2 * KK * mpad pieces — so that the chunk's scale
-// needs no second launch: pass 1 finds the largest magnitude of the chunk, pass 2 writes wp[plane][i] = {hi, lo'} of w * 2^-shift and
-// the shift goes to wexp[cc] (behind the planes; read by the consumer as a scalar per stage).  Source element of piece i as in pack_piece.
-__device__ __forceinline__ void pack_chunk_h16(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
-                                               int flip, int mpad, int phase4, long per_plane, int cc, unsigned* red) {
-  const long per_chunk = 2L * KK * mpad, i0 = (long)cc * per_chunk;
-  auto src_of = [&](long i, int& m, int& c0, int& st) {
-    m = (int)(i % mpad);
-    long r = i / mpad;
-    const int tap = (int)(r % KK); r /= KK;
-    c0 = 16 * (int)(r >> 1) + 8 * (int)(r & 1);
-    st = flip ? KK - 1 - tap : tap;
-    if (phase4) {
-      const int phase = tap >> 2, thp = (tap >> 1) & 1, twp = tap & 1;
-      st = ((((phase >> 1) + 1) & 1) + 2 * (1 - thp)) * 4 + (((phase & 1) + 1) & 1) + 2 * (1 - twp);
-    }
+// fp16 hi / lo form (SPL == 2).  A 16-channel chunk cc of the packed tensor shares one scale, so a pack is two launches: h16_scan_chunk
+// (one 1024-thread workgroup per chunk reads the chunk's 16 * M * KK source floats in runs of consecutive addresses, eight loads in flight
+// per thread, and leaves the shift in wexp[cc] behind the planes, where the consumer reads it as a scalar per stage) and then one thread
+// per 16-byte piece as in pack_piece: wp[plane][i] = {hi, lo'} of w * 2^-shift.
+__device__ __forceinline__ void h16_scan_chunk(const float* __restrict__ w, int* __restrict__ wexp, int M, int Cin, int KK, int w_sm, int w_sc,
+                                               int cc, unsigned* red) {
+  const int cn = min(16, Cin - 16 * cc);                   // channels of this chunk that exist
+  const long total = (long)cn * M * KK;
+  const float* const wc = w + (long)(16 * cc) * w_sc;
+  const bool m_inner = w_sm < w_sc;                         // which of (row m, channel c) continues the run of taps
+  auto at = [&](long idx) -> unsigned {
+    const int st = (int)(idx % KK);
+    const long r = idx / KK;
+    const long m = m_inner ? r % M : r / cn, c = m_inner ? r / M : r % cn;
+    return __builtin_bit_cast(unsigned, wc[m * w_sm + c * w_sc + st]) & 0x7fffffffu;
   };
   unsigned tm = 0;
-  for (long i = i0 + threadIdx.x; i < i0 + per_chunk; i += blockDim.x) {
-    int m, c0, st;
-    src_of(i, m, c0, st);
-    if (m >= M) continue;
+  const long step = blockDim.x;
+  long idx = threadIdx.x;
+  for (; idx + 7 * step < total; idx += 8 * step) {
+    unsigned v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (c0 + j < Cin) tm = max(tm, __builtin_bit_cast(unsigned, w[(long)m * w_sm + (long)(c0 + j) * w_sc + st]) & 0x7fffffffu);
+    for (int q = 0; q < 8; ++q) v[q] = at(idx + q * step);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tm = max(tm, v[q]);
   }
+  for (; idx < total; idx += step) tm = max(tm, at(idx));
   tm = wave_umax(tm);
-  __syncthreads();      // (red may still be read by the previous chunk of this workgroup: none today, one chunk per workgroup)
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tm;
   __syncthreads();
-  unsigned mx = 0;
-  for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mx = max(mx, red[q]);
-  const int sh = h16_shift(mx);
-  const float fac = exp2i(-sh);
-  if (threadIdx.x == 0) reinterpret_cast<int*>(wp + 2 * per_plane)[cc] = sh;
-  for (long i = i0 + threadIdx.x; i < i0 + per_chunk; i += blockDim.x) {
-    int m, c0, st;
-    src_of(i, m, c0, st);
-    f16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = (m < M && c0 + j < Cin) ? w[(long)m * w_sm + (long)(c0 + j) * w_sc + st] * fac : 0.f;
-      _Float16 a, b;
-      split_h16(v, a, b);
-      hi[j] = a; lo[j] = b;
-    }
-    wp[i] = __builtin_bit_cast(u32x4, hi);
-    wp[per_plane + i] = __builtin_bit_cast(u32x4, lo);
+  if (threadIdx.x == 0) {
+    unsigned mx = 0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mx = max(mx, red[q]);
+    wexp[cc] = h16_shift(mx);
   }
 }
-__global__ __launch_bounds__(256) void pack_weights_h16_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm,
-                                                          int w_sc, int flip, int mpad, int nch, int phase4) {
-  __shared__ unsigned red[4];
-  pack_chunk_h16(w, wp, M, Cin, KK, w_sm, w_sc, flip, mpad, phase4, (long)nch * 2 * KK * mpad, (int)blockIdx.x, red);
+__device__ __forceinline__ void pack_piece_h16(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                                               int flip, int mpad, int phase4, long per_plane, long i) {
+  const int m = (int)(i % mpad);
+  long r = i / mpad;
+  const int tap = (int)(r % KK); r /= KK;
+  const int cc = (int)(r >> 1), c0 = 16 * cc + 8 * (int)(r & 1);
+  int st = flip ? KK - 1 - tap : tap;
+  if (phase4) {
+    const int phase = tap >> 2, thp = (tap >> 1) & 1, twp = tap & 1;
+    st = ((((phase >> 1) + 1) & 1) + 2 * (1 - thp)) * 4 + (((phase & 1) + 1) & 1) + 2 * (1 - twp);
+  }
+  const float fac = exp2i(-reinterpret_cast<const int*>(wp + 2 * per_plane)[cc]);
+  f16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (m < M && c0 + j < Cin) ? w[(long)m * w_sm + (long)(c0 + j) * w_sc + st] * fac : 0.f;
+    _Float16 a, b;
+    split_h16(v, a, b);
+    hi[j] = a; lo[j] = b;
+  }
+  wp[i] = __builtin_bit_cast(u32x4, hi);
+  wp[per_plane + i] = __builtin_bit_cast(u32x4, lo);
+}
+__global__ __launch_bounds__(1024) void h16_scan_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
+                                                   long per_plane) {
+  __shared__ unsigned red[16];
+  h16_scan_chunk(w, reinterpret_cast<int*>(wp + 2 * per_plane), M, Cin, KK, w_sm, w_sc, (int)blockIdx.x, red);
+}
+// ... for a descriptor table (pack_many_k): blockIdx.y = row, blockIdx.x strides over the row's chunks
+__global__ __launch_bounds__(1024) void h16_scan_many_k(const long long* __restrict__ d) {
+  __shared__ unsigned red[16];
+  const long long* r = d + (long)blockIdx.y * 14;
+  if (r[9] != 2) return;
+  const int nch = (int)r[3] / 16;
+  for (int cc = blockIdx.x; cc < nch; cc += gridDim.x)
+    h16_scan_chunk(reinterpret_cast<const float*>(r[0]), reinterpret_cast<int*>(reinterpret_cast<u32x4*>(r[1]) + 2 * r[11]), (int)r[2], (int)r[3], (int)r[4],
+                   (int)r[5], (int)r[6], cc, red);
+}
+__global__ void pack_weights_h16_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc, int flip,
+                                   int mpad, int nch, int phase4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_plane = (long)nch * 2 * KK * mpad;
+  if (i >= per_plane) return;
+  pack_piece_h16(w, wp, M, Cin, KK, w_sm, w_sc, flip, mpad, phase4, per_plane, i);
 }
 __global__ void pack_weights_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
                                int flip, int mpad, int nch, int nsplit, int phase4) {
@@ -207,14 +246,13 @@ __global__ void pack_many_k(const long long* __restrict__ d, int n) {
   const long b = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d[(long)mid * WD + 12] <= b) lo = mid; else hi = mid - 1; }
   const long long* r = d + (long)lo * WD;
-  if (r[9] == 2) {      // fp16 hi / lo planes: one workgroup per 16-channel chunk (row[13] = chunks)
-    __shared__ unsigned red[4];
-    pack_chunk_h16(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6],
-                   (int)r[7], (int)r[8], (int)r[10], r[11], (int)(b - r[12]), red);
-    return;
-  }
   const long i = (b - r[12]) * blockDim.x + threadIdx.x, per_plane = r[11];
   if (i >= per_plane) return;
+  if (r[9] == 2) {      // fp16 hi / lo planes (the chunk shifts were left by h16_scan_many_k)
+    pack_piece_h16(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7],
+                   (int)r[8], (int)r[10], per_plane, i);
+    return;
+  }
   pack_piece(reinterpret_cast<const float*>(r[0]), reinterpret_cast<u32x4*>(r[1]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7],
              (int)r[8], (int)r[9], (int)r[10], per_plane, i);
 }
@@ -1104,7 +1142,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // AUX: the bf16 dy operand (WArgs::dy_bf16) and the input transform of x (WArgs::fold) compiled in — the 4x4 / stride-2 family only
 // (weight gradients of ConvTranspose2d(4, 2, 1) and of the folded encoder convolutions); see pconv_k's FEAT for why not everywhere.
 template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS, bool AUX = false>
-__global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
+__global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
   static_assert((NPX == 128 || NPX == 64) && TW >= 4, "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy pieces are two full rows)
@@ -1112,8 +1150,11 @@ __global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(W
   constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
   constexpr int XROW = 2 * BC;                          // bytes per patch pixel
   constexpr int D_PLANE = BMCO * DPITCH, X_PLANE = NQ * XROW;
-  constexpr int NACC = NSPL >= 2 ? 2 : 1;
   constexpr bool H16 = NSPL == 2;      // fp16 hi / lo planes, three products, power-of-two scales per staged tile (see SPL)
+  // 5x5 (25 taps): two accumulator sets are 200 registers and the kernel spilled (188-212 bytes of scratch, one workgroup per CU).  There
+  // the lo terms keep their true scale and all three products go to ONE set: 100 registers, two workgroups per CU.
+  constexpr bool ONEACC = H16 && TSUB > 16;
+  constexpr int NACC = (NSPL >= 2 && !ONEACC) ? 2 : 1;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSPL * (D_PLANE + X_PLANE)];
   __shared__ unsigned wmax_s[H16 ? 2 * (NT / 64) : 1];      // H16: the waves' maxima of the dy tile and of the x patch about to be converted
   unsigned char* const Dl = lds;
@@ -1251,7 +1292,7 @@ __global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(W
       if constexpr (H16) {
         f16x8 hi, lo;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { _Float16 a, b; split_h16(v[q] * dfac, a, b); hi[q] = a; lo[q] = b; }
+        for (int q = 0; q < 8; ++q) { _Float16 a, b; if constexpr (ONEACC) split_h16_unscaled(v[q] * dfac, a, b); else split_h16(v[q] * dfac, a, b); hi[q] = a; lo[q] = b; }
         *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
         *reinterpret_cast<u32x4*>(dst + D_PLANE) = __builtin_bit_cast(u32x4, lo);
         return;
@@ -1278,7 +1319,7 @@ __global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(W
       if constexpr (H16) {      // (input transform and ReLU already applied to the registers by prep_tile)
         f16x8 hi, lo;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) { _Float16 a, b; split_h16(px[sl][jj] * xfac, a, b); hi[jj] = a; lo[jj] = b; }
+        for (int jj = 0; jj < 8; ++jj) { _Float16 a, b; if constexpr (ONEACC) split_h16_unscaled(px[sl][jj] * xfac, a, b); else split_h16(px[sl][jj] * xfac, a, b); hi[jj] = a; lo[jj] = b; }
         unsigned char* dst = Xl + q * XROW + oc * 16;
         *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
         *reinterpret_cast<u32x4*>(dst + X_PLANE) = __builtin_bit_cast(u32x4, lo);
@@ -1440,7 +1481,7 @@ __global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(W
               const f16x8 ah = __builtin_bit_cast(f16x8, fa[0][i]), al = __builtin_bit_cast(f16x8, fa[1][i]);
               const f16x8 bh = __builtin_bit_cast(f16x8, fb[0]), bl = __builtin_bit_cast(f16x8, fb[1]);
               acc[0][i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[0][i][j][t], 0, 0, 0);
-              f32x4& lo = acc[1][i][j][t];
+              f32x4& lo = acc[NACC - 1][i][j][t];
               lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, lo, 0, 0, 0);
               lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, lo, 0, 0, 0);
               continue;
@@ -1481,7 +1522,8 @@ __global__ __launch_bounds__(NT, (NSPL >= 2 && TSUB > 16) ? 1 : 2) void pbww_k(W
             if (tap0 + t >= KK) break;
             float v = acc[0][i][j][t][r];
             if constexpr (NSPL == 3) v += acc[1][i][j][t][r];
-            if constexpr (H16) v = __builtin_ldexpf(fmaf(acc[1][i][j][t][r], 1.0f / 2048.0f, v), S_run);
+            if constexpr (H16 && !ONEACC) v = fmaf(acc[NACC - 1][i][j][t][r], 1.0f / 2048.0f, v);
+            if constexpr (H16) v = __builtin_ldexpf(v, S_run);
             o[tap0 + t] = acc_out ? o[tap0 + t] + v : v;
           }
         }
@@ -1732,7 +1774,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     }
 #undef PC_ABL
   } else if (w8 && a.ks == 3) {
-    if (wide) { if (w32) PC_LAUNCH8(3, 1, 32, 8, 1, 64, SPL, 3, false); else PC_LAUNCH8(3, 1, 16, 16, 1, 64, SPL, 3, false); }
+    if (wide) { if (w32) PC_LAUNCH8(3, 1, 32, 8, 1, 64, SPL, STG, false); else PC_LAUNCH8(3, 1, 16, 16, 1, 64, SPL, STG, false); }
     else if (bm == 128) {
       if (geo == 0 && w32) PC_LAUNCH8(3, 1, 32, 4, 1, 128, SPL, 3, false);
       else if (geo == 0) PC_LAUNCH8(3, 1, 16, 8, 1, 128, SPL, 3, false);
@@ -1760,7 +1802,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
     else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
-    else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, SPL, 3); else PC_LAUNCH(3, 1, 16, 16, 1, 64, SPL, 3); }
+    else if (wide) { if (w32) PC_LAUNCH(3, 1, 32, 8, 1, 64, SPL, STG); else PC_LAUNCH(3, 1, 16, 16, 1, 64, SPL, STG); }
     else if (bm == 128) {
       if (geo == 3) PC_LAUNCH(3, 1, 8, 8, 1, 128, SPL, 3);
       else if (geo == 0 && w32) PC_LAUNCH(3, 1, 32, 4, 1, 128, SPL, 3);
@@ -1797,9 +1839,13 @@ void pconv_pack_desc(const float* w, void* packed, int M, int Cred, int ks, int 
   const long per_plane = (long)nch * 2 * KK * mpad;
   row[0] = (long long)(uintptr_t)w; row[1] = (long long)(uintptr_t)packed; row[2] = M; row[3] = Cred; row[4] = KK; row[5] = w_sm; row[6] = w_sc;
   row[7] = flip; row[8] = mpad; row[9] = pack_planes(nsplit); row[10] = phase4; row[11] = per_plane; row[12] = 0;
-  row[13] = pack_planes(nsplit) == 2 ? nch : (per_plane + 255) / 256;      // (fp16 hi / lo form: one workgroup per 16-channel chunk)
+  row[13] = (per_plane + 255) / 256;
 }
 int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t st, const char* name) {
+  if (SPL == 2) {      // the chunk scales of the fp16 hi / lo rows first (rows of the one-plane form return at once)
+    hipLaunchKernelGGL(h16_scan_many_k, dim3(64, (unsigned)n), dim3(1024), 0, st, (const long long*)rows_dev);
+    AGL_CHECK_LAUNCH(name);
+  }
   hipLaunchKernelGGL(pack_many_k, dim3((unsigned)total_blocks), dim3(256), 0, st, (const long long*)rows_dev, n);
   AGL_CHECK_LAUNCH(name);
   return AGL_OK;
@@ -1808,9 +1854,12 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
                const char* name) {
   const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
   const long per_plane = (long)nch * 2 * KK * mpad;
-  if (pack_planes(nsplit) == 2)
-    hipLaunchKernelGGL(pack_weights_h16_k, dim3((unsigned)nch), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc, flip, mpad, nch, phase4);
-  else
+  if (pack_planes(nsplit) == 2) {
+    hipLaunchKernelGGL(h16_scan_k, dim3((unsigned)nch), dim3(1024), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc, per_plane);
+    AGL_CHECK_LAUNCH(name);
+    hipLaunchKernelGGL(pack_weights_h16_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
+                       flip, mpad, nch, phase4);
+  } else
     hipLaunchKernelGGL(pack_weights_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
                        flip, mpad, nch, nsplit, phase4);
   AGL_CHECK_LAUNCH(name);
