@@ -48,6 +48,9 @@ int pconv_split_products() { return SPL == 2 ? 3 : 6; }
 #define AGL_SPLIT_WIDE_TG 3
 #endif
 constexpr int STG = AGL_SPLIT_WIDE_TG;
+#ifndef AGL_H16_PHASE_LONG
+#define AGL_H16_PHASE_LONG 32      // (chunk, tap) steps above which the stride-2 input gradient takes its 64-pixel tiles (pconvT_plan)
+#endif
 
 namespace {
 
@@ -1992,13 +1995,17 @@ static int pconvT_plan(const PConvArgs& a, int* geo, int* bm, long* ptiles, int*
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 30)) return -1;
   *bm = (a.nsplit == 3 || a.Cout <= 64) ? 64 : 128;
   *ptiles = *geo == 0 ? (long)a.N * (a.H / 8) * (a.W / 16) : (*geo == 1 ? agl_cdiv(a.N, 2) : (*geo == 2 ? agl_cdiv(a.N, 8) : agl_cdiv(a.N, 32)));
+  // fp16 hi / lo split form, reductions of more than 32 (chunk, tap) steps: 64-pixel tiles (geo + 10) — two accumulator blocks per wave
+  // for the two column phases, which leaves registers for the fp32 total the hi*hi accumulator is emptied into (pconv_k FLUSH); without
+  // it a 128-step chain reached 2.7x the exact fp32 kernel's distance to fp64
+  if (a.nsplit == 3 && SPL == 2 && (a.Cin / 16) * 4 > AGL_H16_PHASE_LONG && *geo != 3) { *geo += 10; *ptiles = *geo == 10 ? *ptiles * 2 : (*geo == 11 ? a.N : agl_cdiv(a.N, 4)); }
   int splits = 1;
   const long wgs = *ptiles * agl_cdiv(a.Cout, *bm) * 4;         // (in units of single-phase workgroups)
   if (wgs < 200 && !a.any_grid) {      // small grid: cut the reduction (paired-phase geometries only: they write whole slab rows)
     const int nch = a.Cin / 16;
     splits = std::min(kPconvMaxSplits, nch / 4);
     while (splits > 2 && wgs * (splits / 2) >= 512) splits /= 2;
-    if (*geo == 3 || odd || splits < 2 || wgs * splits < 256 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
+    if (*geo % 10 == 3 || odd || splits < 2 || wgs * splits < 256 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
   }
   if (splits_out) *splits_out = splits;
   return 0;
@@ -2007,7 +2014,7 @@ bool pconvT_eligible(const PConvArgs& a) { int g, b; long t; return pconvT_plan(
 // ... and in the form that reads a bf16 pos_mask (bf16 arithmetic, even size, paired phases, no reduction split)
 bool pconvT_takes_bf16_mask(const PConvArgs& a) {
   int g, b, sp; long t;
-  return pconvT_plan(a, &g, &b, &t, &sp) == 0 && sp == 1 && g != 3 && a.nsplit == 1 && a.OH == 2 * a.H && a.OW == 2 * a.W;
+  return pconvT_plan(a, &g, &b, &t, &sp) == 0 && sp == 1 && g % 10 != 3 && a.nsplit == 1 && a.OH == 2 * a.H && a.OW == 2 * a.W;
 }
 long pconvT_ws_bytes(int Cred, int Crow, int nsplit) {
   if (Cred % 16 != 0 || Crow < 48) return 0;
@@ -2064,6 +2071,9 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
     else PT_LAUNCH_M(4, 4, 8, BM_);                               \
   } while (0)
   if (a.mask_bf16) { if (bm == 128) PT_GEO_M(128); else PT_GEO_M(64); }
+  else if (geo >= 10) {      // (SPL == 2 only: 64-pixel tiles)
+    if (geo == 10) PT_LAUNCH(16, 4, 1, 64, SPL); else if (geo == 11) PT_LAUNCH(8, 8, 1, 64, SPL); else PT_LAUNCH(4, 4, 4, 64, SPL);
+  }
   else if (a.nsplit == 3) PT_GEO(64, SPL);
   else if (bm == 128) PT_GEO(128, 1);
   else PT_GEO(64, 1);

@@ -34,16 +34,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 # Peak of the pipe a convolution launch ran on (agl_conv2d_last_pipe): 0 exact fp32 (fp32 MFMA / fp32 VALU, same 157.3 peak);
-# 1 bf16 MFMA, one product per multiply-add; 3 bf16 MFMA with split operands: SIX MFMA products per fp32 multiply-add, i.e. a
-# 2500/6 = 416.7 TFLOP/s ceiling in fp32-equivalent FLOPs.
-PIPE_PEAK = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS, 3: PEAK_BF16_MFMA_TFLOPS / 6.0}
-PIPE_NAME = {0: "fp32 (MFMA 32x32x2 f32 / VALU)", 1: "bf16 MFMA", 3: "bf16 MFMA, split operands (6 products per MAC)"}
-# JSON dtype = how the multiply-adds are computed: "f32x3" = fp32 tensors and accumulation with every product formed from three
-# bf16 terms per operand on the bf16 matrix cores (config.products spells it out first); "f32" = exact fp32 MFMA everywhere
+# 1 bf16 MFMA, one product per multiply-add; 3 = 16-bit MFMA with split operands: agl_conv2d_split_products() MFMA products per fp32
+# multiply-add — THREE with the fp16 hi / lo form this library is built with (2500/3 = 833.3 fp32-equivalent TFLOP/s ceiling), six with
+# the bf16 x3 form of rounds 2-4 (416.7).  set_split_form() fills entry 3 from the loaded library.
+PIPE_PEAK = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS, 3: PEAK_BF16_MFMA_TFLOPS / 3.0}
+PIPE_NAME = {0: "fp32 (MFMA 32x32x2 f32 / VALU)", 1: "bf16 MFMA", 3: "fp16 MFMA, hi/lo split operands (3 products per MAC)"}
+# JSON dtype = how the multiply-adds are computed: "f32x3" = fp32 tensors and accumulation with every product formed from THREE 16-bit
+# matrix-core products of two fp16 terms per operand (config.products spells it out first); "f32" = exact fp32 MFMA everywhere
 DTYPE_NAME = {"f32": "f32", "f32x3": "f32x3", "bf16": "bf16"}
 PRODUCTS = {
     "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution",
-    "f32x3": "bf16x3 split products: fp32 tensors, 6 bf16-MFMA products per fp32 multiply-add (fp32-accurate), fp32 accumulation",
+    "f32x3": "fp16 hi/lo split products: fp32 tensors, 3 fp16-MFMA products per fp32 multiply-add under power-of-two block scales "
+             "(fp32-accurate: error vs fp64 <= that of the exact fp32 MFMA kernels), fp32 accumulation",
     "bf16": "bf16 MFMA operands (rounded once when staged), fp32 accumulation; activations with convolution-only readers stored as bf16 "
             "(SPADE outputs in front of the decoder's layers, box-filtered maps, first-convolution outputs of the flat D blocks), the "
             "rest and all statistics / gradients fp32",
@@ -51,10 +53,12 @@ PRODUCTS = {
 ARITHMETIC = {
     "f32": "fp32 tensors; every convolution on exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
     "f32x3": "fp32 tensors and fp32 accumulation; in the LDS-patch kernels (csrc/pconv.hip: 1x1/3x3/5x5 stride 1, 4x4/3x3 stride 2 "
-             "forward, stride-1 and 4x4/stride-2 input gradients, weight gradients) each fp32 operand is carried as three bf16 "
-             "terms (exact to 2^-27) and six bf16-MFMA products are accumulated in fp32 — as accurate as the fp32 MFMA chain "
-             "(tests: error vs fp64 <= 2x that of the exact kernel; whole step at this size vs the CPU oracle at the fp32 "
-             "tolerances); exact fp32 MFMA in all other kernels",
+             "forward, stride-1 and 4x4/stride-2 input gradients, weight gradients) each fp32 operand is carried as two fp16 terms "
+             "(hi + lo' * 2^-11, ~23 bits) under a power-of-two scale per staged block (weights: per 16-channel chunk at pack time; "
+             "activations: per staged chunk / tile from the registers being converted), hi*hi + hi*lo' + lo'*hi on the fp16 matrix "
+             "cores, the hi*hi accumulator emptied into an fp32 total every ~32 instructions — measured as accurate as the fp32 MFMA "
+             "chain (tests: error vs fp64 <= 2x that of the exact kernel, also at operand magnitudes 1e-8 and 1e4; whole step at this "
+             "size vs the CPU oracle at the fp32 tolerances); exact fp32 MFMA in all other kernels",
     "bf16": "convolution operands rounded to bf16 when staged (or stored as bf16 by their producer when only convolutions read them: "
             "identical values), bf16 MFMA with fp32 accumulation; BatchNorm / ConditionalBatchNorm apply folded into the consuming "
             "convolution's staging pass; statistics, spectral norm, losses, gradients and Adam fp32",
@@ -63,6 +67,17 @@ CONV_NAMES = ("agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", "
               "agl_conv2d_bwd_weight_fold", "agl_conv2d_fwd_addend", "agl_conv2d_fwd_shortcut")
 NORM_NAMES = ("agl_bn_stats", "agl_bn_stats_from_partials", "agl_norm_apply_fwd", "agl_norm_bwd", "agl_norm_bwd_fold", "agl_norm_apply_fwd_y16",
               "agl_norm_bwd_y16")
+
+
+def set_split_form():
+    """Price pipe 3 (split operands) with the product count of the loaded library (agl_conv2d_split_products: 3 = fp16 hi/lo, 6 = bf16 x3)."""
+    from agl import lib as _L
+    sp = _L.load().agl_conv2d_split_products()
+    PIPE_PEAK[3] = PEAK_BF16_MFMA_TFLOPS / sp
+    if sp == 6:
+        PIPE_NAME[3] = "bf16 MFMA, split operands (6 products per MAC)"
+        PRODUCTS["f32x3"] = "bf16x3 split products: fp32 tensors, 6 bf16-MFMA products per fp32 multiply-add (fp32-accurate), fp32 accumulation"
+    return sp
 
 
 def parse_args(argv=None):
@@ -77,7 +92,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the 128 px / bf16 secondary result")
     ap.add_argument("--dtype", default=None, choices=["f32", "f32x3", "bf16"],
                     help="arithmetic of the convolutions.  f32x3 (default for BASELINE config 2): fp32 tensors, fp32-accurate "
-                         "products formed on the bf16 matrix cores from three bf16 terms per operand (six products, fp32 "
+                         "products formed on the fp16 matrix cores from two fp16 terms per operand (three products, fp32 "
                          "accumulation) in the kernels of csrc/pconv.hip, exact fp32 MFMA elsewhere; f32: exact fp32 MFMA "
                          "everywhere; bf16: operands rounded to bf16 (configs 3/5).  Statistics, SN, losses, Adam: fp32 always")
     ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
@@ -257,10 +272,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             fence()
             serial_ms = 1e3 * (time.perf_counter() - t1) / 3
     if not a.no_roofline and rank == 0:
-        from agl import lib as _L
-        sp = _L.load().agl_conv2d_split_products()      # matrix-core products per fp32 multiply-add of the split arithmetic of this build
-        PIPE_PEAK[3] = PEAK_BF16_MFMA_TFLOPS / sp
-        PIPE_NAME[3] = ("fp16 MFMA, hi/lo split operands (3 products per MAC)" if sp == 3 else "bf16 MFMA, split operands (6 products per MAC)")
+        set_split_form()
         conv = [e for e in log if e[0] in CONV_NAMES]
         conv_ms = sum(e[1].elapsed_time(e[2]) for e in conv)
         executed = sum(e[3] for e in conv)
@@ -310,8 +322,8 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 "achieved_bf16_issue": round(frac * PEAK_BF16_MFMA_TFLOPS, 2) if on_bf16 else None,
                 "definition": "achieved = executed fp32-equivalent FLOPs of all convolution launches / their measured time (one stream, HIP events per "
                               "launch); peak = FLOP-weighted harmonic mean of the peak of the pipe each launch ran on (fp32 157.3, bf16 MFMA 2500, "
-                              "split-operand bf16 MFMA 2500/6 fp32-equivalent); frac = achieved / peak = time at peak / time taken; "
-                              "achieved_bf16_issue = frac x 2500 (bf16 MFMA issue rate: split products count 6x); traffic = HBM bytes per "
+                              f"split-operand 16-bit MFMA 2500/{int(round(PEAK_BF16_MFMA_TFLOPS / PIPE_PEAK[3]))} fp32-equivalent); frac = achieved / peak = time at peak / time taken; "
+                              f"achieved_bf16_issue = frac x 2500 (16-bit MFMA issue rate: split products count {int(round(PEAK_BF16_MFMA_TFLOPS / PIPE_PEAK[3]))}x); traffic = HBM bytes per "
                               "launch of the family from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)",
                 "by_pipe": by_pipe,
                 "kernel": "convolution family: pconv_k / pbww_k (bf16 matrix cores) + igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + "
@@ -418,6 +430,7 @@ def main():
 
     from agl import lib as L
     L.load()
+    set_split_form()
     res = a.res or 64
     dtype = a.dtype or "f32x3"
     per_gpu = a.batch or (64 if res == 64 else 32)

@@ -980,6 +980,49 @@ def test_pconv_bf16_matrix_core_patch_kernel(case, mode):
         assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), (e_split, e_exact)
 
 
+@pytest.mark.parametrize("scales", [(1e-8, 1.0, 1.0), (1e4, 1.0, 1.0), (1.0, 1e-8, 1e4), (1e4, 1e4, 1e-8), (1e-30, 1e-5, 1.0), (1e25, 1e8, 1e-20)])
+def test_split_products_accuracy_class_at_extreme_operand_magnitudes(scales):
+    """The split arithmetic carries fp16 terms (5 exponent bits) under power-of-two block scales found when an operand is staged or
+    packed, so its accuracy class must not depend on the operands' magnitude: activations, weights and output gradients scaled by
+    1e-8 ... 1e4 (and far beyond: 1e-30, 1e25), plus one tensor whose channels span 2^40 in magnitude inside every staged block.  Same
+    gate as the unit-magnitude tests: distance to fp64 <= 2x that of the exact fp32 MFMA kernel (+2e-7 of the result's largest value),
+    forward, both input-gradient forms (stride 1, 4x4 / stride 2 phases) and the weight gradient, short and long reductions."""
+    from agl import lib as L
+    xs, ws, gs = scales
+    g = torch.Generator().manual_seed(21)
+    for (N, Cin, H, Cout, ks, st, pad) in ((9, 64, 16, 128, 3, 1, 1), (6, 512, 8, 256, 3, 1, 1), (8, 256, 16, 512, 4, 2, 1), (12, 128, 8, 256, 5, 1, 2)):
+        x = torch.randn(N, Cin, H, H, generator=g) * xs
+        w = torch.randn(Cout, Cin, ks, ks, generator=g) * (ws / (Cin * ks * ks) ** 0.5)
+        OH = (H + 2 * pad - ks) // st + 1
+        dy = torch.randn(N, Cout, OH, OH, generator=g) * gs
+        x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        y64 = TF.conv2d(x64, w64, None, stride=st, padding=pad)
+        y64.backward(dy.double())
+        refs = (y64.detach(), x64.grad, w64.grad)
+        xd, wd, dyd = dev(x), dev(w), dev(dy)
+        out = {}
+        for name, flags in (("exact", 0), ("split", L.CONV_SPLIT3 | L.CONV_ANY_GRID)):
+            with L.conv_flags(flags):
+                out[name] = (L.conv2d_fwd(xd, wd, None, st, pad), L.conv2d_bwd_data(dyd, wd, (H, H), st, pad), L.conv2d_bwd_weight(dyd, xd, ks, st, pad))
+                if name == "split":
+                    assert L.load().agl_conv2d_last_pipe() == 3, "the call must run on the split matrix-core kernels"
+        for i, what in enumerate(("forward", "input gradient", "weight gradient")):
+            e_exact = float((out["exact"][i].cpu().double() - refs[i]).abs().max())
+            e_split = float((out["split"][i].cpu().double() - refs[i]).abs().max())
+            assert e_split <= 2.0 * e_exact + 2e-7 * float(refs[i].abs().max()), (scales, (N, Cin, H, Cout, ks, st), what, e_split, e_exact)
+    # a wide range INSIDE every staged block: channel c of x scaled by 2^(-(c % 41)); every 16-channel chunk then spans > 2^15
+    N, Cin, H, Cout = 6, 128, 16, 64
+    chs = torch.pow(2.0, -(torch.arange(Cin) % 41).float()).view(1, Cin, 1, 1)
+    x = torch.randn(N, Cin, H, H, generator=g) * chs
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9) ** 0.5)
+    y64 = TF.conv2d(x.double(), w.double(), None, padding=1)
+    with L.conv_flags(0):
+        e_exact = float((L.conv2d_fwd(dev(x), dev(w), None, 1, 1).cpu().double() - y64).abs().max())
+    with L.conv_flags(L.CONV_SPLIT3 | L.CONV_ANY_GRID):
+        e_split = float((L.conv2d_fwd(dev(x), dev(w), None, 1, 1).cpu().double() - y64).abs().max())
+    assert e_split <= 2.0 * e_exact + 2e-7 * float(y64.abs().max()), ("channel range 2^40", e_split, e_exact)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
 @pytest.mark.parametrize("case", [(5, 32, 64, 64, 4, 2, 1), (9, 64, 16, 128, 4, 2, 1), (17, 32, 8, 64, 4, 2, 1), (3, 16, 24, 48, 5, 1, 2),
                                   (37, 32, 4, 80, 4, 2, 1), (4, 64, 32, 128, 4, 2, 1), (3, 32, 33, 64, 4, 2, 1), (2, 48, 64, 200, 5, 1, 2),
