@@ -101,6 +101,9 @@ class FlatParams:
         self.epoch += 1
 
     def adam_step(self, lr, beta1, beta2, eps, grad_scale=1.0):
+        """One Adam launch over the arena on the current stream, then the arena's packed weights re-made in place (agl.lib.PackPlan).
+        PRECONDITION (the caller's job, as for any in-place optimiser): every launch that reads this arena's weights or their packed
+        forms — on any stream — is ordered before the current stream.  Trainer joins all chains and weight-gradient streams first."""
         self.step_count += 1
         self.epoch += 1
         L.adam_step(self.p, self.g, self.m, self.v, lr, beta1, beta2, eps, self.step_count, grad_scale)

@@ -338,8 +338,32 @@ def conv_out_size(h, ks, stride, pad, up=0):
 # a discriminator's weight_orig between two optimiser updates; only sigma of the spectral norm changes per forward call, and the
 # kernels divide by it in their epilogue.  A WeightSrc names where the values of a convolution weight come from; the packed
 # buffers live on the owning parameter and are re-made when its version changes.
-PACK_STATS = {"packs": 0, "hits": 0, "fused": 0}
+PACK_STATS = {"packs": 0, "hits": 0, "fused": 0, "dropped": 0}
 PACK_DESC_WORDS = 14       # = AGL_PACK_DESC_WORDS of include/agl.h
+
+# Cross-stream contract of a pack-cache entry (owner.__dict__["_agl_packs"][key] = (version, buffer, event, stream handle)):
+#   * WRITERS.  An entry's buffer is written by exactly two launch sequences: the pack that creates it (WeightSrc.packed on a miss:
+#     a NEW buffer, written on the current stream) and PackPlan.repack (IN PLACE, on the optimiser's stream, right behind the Adam
+#     launch that changed the weights).  Both record the entry's event AFTER their last launch, so everything that lives in the buffer
+#     (packed planes, the chunk shifts behind them) is covered by the event.  Nothing else may write into a cached buffer — in
+#     particular no consumer call may build side tables inside it at call time: such a write is ordered by no event, and three chains
+#     that share one layer (the generator's rec / rand / shift branches all read layout_encoder.c3's packs) would race on it.
+#   * READERS on the writer's stream are ordered by the stream; readers on any other stream wait for the entry's event first
+#     (WeightSrc.packed on a hit) and mark the buffer with record_stream.
+#   * The in-place re-pack is a second writer of a buffer that earlier readers on OTHER streams may still be using: it is legal only
+#     because whoever calls FlatParams.adam_step has ordered every reader of the arena's weights before the current stream (the weights
+#     themselves are rewritten in place by the Adam launch, which needs exactly the same ordering).  Trainer joins every chain and
+#     weight-gradient stream into the optimiser's stream before adam_step; FlatParams.adam_step documents the requirement.
+# AGL_DEBUG_PACK=1 checks the contract at run time: an entry is only ever re-written on a stream that has been told (note_joined)
+# that all readers were joined, and a hit never finds an entry whose event is missing.
+DEBUG_PACK = os.environ.get("AGL_DEBUG_PACK", "0") == "1"
+_joined_streams = set()      # (debug) stream handles on which the caller declared "all readers of the arena are ordered before this point"
+
+
+def note_joined(stream=None):
+    """Debug bookkeeping for the contract above: Trainer calls this after joining every chain into the optimiser's stream."""
+    if DEBUG_PACK:
+        _joined_streams.add((stream or torch.cuda.current_stream()).cuda_stream)
 
 
 class PackPlan:
@@ -377,12 +401,23 @@ class PackPlan:
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
 
     def repack(self):
-        """Re-pack every noted entry whose cache entry still holds the noted buffer; returns the number of packs done."""
+        """Re-pack every noted entry whose cache entry still holds the noted buffer AND whose parameter still lives where the descriptor
+        table says (the table holds raw device pointers); returns the number of packs done.  An entry whose parameter storage moved
+        (module.to(), a re-flattened arena, a .data reassignment) is dropped together with its cache entry, so the next use packs the
+        new storage on the ordinary miss path instead of convolving with stale weights."""
         live = {}
         for k, e in self.entries.items():
-            hit = e[0].__dict__.get("_agl_packs", {}).get(e[1])
-            if hit is not None and hit[1] is e[9]:
-                live[k] = e
+            owner, key, wsrc, buf, src = e[0], e[1], e[2], e[9], e[10]
+            cache = owner.__dict__.get("_agl_packs", {})
+            hit = cache.get(key)
+            if hit is None or hit[1] is not buf:
+                continue
+            cur_src = wsrc.base if wsrc.base is not None else wsrc.owner
+            if cur_src.data_ptr() != src.data_ptr() or cur_src.device != buf.device:
+                cache.pop(key, None)
+                PACK_STATS["dropped"] += 1
+                continue
+            live[k] = e
         if len(live) != len(self.entries):
             self.entries, self.table = live, None
         if not self.entries:
@@ -390,8 +425,11 @@ class PackPlan:
         dev = next(iter(self.entries.values()))[9].device
         if self.table is None:
             self._build(dev)
-        call("agl_conv2d_pack_many", self.table.data_ptr(), len(self.order), self.blocks, stream())
         cur = torch.cuda.current_stream()
+        if DEBUG_PACK:
+            assert cur.cuda_stream in _joined_streams, "PackPlan.repack on a stream nobody declared joined (agl.lib.note_joined): readers of the old packs may still run"
+            _joined_streams.discard(cur.cuda_stream)
+        call("agl_conv2d_pack_many", self.table.data_ptr(), len(self.order), self.blocks, stream())
         ev = torch.cuda.Event()
         ev.record(cur)
         for (owner, key, wsrc, *_rest) in self.order:
@@ -429,14 +467,17 @@ class WeightSrc:
         cur = torch.cuda.current_stream()
         if hit is not None and hit[0] == ver and hit[1].numel() >= nbytes:
             PACK_STATS["hits"] += 1
+            if DEBUG_PACK:
+                assert hit[2] is not None and hit[1].device == cur.device, "pack-cache entry without an event / on another device"
             if hit[3] != cur.cuda_stream:      # packed on another stream (concurrent chains share layers): order this stream behind it,
                 cur.wait_event(hit[2])         # and tell the allocator that this stream reads the buffer too (its memory
                 hit[1].record_stream(cur)      # must not be handed out again before the reads queued here have run)
             return hit[1]
         src = make() if make is not None else (self.base if self.base is not None else w)
-        # A new version gets a NEW buffer: the old one may still be read by launches queued on other chains' streams, which nothing
-        # orders before an in-place re-pack; dropping the cache entry hands it back to the stream-aware allocator instead (its
-        # record_stream marks keep the memory out of circulation until those reads are done).
+        # A miss gets a NEW buffer: the old one may still be read by launches queued on other chains' streams, which nothing orders
+        # before a re-pack issued from HERE (an arbitrary consumer stream); dropping the cache entry hands it back to the stream-aware
+        # allocator instead (its record_stream marks keep the memory out of circulation until those reads are done).  The one in-place
+        # writer is PackPlan.repack, on the optimiser's stream, under the contract stated above PACK_STATS.
         buf = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
         call("agl_conv2d_pack_weights", ptr(src.detach()), buf.data_ptr(), buf.numel(), pass_, Cin, Cout, ks, stride, CONV_FLAGS, stream())
         ev = torch.cuda.Event()

@@ -211,13 +211,17 @@ class Trainer:
     def _reduce_and_step(self, flat: FlatParams):
         """All-reduce the arena's gradients (side stream) and apply Adam there; returns the event the main
         stream must wait on before it reads the updated weights."""
+        # (the callers have joined every chain and weight-gradient stream into the current stream: the precondition of
+        #  FlatParams.adam_step and of the in-place re-pack behind it — agl.lib, pack-cache contract)
         if not self.sync.enabled:
+            L.note_joined()
             flat.adam_step(LR, BETA1, BETA2, ADAM_EPS, 1.0)
             return None
         main = torch.cuda.current_stream(self.dev)
         side = self.sync.side_stream(self.dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            L.note_joined(side)
             self.sync.all_reduce_(flat.g)
             flat.adam_step(LR, BETA1, BETA2, ADAM_EPS, self.sync.grad_scale)
             ev = torch.cuda.Event()

@@ -186,6 +186,9 @@ __device__ __forceinline__ void h16_scan_chunk(const float* __restrict__ w, int*
     unsigned mx = 0;
     for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mx = max(mx, red[q]);
     wexp[cc] = h16_shift(mx);
+    const int nch = Cin / 16;
+    if (cc == nch - 1)      // the 16-byte rounding of the shift array: defined bytes (packs are compared bit for bit)
+      for (int q = nch; q < ((nch + 3) & ~3); ++q) wexp[q] = 0;
   }
 }
 __device__ __forceinline__ void pack_piece_h16(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
