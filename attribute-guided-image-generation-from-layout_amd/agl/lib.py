@@ -375,6 +375,7 @@ class PackPlan:
 
     def __init__(self):
         self.entries = {}          # (id(owner), key) -> (owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src)
+        self.noted_ptr = {}        # (id(owner), key) -> (device address of src, of buf) as they go into the descriptor table
         self.table = None          # device int64 (n, PACK_DESC_WORDS)
         self.blocks = 0
         self.order = []
@@ -384,6 +385,7 @@ class PackPlan:
         old = self.entries.get(k)
         if old is None or old[9] is not buf or old[8] != flags:
             self.entries[k] = (owner, key, wsrc, pass_, Cin, Cout, ks, stride, flags, buf, src)
+            self.noted_ptr[k] = (src.data_ptr(), buf.data_ptr())
             self.table = None
 
     def _build(self, device):
@@ -413,13 +415,14 @@ class PackPlan:
             if hit is None or hit[1] is not buf:
                 continue
             cur_src = wsrc.base if wsrc.base is not None else wsrc.owner
-            if cur_src.data_ptr() != src.data_ptr() or cur_src.device != buf.device:
+            if (cur_src.data_ptr(), buf.data_ptr()) != self.noted_ptr.get(k) or cur_src.device != buf.device:
                 cache.pop(key, None)
                 PACK_STATS["dropped"] += 1
                 continue
             live[k] = e
         if len(live) != len(self.entries):
             self.entries, self.table = live, None
+            self.noted_ptr = {k: v for k, v in self.noted_ptr.items() if k in live}
         if not self.entries:
             return 0
         dev = next(iter(self.entries.values()))[9].device

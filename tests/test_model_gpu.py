@@ -874,15 +874,21 @@ def test_full_step_at_config3_size_bf16_vs_oracle():
 
 
 def test_generator_bf16_only_paths_equal_plain_bf16_arithmetic():
-    """Fidelity of the code paths that exist only in bf16 mode, HIP against HIP: one iteration at 128 px with the
-    BatchNorm / ConditionalBN apply folded into its consumer and the SPADE outputs stored as bf16 inside their consumer's node (the
-    defaults), against the same iteration with both switched off (agl.functional.NORM_FOLD / SPADE_Y16: stand-alone apply passes, fp32
-    modulated tensors) — the SAME bf16 arithmetic (operands are rounded when staged either way; the bf16 store is bit-identical, the
-    fold differs by one fp32 rounding of scale / shift), so unlike a comparison with any oracle there is no sqrt(e) perturbation in
-    between: D-step losses 1e-4 (G-step terms 5e-3: they follow the discriminators' lr * sign(g) update), generator outputs 2e-3 of their
-    maximum, every large gradient tensor within 2e-2 (discriminators) / 6e-2 (generator, through the updated discriminators) relative L2
-    — an order of magnitude below the 0.2-0.5 that separates any two independently rounded bf16 evaluations.  A kernel defect in _SpadeThenConv's bf16 y, the
-    folded staging pass, the bf16 dy operand of the weight gradient or the few-channel role swap would show up here at O(1)."""
+    """Fidelity of the code paths that exist only in bf16 mode, HIP against HIP at network level, one 128 px iteration:
+
+    (A) SPADE outputs stored as bf16 inside their consumer's node (agl.functional.SPADE_Y16, the default) against fp32-stored modulated
+        tensors: every reader rounds to bf16 when it stages the tensor anyway, so the WHOLE iteration must be BIT-IDENTICAL — all losses,
+        all eleven generator outputs, every gradient tensor of all four networks.  This is the tight check of _SpadeThenConv's bf16 y,
+        the bf16 dy operand of the transposed convolutions' weight gradients (pbww_k AUX), the bf16 x of the 7x7 few-channel layers and
+        their role swap: a defect in any of them breaks equality.
+    (B) the BatchNorm / ConditionalBN apply folded into its consumer's staging pass (NORM_FOLD) against the stand-alone apply pass.
+        Per layer the two differ in ~1 % of the outputs by one bf16 rounding (tools/fold_diag.py: rms 1e-5 of the output's rms; the
+        transform itself agrees to 5e-7) — but bf16 rounding is discontinuous, and a perturbation of ANY size is amplified to the bf16
+        noise floor within three or four layers (1e-5 -> 0.25 % of the next layer's operands flip by one 2^-8 step -> 1e-4 -> ...), which
+        is also why an oracle with bf16-rounded operands is no closer to this path than the fp32 oracle (the config-3 test above).  So
+        (B) can only assert the floor: D-step losses 1e-4, the crop encoder's mu / logvar (four folded layers deep) within 5e-3 of their
+        maximum, images within the distance bf16 has from the fp32-accurate arithmetic (max 6e-2, rms 8e-3 of the maximum).  The tight
+        statement about the fold is the per-layer one (tests/test_ops_gpu.py: folded vs two passes, both arithmetic modes)."""
     from agl import functional as F
     from agl import synth
     from agl.trainer import Trainer, batch_to_device
@@ -891,42 +897,65 @@ def test_generator_bf16_only_paths_equal_plain_bf16_arithmetic():
     O = bn["objs"].shape[0]
     gen = torch.Generator().manual_seed(5)
     eps = [torch.randn(O, 64, generator=gen) for _ in range(6)]
-    res = []
     old = (F.NORM_FOLD, F.SPADE_Y16)
-    try:
-        for on in (True, False):
-            F.NORM_FOLD, F.SPADE_Y16 = on, on
-            nets = build_nets(True)
-            tr = Trainer(*nets, pw, conv_dtype="bf16")
-            grads = {}
 
-            def grab(tag, which):
-                def f(t):
-                    grads[tag] = [(n, q.grad.detach().cpu().clone()) for net in which for n, q in net.named_parameters()]
-                return f
-            tr.on_d_backward, tr.on_g_backward = grab("D", nets[1:]), grab("G", nets[:1])
-            tr.step(batch_to_device(bn, DEV), eps[:3], eps[3:])
-            tr.finish()
-            torch.cuda.synchronize()
-            res.append((tr.loss_dict(), [t.detach().cpu() for t in tr.last_outputs], grads))
+    def run(fold, y16):
+        F.NORM_FOLD, F.SPADE_Y16 = fold, y16
+        nets = build_nets(True)
+        tr = Trainer(*nets, pw, conv_dtype="bf16")
+        grads = {}
+
+        def grab(tag, which):
+            def f(t):
+                grads[tag] = [(n, q.grad.detach().cpu().clone()) for net in which for n, q in net.named_parameters()]
+            return f
+        tr.on_d_backward, tr.on_g_backward = grab("D", nets[1:]), grab("G", nets[:1])
+        tr.step(batch_to_device(bn, DEV), eps[:3], eps[3:])
+        tr.finish()
+        torch.cuda.synchronize()
+        return tr.loss_dict(), [t.detach().cpu() for t in tr.last_outputs], grads
+    try:
+        base = run(True, True)
+        again = run(True, True)
+        y16_off = run(True, False)
+        fold_off = run(False, True)
     finally:
         F.NORM_FOLD, F.SPADE_Y16 = old
-    (la, oa, ga), (lb, ob_, gb) = res
-    for k in la:      # (the G-step terms are evaluated after the discriminators' first Adam update, lr * sign(g): rounding-level differences of a
-        tol = 1e-4 if k.startswith("D/") else 5e-3      #  small gradient flip its sign and move that weight by 2 lr — see __graft_entry__.smoke)
-        assert abs(la[k] - lb[k]) <= tol * max(1.0, abs(lb[k])), (k, la[k], lb[k])
-    for i, (a, b) in enumerate(zip(oa, ob_)):
-        err = float((a.double() - b.double()).abs().max() / max(float(b.abs().max()), 1e-6))
-        assert err <= 2e-3, ("generator output", i, err)
+    # (A) bit identity — for everything that is bit-reproducible from run to run (a few gradient slots receive their branch contributions
+    # in the order the streams finish; those are held to that run-to-run distance instead)
+    assert base[0] == y16_off[0], "losses differ with fp32-stored SPADE outputs"
+    for i, (a, b) in enumerate(zip(base[1], y16_off[1])):
+        assert torch.equal(a, b), ("generator output", i)
+    exact = loose = 0
     for tag in ("D", "G"):
-        norms = np.array([float(b.double().norm()) for _, b in gb[tag]])
-        worst = 0.0
-        for (n, a), (_, b), nb in zip(ga[tag], gb[tag], norms):
-            if nb > 1e-2 * norms.max():
-                rel = float((a.double() - b.double()).norm()) / nb
-                worst = max(worst, rel)
-                assert rel <= (2e-2 if tag == "D" else 6e-2), (tag, n, rel)      # (G: through the sign-flipped discriminators, as above)
-        print(f"[bf16-only paths on / off] {tag}: worst relative L2 gradient distance {worst:.2e}")
+        for (n, a), (_, a2), (_, b) in zip(base[2][tag], again[2][tag], y16_off[2][tag]):
+            if n in ("decoder.c4.weight", "decoder.c7.weight"):
+                # the 64|128 -> 3 7x7 layers: their weight gradient runs on the exact-fp32 few-channel kernel (few_bww_k, role swap), which
+                # does not round its operands — it reads the modulated tensor as stored, bf16 or fp32: one bf16 rounding of one operand apart
+                assert float((a.double() - b.double()).norm()) <= 1e-2 * float(a.double().norm()), ("gradient", tag, n)
+            elif torch.equal(a, a2):
+                assert torch.equal(a, b), ("gradient", tag, n, float((a - b).abs().max()))
+                exact += 1
+            else:
+                nrm = float(a.double().norm()) + 1e-30
+                assert float((a.double() - b.double()).norm()) / nrm <= 4 * float((a.double() - a2.double()).norm()) / nrm + 1e-6, ("gradient", tag, n)
+                loose += 1
+    print(f"[SPADE outputs bf16 / fp32 stored] gradient tensors bit-identical: {exact}, order-dependent from run to run: {loose}")
+    assert exact >= 50, (exact, loose)      # (the discriminators' slots and the single-branch generator layers are reproducible bit for bit)
+    # (B) the bf16 floor
+    la, lb = base[0], fold_off[0]
+    for k in la:
+        if k.startswith("D/"):
+            assert abs(la[k] - lb[k]) <= 1e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift", "mu", "logvar", "z_rand_rec", "z_rand_shift"]
+    for n, a, b in zip(names, base[1], fold_off[1]):
+        mx = max(float(b.abs().max()), 1e-6)
+        e_max, e_rms = float((a.double() - b.double()).abs().max()) / mx, float((a.double() - b.double()).pow(2).mean().sqrt()) / mx
+        print(f"[fold on / off] {n}: max {e_max:.2e} rms {e_rms:.2e} of the maximum")
+        if n in ("mu", "logvar"):
+            assert e_max <= 5e-3, (n, e_max)
+        else:
+            assert e_max <= 6e-2 and e_rms <= 8e-3, (n, e_max, e_rms)
 
 
 def test_two_trainers_driven_from_two_host_threads():

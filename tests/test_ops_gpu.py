@@ -773,6 +773,10 @@ def test_norm_folded_into_the_consuming_convolution(case, mode):
         close(rv, bnr.running_var, 1e-5, f"{tag}: running var")
         assert nbt == 1
     close(res[True][0], res[False][0], 1e-5 if mode == "split3" else 1e-2, "folded vs two passes: y")
+    if mode == "bf16":      # the tight form of that statement: the two differ by single bf16 roundings of a few staged elements (tools/fold_diag.py)
+        d = (res[True][0] - res[False][0]).double()
+        rel_rms = float(d.pow(2).mean().sqrt() / res[False][0].double().pow(2).mean().sqrt().clamp_min(1e-30))
+        assert rel_rms <= 2e-4, ("folded vs two passes: rms distance of y relative to its rms", rel_rms)
     close(res[True][1], res[False][1], 1e-4 if mode == "split3" else 2e-2, "folded vs two passes: dx")
     # the folded call leaves the partial rows of its own output (the next norm's statistics without a read of y)
     y, stats = res[True][0], res[True][8]
