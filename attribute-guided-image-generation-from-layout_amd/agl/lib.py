@@ -245,6 +245,49 @@ def work_of(name, args) -> float:
     return 0.0
 
 
+def bytes_of(name, args) -> float:
+    """Algorithmic HBM bytes of one logged convolution call: every operand once at its stored width (x / dy / mask / addend read, y /
+    dx / dw written; weights fp32 as the parameter is stored).  bench.py's roofline leg prices a launch against
+    min(pipe peak, bytes-bound) with it.  0 for calls that are not convolutions."""
+    def osz(h, ks, stride, pad, up=0):
+        return ((h << up) + 2 * pad - ks) // stride + 1
+    fl = lambda a: a if isinstance(a, int) else 0
+    if name in ("agl_conv2d_fwd", "agl_conv2d_fwd_stats"):
+        N, Cin, H, W, Cout, ks, stride, pad, up = args[8:17]
+        flags = fl(args[20]) if name == "agl_conv2d_fwd" else fl(args[18])
+        ex, ey = (2 if flags & CONV_X_BF16 else 4), (2 if flags & CONV_Y_BF16 else 4)
+        acc = 1 if (name == "agl_conv2d_fwd" and args[19]) else 0
+        return N * Cin * H * W * ex + Cout * Cin * ks * ks * 4 + N * Cout * osz(H, ks, stride, pad, up) * osz(W, ks, stride, pad, up) * ey * (1 + acc)
+    if name == "agl_conv2d_fwd_fold":
+        N, Cin, H, W, Cout, ks, stride, pad = args[12:20]
+        return N * Cin * H * W * 4 + Cout * Cin * ks * ks * 4 + N * Cout * osz(H, ks, stride, pad) * osz(W, ks, stride, pad) * 4
+    if name == "agl_conv2d_fwd_addend":
+        N, Cin, H, W, Cout, ks, stride, pad = args[9:17]
+        flags = fl(args[19])
+        ex, ey = (2 if flags & CONV_X_BF16 else 4), (2 if flags & CONV_Y_BF16 else 4)
+        no = N * Cout * osz(H, ks, stride, pad) * osz(W, ks, stride, pad)
+        return N * Cin * H * W * ex + Cout * Cin * ks * ks * 4 + no * (ey + 4)
+    if name == "agl_conv2d_fwd_shortcut":
+        N, Cin, H, W, Cout, ks, pad = args[12:19]
+        flags = fl(args[21])
+        ex, ey = (2 if flags & CONV_X_BF16 else 4), (2 if flags & CONV_Y_BF16 else 4)
+        return N * Cin * H * W * ex + Cout * Cin * ks * ks * 4 + N * Cout * H * W * ey + N * args[8] * H * W * 4
+    if name == "agl_conv2d_bwd_data":
+        N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad = args[9:19]
+        flags = fl(args[21])
+        edy, em = (2 if flags & CONV_DY_BF16 else 4), (2 if flags & CONV_MASK_BF16 else 4)
+        return N * Cout * OH * OW * edy + Cout * Cin * ks * ks * 4 + N * Cin * IH * IW * (4 + (em if args[5] else 0) + (4 if args[20] else 0))
+    if name == "agl_conv2d_bwd_weight":
+        N, Cin, H, W, Cout, OH, OW, ks = args[8:16]
+        flags = fl(args[21])
+        ex, edy = (2 if flags & CONV_X_BF16 else 4), (2 if flags & CONV_DY_BF16 else 4)
+        return N * Cin * H * W * ex + N * Cout * OH * OW * edy + Cout * Cin * ks * ks * 4
+    if name == "agl_conv2d_bwd_weight_fold":
+        N, Cin, H, W, Cout, OH, OW, ks = args[12:20]
+        return N * Cin * H * W * 4 + N * Cout * OH * OW * 4 + Cout * Cin * ks * ks * 4
+    return 0.0
+
+
 CALL_COUNT = 0      # C-ABI calls issued through call() (bench.py reports calls per training iteration)
 
 
@@ -259,7 +302,8 @@ def call(name: str, *args):
         rc = getattr(lib, name)(*args)
         e1.record()
         pipe = lib.agl_conv2d_last_pipe() if name.startswith("agl_conv2d") else -1
-        log.append((name, e0, e1, work_of(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-15:], pipe))
+        log.append((name, e0, e1, work_of(name, args), tuple(a for a in args if isinstance(a, int) and abs(a) < 100000)[-15:], pipe,
+                    bytes_of(name, args)))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

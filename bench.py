@@ -172,17 +172,22 @@ def cpu_baseline(max_seconds=30.0):
 
 def hbm_traffic(tag):
     """HBM bytes per iteration of the normalisation family and of the convolution family from the committed rocprofv3 PMC passes
-    (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/hbm_table.py writes the file).  The newest
-    round's file that has the tag; None if not collected."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f).get(tag)
-            if d:
-                return d
-        except (OSError, ValueError):
-            pass
-    return None
+    (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/hbm_table.py writes the file).  This round's
+    file; None when it was not collected for the loaded library's ABI / split form."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")) as f:
+            d = json.load(f).get(tag)
+    except (OSError, ValueError):
+        return None
+    if not d:
+        return None
+    # a counter profile describes the kernels it was collected on: quote it only for a library of the same ABI and split form
+    # (ADVICE r4: the figure must not go stale silently); `collected_at` names the commit
+    from agl import lib as _L
+    lib = _L.load()
+    if d.get("abi") != lib.agl_version() or d.get("split_products") != lib.agl_conv2d_split_products():
+        return None
+    return d
 
 
 def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
@@ -258,7 +263,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             cycles_per_ms = 2_000_000 / max(1e-3, c0.elapsed_time(c1))
             torch.cuda._sleep(int(min(800.0, 2.5 * 1e3 * dt / steps) * cycles_per_ms))
             L.EVENT_LOG = [] if rank == 0 else None
-            packs0 = L.PACK_STATS["packs"]
+            packs0, fused0 = L.PACK_STATS["packs"], L.PACK_STATS["fused"]
             one_step()
             tr.finish()
             fence()
@@ -280,7 +285,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
             only = os.environ.get("AGL_DUMP_PIPE")             # e.g. 0: the launches that stayed on the exact-fp32 kernels
-            for name, e0, e1, f, dims, _pipe in conv:
+            for name, e0, e1, f, dims, _pipe, _bytes in conv:
                 if only is not None and str(_pipe) != only:
                     continue
                 k = (name.replace('agl_conv2d_', ''), dims)
@@ -308,6 +313,17 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             by_pipe[PIPE_NAME[pipe]] = {"launches": len(sel), "ms": round(ms, 3), "executed_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms else None,
                                         "peak_tflops": round(PIPE_PEAK[pipe], 1), "frac": round(fl / (PIPE_PEAK[pipe] * 1e12) / (ms * 1e-3), 4) if ms else None}
         frac = t_at_peak / (conv_ms * 1e-3)
+        # What binds each launch: its algorithmic HBM bytes — every operand once at its stored width (agl.lib.bytes_of) —
+        # give a second lower bound, bytes / 8 TB/s, beside FLOPs / pipe peak; the launch's roof is the larger of the two.
+        # frac_binding = sum(roof time) / sum(measured time); hbm_roofed_share = share of the family's measured time spent in launches
+        # whose byte bound exceeds their matrix-pipe bound (below the ridge point of their pipe).
+        t_roof = ms_hbm_roofed = alg_bytes = 0.0
+        for e in conv:
+            t_m, t_h = e[3] / (PIPE_PEAK[e[5]] * 1e12), e[6] / (PEAK_HBM_GBS * 1e9)
+            t_roof += max(t_m, t_h)
+            alg_bytes += e[6]
+            if t_h > t_m:
+                ms_hbm_roofed += e[1].elapsed_time(e[2])
         # achieved = executed (fp32-equivalent) FLOPs over the launches' time — comparable from round to round and between arithmetic
         # modes; peak = the FLOP-weighted harmonic mean of the peaks of the pipes the launches ran on, so that
         # frac = achieved / peak = time at peak / time taken.  The bf16 issue rate (split products counted six times) is its own key.
@@ -317,14 +333,21 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
         tr_conv = hbm_traffic(f"{res}_{dtype}")
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(achieved / frac, 1), "unit": "TFLOP/s",
                 "frac": round(frac, 4),
+                "frac_binding": round(t_roof / (conv_ms * 1e-3), 4),
+                "hbm_roofed_share_of_time": round(ms_hbm_roofed / conv_ms, 4) if conv_ms else None,
+                "algorithmic_bytes_per_launch": round(alg_bytes / max(1, len(conv))),
                 "traffic": round(tr_conv["conv_bytes_per_iteration"] / max(1, len(conv))) if tr_conv and "conv_bytes_per_iteration" in tr_conv else None,
-                "traffic_source": tr_conv.get("source") if tr_conv and "conv_bytes_per_iteration" in tr_conv else None,
+                "traffic_source": (f'{tr_conv.get("source")} @ {tr_conv.get("collected_at")}' if tr_conv and "conv_bytes_per_iteration" in tr_conv else None),
                 "achieved_bf16_issue": round(frac * PEAK_BF16_MFMA_TFLOPS, 2) if on_bf16 else None,
                 "definition": "achieved = executed fp32-equivalent FLOPs of all convolution launches / their measured time (one stream, HIP events per "
                               "launch); peak = FLOP-weighted harmonic mean of the peak of the pipe each launch ran on (fp32 157.3, bf16 MFMA 2500, "
                               f"split-operand 16-bit MFMA 2500/{int(round(PEAK_BF16_MFMA_TFLOPS / PIPE_PEAK[3]))} fp32-equivalent); frac = achieved / peak = time at peak / time taken; "
                               f"achieved_bf16_issue = frac x 2500 (16-bit MFMA issue rate: split products count {int(round(PEAK_BF16_MFMA_TFLOPS / PIPE_PEAK[3]))}x); traffic = HBM bytes per "
-                              "launch of the family from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)",
+                              "launch of the family from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE); algorithmic_bytes_per_launch = "
+                              "every operand of a launch once at its stored width, family average (traffic / that = wasted-traffic ratio); "
+                              "frac_binding = sum over launches of max(FLOPs / pipe peak, algorithmic bytes / 8 TB/s) / measured time: the "
+                              "utilisation of whichever roof binds each launch; hbm_roofed_share_of_time = share of the measured time in "
+                              "launches whose byte bound is the larger one",
                 "by_pipe": by_pipe,
                 "kernel": "convolution family: pconv_k / pbww_k (bf16 matrix cores) + igemm_f32<Fwd|BwdData|BwdWeight|Pos*> + patch_conv + "
                           "few_bww_k / small_cout_conv incl. weight packing and slab / split-K reductions (all agl_conv2d_* launches of one step)",
@@ -332,7 +355,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 "executed_flops_per_step": executed, "algorithmic_flops_per_step": flops_step,
                 "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3),
                 "weight_packs_per_step": L.PACK_STATS["packs"] - packs0,      # individual pack launches (derived weights: ConvLSTM halves, pooled filters)
-                "fused_repacks_per_step": 2 if L.PACK_STATS.get("fused") else 0}      # one launch per arena after its Adam step (agl.lib.PackPlan)
+                "fused_repacks_per_step": L.PACK_STATS["fused"] - fused0}      # launches of agl.lib.PackPlan.repack in the instrumented step (one per arena)
         nrm = [e for e in log if e[0] in NORM_NAMES]
         nrm_ms = sum(e[1].elapsed_time(e[2]) for e in nrm)
         nbytes = sum(e[3] for e in nrm)
@@ -343,7 +366,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4),
                         "traffic": round(tr_["bytes_per_iteration"] / max(1, len(nrm))) if tr_ else None,
-                        "traffic_source": tr_["source"] if tr_ else None,
+                        "traffic_source": (f'{tr_["source"]} @ {tr_.get("collected_at")}' if tr_ else None),
                         "algorithmic_bytes_per_launch": round(nbytes / max(1, len(nrm))),
                         "kernel": "normalisation family: bn_stats_partial/final + norm_apply_fwd + norm_bwd_rows/channels/apply "
                                   "(agl_bn_stats, agl_norm_apply_fwd, agl_norm_bwd launches of one step; algorithmic bytes of "

@@ -72,7 +72,7 @@ def main():
                 tot_n += n
         conv_fam = ("pconv_k", "pbww_k", "igemm_f32", "patch_conv", "small_cout_conv", "few_bww_k", "few_cin_fwd_k", "splitk_epilogue",
                     "slab_reduce", "pack_weights_k", "pack_vert_k", "vert_diag_sum_k", "phase_edge_k", "linear_bww_k", "linear_bwd_data_k",
-                    "tap_major_to_w_k", "flip_transpose_w", "transpose_in")
+                    "tap_major_to_w_k", "flip_transpose_w", "transpose_in", "pack_weights_h16_k", "h16_scan_k", "h16_scan_many_k", "pack_many_k")
         conv_b = conv_n = 0.0
         for secs, k, n, us, fb, wb, raw, cor in rows:
             if any(x in k for x in conv_fam):
@@ -83,7 +83,12 @@ def main():
             data = json.load(open(out_json))
         # bench.py's HBM roofline object counts one "launch" per C-ABI call of the family (a call issues 2-3 kernels), so the
         # figure it needs is the family's HBM bytes per training iteration; it divides by its own calls-per-iteration count
-        data[tag] = {"bytes_per_iteration": round(tot_b / iters), "kernel_launches_per_iteration": round(tot_n / iters),
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "attribute-guided-image-generation-from-layout_amd"))
+        from agl import lib as _L
+        _lib = _L.load()
+        data[tag] = {"abi": _lib.agl_version(), "split_products": _lib.agl_conv2d_split_products(),
+                     "collected_at": os.environ.get("AGL_PROFILE_COMMIT", "unknown"),
+                     "bytes_per_iteration": round(tot_b / iters), "kernel_launches_per_iteration": round(tot_n / iters),
                      "conv_bytes_per_iteration": round(conv_b / iters), "conv_kernel_launches_per_iteration": round(conv_n / iters),
                      "source": os.path.relpath(out_csv, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
                      "note": "FETCH_SIZE x2 (16-byte reads) + WRITE_SIZE, KiB -> bytes, summed over the normalisation-family kernels"}
