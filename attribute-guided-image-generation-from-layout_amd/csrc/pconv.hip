@@ -155,9 +155,14 @@ __device__ __forceinline__ void pack_piece(const float* __restrict__ w, u32x4* _
 // (one 1024-thread workgroup per chunk reads the chunk's 16 * M * KK source floats in runs of consecutive addresses, eight loads in flight
 // per thread, and leaves the shift in wexp[cc] behind the planes, where the consumer reads it as a scalar per stage) and then one thread
 // per 16-byte piece as in pack_piece: wp[plane][i] = {hi, lo'} of w * 2^-shift.
+constexpr int H16_SCAN_G = 8;      // workgroups that share the scan of one chunk (slices of its rows); partial maxima behind the shifts
 __device__ __forceinline__ void h16_scan_chunk(const float* __restrict__ w, int* __restrict__ wexp, int M, int Cin, int KK, int w_sm, int w_sc,
-                                               int cc, unsigned* red) {
+                                               int cc, int g, unsigned* red) {
   const int cn = min(16, Cin - 16 * cc);                   // channels of this chunk that exist
+  const int nch = Cin / 16, nchp = (nch + 3) & ~3;
+  const int m_lo = (int)((long)M * g / H16_SCAN_G), m_hi = (int)((long)M * (g + 1) / H16_SCAN_G);      // this workgroup's rows
+  w += (long)m_lo * w_sm;
+  M = m_hi - m_lo;
   const long total = (long)cn * M * KK;
   const float* const wc = w + (long)(16 * cc) * w_sc;
   const bool m_inner = w_sm < w_sc;                         // which of (row m, channel c) continues the run of taps
@@ -185,11 +190,16 @@ __device__ __forceinline__ void h16_scan_chunk(const float* __restrict__ w, int*
   if (threadIdx.x == 0) {
     unsigned mx = 0;
     for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mx = max(mx, red[q]);
-    wexp[cc] = h16_shift(mx);
-    const int nch = Cin / 16;
-    if (cc == nch - 1)      // the 16-byte rounding of the shift array: defined bytes (packs are compared bit for bit)
-      for (int q = nch; q < ((nch + 3) & ~3); ++q) wexp[q] = 0;
+    reinterpret_cast<unsigned*>(wexp)[nchp + cc * H16_SCAN_G + g] = mx;      // partial maximum (h16_chunk_shift combines them)
   }
+}
+// shift of chunk cc from the partial maxima (every reader computes the same value)
+__device__ __forceinline__ int h16_chunk_shift(const int* __restrict__ wexp, int nch, int cc) {
+  const unsigned* pm = reinterpret_cast<const unsigned*>(wexp) + ((nch + 3) & ~3) + cc * H16_SCAN_G;
+  unsigned mx = 0;
+#pragma unroll
+  for (int q = 0; q < H16_SCAN_G; ++q) mx = max(mx, pm[q]);
+  return h16_shift(mx);
 }
 __device__ __forceinline__ void pack_piece_h16(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
                                                int flip, int mpad, int phase4, long per_plane, long i) {
@@ -202,7 +212,14 @@ __device__ __forceinline__ void pack_piece_h16(const float* __restrict__ w, u32x
     const int phase = tap >> 2, thp = (tap >> 1) & 1, twp = tap & 1;
     st = ((((phase >> 1) + 1) & 1) + 2 * (1 - thp)) * 4 + (((phase & 1) + 1) & 1) + 2 * (1 - twp);
   }
-  const float fac = exp2i(-reinterpret_cast<const int*>(wp + 2 * per_plane)[cc]);
+  int* const wexp = reinterpret_cast<int*>(wp + 2 * per_plane);
+  const int nch = (Cin + 15) / 16, sh = h16_chunk_shift(wexp, nch, cc);
+  if (m == 0 && tap == 0 && (r & 1) == 0) {      // one piece per chunk publishes the shift the consumers read (wexp[cc]; padding defined)
+    wexp[cc] = sh;
+    if (cc == nch - 1)
+      for (int q = nch; q < ((nch + 3) & ~3); ++q) wexp[q] = 0;
+  }
+  const float fac = exp2i(-sh);
   f16x8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -217,7 +234,7 @@ __device__ __forceinline__ void pack_piece_h16(const float* __restrict__ w, u32x
 __global__ __launch_bounds__(1024) void h16_scan_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc,
                                                    long per_plane) {
   __shared__ unsigned red[16];
-  h16_scan_chunk(w, reinterpret_cast<int*>(wp + 2 * per_plane), M, Cin, KK, w_sm, w_sc, (int)blockIdx.x, red);
+  h16_scan_chunk(w, reinterpret_cast<int*>(wp + 2 * per_plane), M, Cin, KK, w_sm, w_sc, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 // ... for a descriptor table (pack_many_k): blockIdx.y = row, blockIdx.x strides over the row's chunks
 __global__ __launch_bounds__(1024) void h16_scan_many_k(const long long* __restrict__ d) {
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(1024) void h16_scan_many_k(const long long* __restr
   const int nch = (int)r[3] / 16;
   for (int cc = blockIdx.x; cc < nch; cc += gridDim.x)
     h16_scan_chunk(reinterpret_cast<const float*>(r[0]), reinterpret_cast<int*>(reinterpret_cast<u32x4*>(r[1]) + 2 * r[11]), (int)r[2], (int)r[3], (int)r[4],
-                   (int)r[5], (int)r[6], cc, red);
+                   (int)r[5], (int)r[6], cc, (int)blockIdx.z, red);
 }
 __global__ void pack_weights_h16_k(const float* __restrict__ w, u32x4* __restrict__ wp, int M, int Cin, int KK, int w_sm, int w_sc, int flip,
                                    int mpad, int nch, int phase4) {
@@ -1540,7 +1557,8 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
 
 // planes of a packed weight buffer for the ABI-level nsplit (1 or 3), and the bytes behind them (H16: one shift per 16-channel chunk)
 static inline int pack_planes(int nsplit) { return nsplit == 3 ? SPL : 1; }
-static inline long pack_tail_bytes(int nch, int nsplit) { return (nsplit == 3 && SPL == 2) ? (long)round_up(nch * 4, 16) : 0; }
+// (H16 tail: nch shifts rounded up to 16 bytes, then H16_SCAN_G partial maxima per chunk)
+static inline long pack_tail_bytes(int nch, int nsplit) { return (nsplit == 3 && SPL == 2) ? (long)round_up(nch * 4, 16) + (long)nch * H16_SCAN_G * 4 : 0; }
 long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit) {
   if (!(ks == 1 || ks == 3 || ks == 4 || ks == 5) || Cin % 16 != 0 || Cout < 48) return 0;
   return (long)pack_planes(nsplit) * (Cin / 16) * 2 * ks * ks * round_up(Cout, 128) * 16 + pack_tail_bytes(Cin / 16, nsplit);
@@ -1849,7 +1867,7 @@ void pconv_pack_desc(const float* w, void* packed, int M, int Cred, int ks, int 
 }
 int pconv_pack_many(const void* rows_dev, int n, long total_blocks, hipStream_t st, const char* name) {
   if (SPL == 2) {      // the chunk scales of the fp16 hi / lo rows first (rows of the one-plane form return at once)
-    hipLaunchKernelGGL(h16_scan_many_k, dim3(64, (unsigned)n), dim3(1024), 0, st, (const long long*)rows_dev);
+    hipLaunchKernelGGL(h16_scan_many_k, dim3(64, (unsigned)n, H16_SCAN_G), dim3(1024), 0, st, (const long long*)rows_dev);
     AGL_CHECK_LAUNCH(name);
   }
   hipLaunchKernelGGL(pack_many_k, dim3((unsigned)total_blocks), dim3(256), 0, st, (const long long*)rows_dev, n);
@@ -1861,7 +1879,7 @@ int pconv_pack(const float* w, void* packed, int M, int Cred, int ks, int w_sm, 
   const int KK = phase4 ? 16 : ks * ks, nch = Cred / 16, mpad = round_up(M, 128);
   const long per_plane = (long)nch * 2 * KK * mpad;
   if (pack_planes(nsplit) == 2) {
-    hipLaunchKernelGGL(h16_scan_k, dim3((unsigned)nch), dim3(1024), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc, per_plane);
+    hipLaunchKernelGGL(h16_scan_k, dim3((unsigned)nch, H16_SCAN_G), dim3(1024), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc, per_plane);
     AGL_CHECK_LAUNCH(name);
     hipLaunchKernelGGL(pack_weights_h16_k, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, KK, w_sm, w_sc,
                        flip, mpad, nch, phase4);
