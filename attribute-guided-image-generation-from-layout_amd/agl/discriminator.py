@@ -44,7 +44,7 @@ def _fork(x, c1, w1, in_relu):
     return c1(x, in_relu=in_relu, relu=True, relu_grad_by_consumer=True, weight=w1), F.avg_pool2(x, in_relu=in_relu)
 
 
-FORK = os.environ.get("AGL_D_FORK", "1") != "0"      # A/B switch: 0 = two graph nodes, autograd adds their input gradients
+FORK = True      # False: two graph nodes, autograd adds their input gradients (closed A/B, round 3; tests flip it in process)
 
 
 class OptimizedBlock(nn.Module):

@@ -838,7 +838,7 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         ctx.wsrc = getattr(w3, "_agl_wsrc", None)
         x, w3 = _c(x), _c(w3)
         # bf16 arithmetic: the filtered map is read by this convolution (and its weight gradient) only — written as bf16 it holds the
-        # very values they would round it to, at half the traffic (where both run on the matrix-core kernels; AGL_BOX_BF16=0: fp32)
+        # very values they would round it to, at half the traffic (where both run on the matrix-core kernels; BOX_BF16 False: fp32)
         N, Cc, H, W = x.shape
         as_bf16 = BOX_BF16 and L.box_input_as_bf16(N, Cc, H + 1, W + 1, w3.shape[0], need_bww=ctx.needs_input_grad[1])
         xb = L.box2_fwd(x, bf16=as_bf16)
@@ -891,11 +891,12 @@ class _Conv3x3AvgPool(torch.autograd.Function):
         return dx, dw, db, None
 
 
-BOX_BF16 = os.environ.get("AGL_BOX_BF16", "1") != "0"      # A/B switch: 0 keeps the box-filtered maps in fp32 in bf16 mode
-H_BF16 = os.environ.get("AGL_H_BF16", "1") != "0"          # ... and the first-convolution output of a flat discriminator block
-BOX_FORM = os.environ.get("AGL_BOX_FORM", "1") != "0"     # False: the 4x4 stride-2 form with the pooled filter (A/B tests)
-BOX_BWD = os.environ.get("AGL_BOX_BWD", "0") == "1"   # input gradient through the 3x3/stride-2 phases + box transpose
-BOX_BWD_MIN = int(os.environ.get("AGL_BOX_BWD_MIN", "16"))   # ... used from this map size up (measured: 0.24 vs 0.34 ms at
+# (Closed A/B experiments of rounds 2-4: plain module constants now — tests flip them in process; no environment switches.)
+BOX_BF16 = True       # bf16 arithmetic stores the box-filtered maps as bf16 (False: fp32)
+H_BF16 = True         # ... and the first-convolution output of a flat discriminator block
+BOX_FORM = True       # False: the 4x4 stride-2 form with the pooled filter (equivalence tests)
+BOX_BWD = False       # input gradient through the 3x3/stride-2 phases + box transpose
+BOX_BWD_MIN = 16      # ... used from this map size up (measured: 0.24 vs 0.34 ms at
                                                              # 32x32 and 16x16, but 0.48 vs 0.30 ms at 8x8)
 
 

@@ -16,11 +16,11 @@ from . import nn as A
 from .convlstm import SequencePlan, layout_conv_lstm
 
 import os
-FRONT_STREAMS = os.environ.get("AGL_FRONT_STREAMS", "1") != "0"      # A/B switch: the rand / shift layout-encoder fronts on their branch streams
+FRONT_STREAMS = True      # the rand / shift layout-encoder fronts on their branch streams (closed A/B, round 4)
 # opt-in: the reconstruction branch's front + ConvLSTM on the third branch stream, so that its backward recurrence overlaps the batched
 # rand / shift one.  Measured on one box, alternating (profiles/r04_ab_switches.txt): 466 / 472 images/s with it against 483 / 483 without
 # at 64 px — two compute-bound recurrences beside each other run slower than one after the other — so the default keeps it off.
-REC_CLSTM_STREAM = os.environ.get("AGL_REC_CLSTM_STREAM", "0") == "1"
+REC_CLSTM_STREAM = False
 
 
 def get_z_random(batch_size, z_dim, random_type="gauss"):

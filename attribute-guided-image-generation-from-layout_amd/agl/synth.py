@@ -25,6 +25,26 @@ def _raster(mask, y0, y1, x0, x1, R):
     mask[0, round(y0 * R):round(y1 * R), round(x0 * R):round(x1 * R)] = 1.0
 
 
+def balanced_object_counts(images_per_rank: int, world: int, seed: int = 1234):
+    """Object counts per image for `world` data-parallel ranks of `images_per_rank` images each, drawn like make_batch draws them
+    (P ~ U{3..9}) for the GLOBAL batch and then dealt to the ranks so that every rank gets the same number of images and (nearly) the
+    same number of objects: the object-level work (crop / layout encoders, object and attribute discriminators, ~60 % of the FLOPs)
+    scales with the object count and a data-parallel step takes as long as its slowest rank.  Greedy: images by decreasing object
+    count, each to the rank with the fewest objects among those that still have room (longest-processing-time rule).  Deterministic in
+    (images_per_rank, world, seed); every rank computes the same table and takes its row."""
+    rng = np.random.default_rng(seed)
+    P = rng.integers(3, 10, size=images_per_rank * world)
+    order = np.argsort(-P, kind="stable")
+    load = np.zeros(world, np.int64)
+    rows = [[] for _ in range(world)]
+    for i in order:
+        free = [r for r in range(world) if len(rows[r]) < images_per_rank]
+        r = min(free, key=lambda q: (load[q], q))
+        rows[r].append(int(P[i]))
+        load[r] += int(P[i])
+    return [np.asarray(sorted(row, reverse=True), dtype=np.int64) for row in rows]
+
+
 def make_batch(n_images: int, image_size: int, *, seed: int = 1234, z_dim: int = 64,
                objs_per_image=None, n_attr: int = NUM_ATTRIBUTES,
                n_classes: int = NUM_OBJECT_CLASSES) -> Dict[str, np.ndarray]:

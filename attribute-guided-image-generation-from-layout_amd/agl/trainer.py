@@ -25,6 +25,8 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
+G_REC_STREAM = False      # the G step's reconstruction branch on a stream of its own (closed experiment, round 3)
+
 from . import functional as F
 from . import lib as L
 from . import losses as LS
@@ -184,7 +186,7 @@ class Trainer:
             F.BN_TAPE = None
             e = G.draw_eps(sh, eps)
             bs = G.__dict__.get("branch_streams")
-            if bs is not None and len(bs) >= 3 and G.batch_clstm and G.training and os.environ.get("AGL_G_REC_BESIDE_B", "1") != "0":
+            if bs is not None and len(bs) >= 3 and G.batch_clstm and G.training:
                 rec = G.part_rec_nograd_beside_b(sh, e[0], tape_b)      # the graph-less reconstruction branch beside part_b
             else:
                 with torch.no_grad():
@@ -354,7 +356,7 @@ class Trainer:
         # updates of the first evaluation are complete; the CPU draws are consumed in the reference's order)
         out_g = None
         if gen_state is not None and self.d_streams:
-            if self.g_streams and os.environ.get("AGL_G_REC_STREAM", "0") == "1":   # opt-in: on its own stream with its own gradient arena
+            if self.g_streams and G_REC_STREAM:   # (measured slower: 460 vs 470 images/s; kept as a constant for the equivalence test)
                 # (measured on one box, alternating: 460 images/s with it against 470 without — beside the D step it competes with
                 #  the chains on the critical path — so the default keeps it on the main stream)
                 main, g2 = torch.cuda.current_stream(), self.g_streams[2]

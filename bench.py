@@ -96,6 +96,10 @@ def parse_args(argv=None):
                          "accumulation) in the kernels of csrc/pconv.hip, exact fp32 MFMA elsewhere; f32: exact fp32 MFMA "
                          "everywhere; bf16: operands rounded to bf16 (configs 3/5).  Statistics, SN, losses, Adam: fp32 always")
     ap.add_argument("--seed", type=int, default=1234, help="synthetic batch seed (rank is added)")
+    ap.add_argument("--vary-batch", type=int, default=4, metavar="K",
+                    help="after the timed steps on the fixed batch, time the same number of steps cycling K pre-resident batches with "
+                         "different object counts (real training changes O every batch: workspaces, pack plans and allocator state must "
+                         "cope); reported as `vary_batch` beside the fixed-batch value; 0 = skip")
     ap.add_argument("--two-generator-passes", action="store_true",
                     help="evaluate the whole generator twice per iteration like the reference loop instead of reusing the "
                          "draw-independent parts of the first evaluation (identical results; reported for comparison)")
@@ -201,7 +205,10 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
     pw = torch.from_numpy(synth.make_pos_weight())
     # attribute_est is derived on device from the pre-step D_att logits, as the reference loop does (train64.py:156-166)
     tr = Trainer(*nets, pw, estimate_attributes=True, reuse_generator_pass=not a.two_generator_passes, conv_dtype=dtype)
-    bn = synth.make_batch(per_gpu, res, seed=a.seed + rank)
+    # one rank: the plain draw (P ~ U{3..9} per image); N ranks: the global batch's images dealt so that the ranks' object counts match
+    # (agl.synth.balanced_object_counts) — the weak-scaling step is as slow as the rank with the most objects
+    counts = synth.balanced_object_counts(per_gpu, world, seed=a.seed)[rank] if world > 1 else None
+    bn = synth.make_batch(per_gpu, res, seed=a.seed + rank, objs_per_image=counts)
     b = batch_to_device(bn, dev)
     O = int(bn["objs"].shape[0])
     gen = torch.Generator().manual_seed(100 + rank)
@@ -230,6 +237,33 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
     dt = time.perf_counter() - t0
     abi_calls = (L.CALL_COUNT - calls0) / max(1, steps)
     objs = [O]
+    vary = None
+    if a.vary_batch and a.vary_batch > 1:
+        # K batches with different image contents and object counts, all resident before the clock starts (no H2D in the timed region)
+        K = a.vary_batch
+        pool = []
+        for i in range(K):
+            bi = synth.make_batch(per_gpu, res, seed=a.seed + rank + 1000 * (i + 1))
+            Oi = int(bi["objs"].shape[0])
+            gi = torch.Generator().manual_seed(200 + rank + i)
+            pool.append((batch_to_device(bi, dev), [torch.randn(Oi, 64, generator=gi).to(dev) for _ in range(6)], Oi))
+        for bb, ee, _ in pool:                     # one untimed pass: every object count has been seen once (allocations, plans)
+            tr.step(bb, ee[:3], ee[3:])
+        tr.finish()
+        fence()
+        tv = time.perf_counter()
+        for i in range(steps):
+            bb, ee, _ = pool[i % K]
+            tr.step(bb, ee[:3], ee[3:])
+        tr.finish()
+        fence()
+        dv = time.perf_counter() - tv
+        if world > 1:
+            t = torch.tensor([dv], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dv = float(t.item())
+        vary = {"k": K, "value": round(per_gpu * world * steps / dv, 3), "unit": "images/s", "ms_per_step": round(1e3 * dv / steps, 3),
+                "objects_per_batch_rank0": [o for _, _, o in pool], "peak_device_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -394,7 +428,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                        # host time to enqueue the K steps; the HIP queue throttles the host to the GPU's pace, so this is an upper
                        # bound of the host cost (measured un-throttled at batch 2: 60 ms per iteration, tools/host_profile.py)
                        "host_enqueue_ms_per_step_upper_bound": round(1e3 * t_host / steps, 3)},
-            "roofline": roof, "roofline_hbm": roof_hbm}
+            "roofline": roof, "roofline_hbm": roof_hbm, "vary_batch": vary}
 
 
 def main():
@@ -416,9 +450,11 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if a.dry_run:
+        from agl import synth
         if world > 1:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
             dist.barrier()
+        objs_rank = [int(c.sum()) for c in synth.balanced_object_counts(64, world, seed=a.seed)] if world > 1 else None
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -430,7 +466,7 @@ def main():
                               "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "none (launcher dry run, no training step)",
                               "dry_run": True, "max_rank_seconds": float(t.item()),
-                              "config": {"workload": "dry run", "parallelism": f"dp{world}"}}), flush=True)
+                              "config": {"workload": "dry run", "parallelism": f"dp{world}", "objects_per_rank": objs_rank}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -463,7 +499,9 @@ def main():
         # BASELINE config 3 (config 5 when N > 1): the 128 px half of the metric, bf16 MFMA convolutions
         second = run_workload(a, 128, "bf16", 32, min(a.steps, 10), min(a.warmup, 3), dev, rank, world, dist)
         # the headline workload once more with exact fp32 MFMA in every convolution (v_mfma_f32_32x32x2_f32), for comparison
-        exact = run_workload(a, 64, "f32", 64, min(a.steps, 6), min(a.warmup, 2), dev, rank, world, dist)
+        a_fixed = argparse.Namespace(**vars(a))
+        a_fixed.vary_batch = 0
+        exact = run_workload(a_fixed, 64, "f32", 64, min(a.steps, 6), min(a.warmup, 2), dev, rank, world, dist)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -472,7 +510,7 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_r["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dtype], "data": "synthetic",
                "config": main_r["config"], "roofline": main_r["roofline"], "roofline_hbm": main_r["roofline_hbm"],
-               "cpu_baseline": cpu}
+               "cpu_baseline": cpu, "vary_batch": main_r.get("vary_batch")}
         if second is not None:
             second["metric"] = "images/sec per G+D train step (128px)"
             second["unit"] = "images/s"

@@ -958,6 +958,33 @@ def test_generator_bf16_only_paths_equal_plain_bf16_arithmetic():
             assert e_max <= 6e-2 and e_rms <= 8e-3, (n, e_max, e_rms)
 
 
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_soak_every_iteration_a_new_batch(mode):
+    """Real training changes the image contents and the object count O every iteration (the bench reuses one resident batch): ten
+    iterations on ten different synthetic batches (11-16 images, O between ~50 and ~110) must keep every loss finite, keep the
+    fused re-pack plan in use (no individual re-pack of a planned parameter), and must not grow the device memory after the first
+    iterations have sized the workspaces (tools/soak.py is the long form of this test)."""
+    import math
+    from agl import lib as L, synth
+    from agl.trainer import Trainer, batch_to_device
+    nets = build_nets(False)
+    tr = Trainer(*nets, torch.from_numpy(synth.make_pos_weight()), conv_dtype=mode)
+    torch.cuda.reset_peak_memory_stats()
+    mem, objs = [], []
+    for i in range(10):
+        bn = synth.make_batch(16 - (i % 6), 64, seed=500 + i)
+        objs.append(int(bn["objs"].shape[0]))
+        tr.step(batch_to_device(bn, DEV))
+        tr.finish()
+        torch.cuda.synchronize()
+        d = tr.loss_dict()
+        assert all(math.isfinite(v) for v in d.values()), (i, d)
+        mem.append(torch.cuda.max_memory_allocated() / 2**30)
+    assert len(set(objs)) >= 6, objs
+    assert mem[-1] <= mem[6] * 1.10 + 0.25, f"device memory keeps growing over changing batches: {mem}"
+    assert L.PACK_STATS["fused"] >= 20
+
+
 def test_two_trainers_driven_from_two_host_threads():
     """the schedule of an iteration lives in module-level switches (BatchNorm tape, deferred updates, private
     gradient arenas, convolution flags, weight-gradient streams); Trainer.step() holds a process lock and restores them, so two
