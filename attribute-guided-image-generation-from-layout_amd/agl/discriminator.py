@@ -141,7 +141,8 @@ class _Discriminator(nn.Module):
                 for m in (c1, c2, b.sc):
                     w = _w(W, m)
                     params += [w if w is not None else m.weight, m.bias]
-            h = T.run(h, spec, out16, params)
+            blocked = T.blocked_ok(kinds, chans, k0, k1, out16, x.shape[0], x.shape[2], x.shape[3])
+            h = T.run(h, spec, out16, params, blocked=blocked)
         for blk in blocks[k1:]:
             h = blk(h, W)
         return F.sum_hw(h, in_relu=True)

@@ -22,6 +22,16 @@ bf16 tensors, weight gradients with bf16 x operands); the pooled-filter weight g
 
 `cover()` decides per call which prefix of blocks runs here: every launch of a covered block must be one of the matrix-core forms
 that read / write bf16 (asked through the C ABI's predicates); the remaining blocks run as before.  Only in bf16 arithmetic.
+
+CHANNEL-BLOCKED FORM (D_BLOCKED, round 5).  The bf16 tensors of the node — h of every block and the block outputs handed to the next
+covered block — are stored as [N][C/8][H][W][8] (include/agl.h AGL_CONV_X_BLOCKED ...): the convolutions that read them stage one aligned
+16-byte piece per 8 channels of a pixel instead of eight 2-byte element loads a channel stride apart (the staging pass of the NCHW form is
+what bounds the bf16-mode kernels), and the producers store half a piece per lane straight from the accumulators.  Readers:
+c1 (3x3, blocked in -> blocked out), the pooled 4x4 / stride-2 convolution (blocked in -> fp32 NCHW out), both weight gradients (blocked x),
+the input gradients (blocked ReLU mask; dy / dx stay fp32 NCHW), the shortcut's average pool and its backward (blocked in / blocked mask).
+An fp32 block input (the image discriminator's first covered block) is converted once (agl_to_blocked) for the convolution operands; its
+pool and masks keep reading the fp32 tensor.  Same values as the NCHW bf16 form in every element (tests: bit identity of the node's output
+and of every gradient against D_BLOCKED = False); taken when every launch of every covered block has its blocked form (blocked_ok).
 """
 from __future__ import annotations
 
@@ -34,6 +44,7 @@ from . import functional as F
 from . import lib as L
 
 D_TRUNK = os.environ.get("AGL_D_TRUNK", "1") != "0"      # A/B switch: 0 = the per-op graph in every arithmetic
+D_BLOCKED = os.environ.get("AGL_D_BLOCKED", "1") != "0"  # A/B switch: 0 = NCHW bf16 tensors inside the node (the round-4 form)
 
 
 def _pooled(w3):
@@ -80,6 +91,46 @@ def down_ok(N, C, H, W, Cout, in_bf16):
 def out_bf16_ok(N, Cin, H2, W2, Cout):
     """The 1x1 shortcut + addend launch of a down block can write the block output as bf16."""
     return bool(L.load().agl_conv2d_fwd_writes_bf16_y(N, Cin, H2, W2, Cout, 1, 1, 0, 0, 0, 0, L.CONV_FLAGS))
+
+
+_blocked_memo = {}
+
+
+def blocked_ok(kinds, chans, k0, k1, out16, N, H, W):
+    """Every launch of the covered blocks [k0, k1) has its channel-blocked form (C ABI predicates) — all or nothing per call."""
+    if not D_BLOCKED or k1 <= k0:
+        return False
+    key = (tuple(kinds), tuple(chans), k0, k1, tuple(out16), N, H, W, L.CONV_FLAGS)
+    hit = _blocked_memo.get(key)
+    if hit is None:
+        hit = _blocked_memo[key] = _blocked_ok(kinds, chans, k0, k1, out16, N, H, W)
+    return hit
+
+
+def _blocked_ok(kinds, chans, k0, k1, out16, N, H, W):
+    lib, fl = L.load(), L.CONV_FLAGS
+    XB, YB = L.CONV_X_BF16 | L.CONV_X_BLOCKED, L.CONV_Y_BF16 | L.CONV_Y_BLOCKED
+    h, w = H, W
+    if kinds[0] == "first_down":
+        h, w = H // 2, W // 2
+    for k in range(k0, k1):
+        cin, cout = chans[k]
+        if kinds[k] == "first_flat":
+            if not out16[k - k0] or cout % 8 or w % 4:          # (the shortcut launch writes a blocked y only)
+                return False
+            if not lib.agl_conv2d_fwd_takes_blocked(N, cout, h, w, cout, 3, 1, 1, fl | XB | YB):
+                return False
+        else:
+            if cin % 16 or cout % 8 or w % 8 or h % 2:
+                return False
+            if not lib.agl_conv2d_fwd_takes_blocked(N, cin, h, w, cin, 3, 1, 1, fl | XB | YB):            # c1
+                return False
+            if not lib.agl_conv2d_fwd_takes_blocked(N, cin, h, w, cout, 4, 2, 1, fl | XB):                # pooled c2
+                return False
+            h, w = h // 2, w // 2
+            if out16[k - k0] and not lib.agl_conv2d_fwd_takes_blocked(N, cin, h, w, cout, 1, 1, 0, fl | YB):      # shortcut + sum
+                return False
+    return True
 
 
 _cover_memo = {}
@@ -136,24 +187,28 @@ class _DTrunk(torch.autograd.Function):
         o = x
         saved, metas = [], []
         srcs = [getattr(p, "_agl_wsrc", None) if p is not None else None for p in params]
+        blk = ctx_blk = bool(blocks and blocks[0][0].endswith("+blk"))      # (run() marks the call: channel-blocked tensors inside)
+        blocks = tuple((kd.replace("+blk", ""), r) for kd, r in blocks)
         for k, (kind, in_relu) in enumerate(blocks):
             w1, b1, w2, b2, wsc, bsc = [F._c(p) if p is not None else None for p in params[6 * k: 6 * k + 6]]
             s1, s2, ssc = srcs[6 * k], srcs[6 * k + 2], srcs[6 * k + 4]
+            ox = None
             if kind == "first_flat":
-                h16 = L.conv2d_fwd(o, w1, b1, 1, 1, 0, False, True, wsrc=s1, out_bf16=True)
-                out = L.conv2d_fwd_shortcut(h16, w2, b2, o, wsc.reshape(wsc.shape[0], -1), bsc, 1, wsrc=s2, out_bf16=out16[k])
-                saved += [o, h16, None]
+                h16 = L.conv2d_fwd(o, w1, b1, 1, 1, 0, False, True, wsrc=s1, out_bf16=True, out_blk=blk)
+                out = L.conv2d_fwd_shortcut(h16, w2, b2, o, wsc.reshape(wsc.shape[0], -1), bsc, 1, wsrc=s2, out_bf16=out16[k], out_blk=blk and out16[k])
+                saved += [o, h16, None, None]
             else:
-                C, Cout = o.shape[1], w2.shape[0]
-                h16 = L.conv2d_fwd(o, w1, b1, 1, 1, 0, in_relu, True, wsrc=s1, out_bf16=True)
+                C, Cout = L.nchw_shape(o)[1], w2.shape[0]
+                ox = (o if L.is_blk(o) else L.to_blocked_dev(o)) if blk else o      # the convolutions' operand (blocked form: one conversion of an fp32 input)
+                h16 = L.conv2d_fwd(ox, w1, b1, 1, 1, 0, in_relu, True, wsrc=s1, out_bf16=True, out_blk=blk)
                 s = L.avgpool2_fwd(o, in_relu)
                 d2 = s2.derived("pool4f") if s2 is not None else None
                 if d2 is not None:
                     hp = L.conv2d_fwd(h16, None, b2, 2, 1, wsrc=d2, w_shape=(Cout, C, 4, 4), make_base=lambda w2=w2, s2=s2: _pooled_src(w2, s2))
                 else:
                     hp = L.conv2d_fwd(h16, _pooled(w2), b2, 2, 1)
-                out = L.conv2d_fwd_addend(s, wsc, bsc, hp, 1, 0, wsrc=ssc, out_bf16=out16[k])
-                saved += [o, h16, s]
+                out = L.conv2d_fwd_addend(s, wsc, bsc, hp, 1, 0, wsrc=ssc, out_bf16=out16[k], out_blk=blk and out16[k])
+                saved += [o, h16, s, ox if (blk and ox is not o) else None]
             metas.append((kind, in_relu))
             o = out
         ctx.metas, ctx.srcs, ctx.nparams = metas, srcs, len(params)
@@ -176,13 +231,15 @@ class _DTrunk(torch.autograd.Function):
         d = F._c(dout)
         for k in reversed(range(len(ctx.metas))):
             kind, in_relu = ctx.metas[k]
-            o, h16, s = saved[3 * k: 3 * k + 3]
+            o, h16, s, ox = saved[4 * k: 4 * k + 4]
+            if ox is None:
+                ox = o              # (the convolutions' operand is the block input itself)
             w1, b1, w2, b2, wsc, bsc = params[6 * k: 6 * k + 6]
             s1, s2, ssc = ctx.srcs[6 * k], ctx.srcs[6 * k + 2], ctx.srcs[6 * k + 4]
             nw = [need[3 + 6 * k + j] for j in range(6)]
             sl = ctx.slots[6 * k: 6 * k + 6]
             need_in = k > 0 or need[0]
-            H, W = o.shape[2], o.shape[3]
+            H, W = L.nchw_shape(o)[2], L.nchw_shape(o)[3]
             if kind == "first_flat":
                 # out = c2(h) + sc(x): the shortcut's gradients from (d, x), the residual branch through h
                 dh = L.conv2d_bwd_data(d, w2, (H, W), 1, 1, pos_mask=h16, wsrc=s2)
@@ -194,7 +251,7 @@ class _DTrunk(torch.autograd.Function):
                     L.conv2d_bwd_data(d, wsc, (H, W), 1, 0, out=do, accumulate=True, wsrc=ssc)
                     d = do
                 continue
-            C, Cout = o.shape[1], w2.shape[0]
+            C, Cout = L.nchw_shape(o)[1], w2.shape[0]
             # shortcut: out = hp + sc(s)
             ds = L.conv2d_bwd_data(d, wsc, (H // 2, W // 2), 1, 0, wsrc=ssc)
             grads[6 * k + 4], grads[6 * k + 5] = F._conv_param_grads((sl[4], sl[5]), nw[4], bsc is not None and nw[5], d, s, wsc, 1, 0, 0, False)
@@ -214,14 +271,17 @@ class _DTrunk(torch.autograd.Function):
                     L.channel_sum(d, out=sl[3], accumulate=True)
                 else:
                     grads[6 * k + 3] = L.channel_sum(d)
-            grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((sl[0], sl[1]), nw[0], b1 is not None and nw[1], dh, o, w1, 1, 1, 0, in_relu)
+            grads[6 * k + 0], grads[6 * k + 1] = F._conv_param_grads((sl[0], sl[1]), nw[0], b1 is not None and nw[1], dh, ox, w1, 1, 1, 0, in_relu)
             if need_in:
-                do = L.avgpool2_bwd(ds, o if in_relu else tuple(o.shape), in_relu)
+                do = L.avgpool2_bwd(ds, o if in_relu else L.nchw_shape(o), in_relu)
                 L.conv2d_bwd_data(dh, w1, (H, W), 1, 1, pos_mask=o if in_relu else None, out=do, accumulate=True, wsrc=s1)
                 d = do
         return (d if need[0] else None, None, None) + tuple(grads)
 
 
-def run(x, blocks, out16, params):
-    """blocks: [(kind, in_relu)], out16: per block, params: flat list of 6 tensors per block -> the last block's output."""
+def run(x, blocks, out16, params, blocked=False):
+    """blocks: [(kind, in_relu)], out16: per block, params: flat list of 6 tensors per block -> the last block's output.
+    blocked: the node keeps its bf16 tensors channel-blocked (blocked_ok said every launch has that form)."""
+    if blocked:
+        blocks = [(kd + "+blk", r) for kd, r in blocks]
     return _DTrunk.apply(x, tuple(blocks), tuple(out16), *params)

@@ -84,6 +84,9 @@ SIGNATURES = {
     "agl_avgpool2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "agl_avgpool2_fwd_x16": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "agl_avgpool2_bwd_x16": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "agl_to_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "agl_avgpool2_fwd_xblk": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "agl_avgpool2_bwd_xblk": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agl_conv2d_fwd_shortcut_ok": (_I, [_I] * 8),
     "agl_conv2d_fwd_shortcut": (_I, [_P] * 8 + [_I, _P, _P, _L] + [_I] * 10 + [_P]),
     "agl_upsample_nearest_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
@@ -177,7 +180,8 @@ EVENT_NAMES = {"agl_conv2d_fwd", "agl_conv2d_fwd_stats", "agl_conv2d_bwd_data", 
 CONV_BF16, CONV_NO_PATCH, CONV_NO_PATCH_S2, CONV_NO_POS, CONV_POS_ALL_KS, CONV_SPLIT3, CONV_ANY_GRID = 1, 2, 4, 8, 16, 32, 64
 CONV_W8, CONV_PRIO = 128, 256
 CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
-CONV_BLOCKED = 1 << 21      # prototype: channel-blocked bf16 x and y of conv2d_fwd_blocked
+CONV_X_BLOCKED, CONV_Y_BLOCKED, CONV_MASK_BLOCKED = 1 << 21, 1 << 22, 1 << 23      # channel-blocked bf16 operands (include/agl.h)
+CONV_BLOCKED = CONV_X_BLOCKED | CONV_Y_BLOCKED
 CONV_Y_BF16, CONV_MASK_BF16, CONV_DY_BF16 = 1 << 18, 1 << 19, 1 << 20      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
 CONV_FLAGS = 0
 
@@ -560,19 +564,24 @@ def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up, make=None):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None, out_bf16=False,
-               w_shape=None, make_base=None):
+               w_shape=None, make_base=None, out_blk=False):
     """out_bf16: y as a torch.bfloat16 tensor (agl_conv2d_fwd_writes_bf16_y says when the kernel that runs can write it).
     w may be None when w_shape + wsrc + make_base are given: a derived weight that only exists in packed form (cached under wsrc;
     make_base() builds the tensor to pack on a miss) — the call must then run on the matrix-core patch kernel."""
-    N, Cin, H, W = x.shape
+    xblk = is_blk(x)
+    N, Cin, H, W = nchw_shape(x)
     Cout, Cin_w, ks, ks2 = w.shape if w is not None else w_shape
     assert Cin_w == Cin and ks == ks2, (x.shape, w_shape if w is None else w.shape)
     OH, OW = conv_out_size(H, ks, stride, pad, up), conv_out_size(W, ks, stride, pad, up)
     if out is None:
         assert not accumulate
-        out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+        if out_blk:      # channel-blocked bf16 output (agl_conv2d_fwd_takes_blocked says when the kernel that runs can write it)
+            out = torch.empty((N, Cout // 8, OH, OW, 8), dtype=torch.bfloat16, device=x.device)
+        else:
+            out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     else:
-        assert tuple(out.shape) == (N, Cout, OH, OW)
+        assert nchw_shape(out) == (N, Cout, OH, OW)
+        out_blk = is_blk(out)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, up)
     ws = workspace(need, x.device) if need else None
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up, make=make_base) if not (relu and accumulate) else (None, None)
@@ -582,15 +591,39 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
     call("agl_conv2d_fwd", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
          ptr(out, out.dtype if yb16 else torch.float32), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
          N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), int(relu), int(accumulate),
-         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0), stream())
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0) | (CONV_X_BLOCKED if xblk else 0) | (CONV_Y_BLOCKED if out_blk else 0),
+         stream())
     return out
 
 
+def is_blk(t) -> bool:
+    """A channel-blocked bf16 tensor (N, C/8, H, W, 8) — include/agl.h AGL_CONV_X_BLOCKED."""
+    return t is not None and torch.is_tensor(t) and t.dim() == 5 and t.dtype == torch.bfloat16 and t.shape[-1] == 8
+
+
+def nchw_shape(t):
+    """(N, C, H, W) of an NCHW or a channel-blocked tensor."""
+    if is_blk(t):
+        N, G, H, W, _ = t.shape
+        return N, 8 * G, H, W
+    return tuple(t.shape)
+
+
 def to_blocked(x):
-    """(N, C, H, W) fp32 / bf16 -> channel-blocked bf16 (N, C/8, H, W, 8)."""
+    """(N, C, H, W) fp32 / bf16 -> channel-blocked bf16 (N, C/8, H, W, 8) by torch ops (tests)."""
     N, C, H, W = x.shape
     assert C % 8 == 0
     return x.to(torch.bfloat16).view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def to_blocked_dev(x):
+    """The same by one launch (agl_to_blocked): fp32 values are rounded to bf16 (RNE), bf16 values are moved."""
+    N, C, H, W = x.shape
+    assert C % 8 == 0 and x.is_contiguous()
+    y = torch.empty((N, C // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    b16 = x.dtype == torch.bfloat16
+    call("agl_to_blocked", ptr(x, x.dtype if b16 else torch.float32), ptr(y, torch.bfloat16), N, C, H, W, int(b16), stream())
+    return y
 
 
 def from_blocked(xb):
@@ -620,13 +653,18 @@ def conv2d_fwd_blocked(xb, w, bias=None, in_relu=False, relu=False, wsrc=None):
     return out
 
 
-def conv2d_fwd_addend(x, w, bias, addend, stride=1, pad=0, in_relu=False, relu=False, wsrc=None, out_bf16=False):
-    """y = conv(x) + addend (+ bias, ReLU) out of place (agl_conv2d_fwd_addend); y bf16 on request (the fp32 sum rounded once)."""
+def conv2d_fwd_addend(x, w, bias, addend, stride=1, pad=0, in_relu=False, relu=False, wsrc=None, out_bf16=False, out_blk=False):
+    """y = conv(x) + addend (+ bias, ReLU) out of place (agl_conv2d_fwd_addend); y bf16 on request (the fp32 sum rounded once),
+    channel-blocked with out_blk."""
     N, Cin, H, W = x.shape
     Cout, _, ks, _ = w.shape
     OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
     assert tuple(addend.shape) == (N, Cout, OH, OW) and addend.dtype == torch.float32
-    out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    if out_blk:
+        out_bf16 = True
+        out = torch.empty((N, Cout // 8, OH, OW, 8), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty((N, Cout, OH, OW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0)
     ws = workspace(need, x.device) if need else None
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, 0)
@@ -634,17 +672,23 @@ def conv2d_fwd_addend(x, w, bias, addend, stride=1, pad=0, in_relu=False, relu=F
     call("agl_conv2d_fwd_addend", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
          ptr(addend), ptr(out, out.dtype), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
          N, Cin, H, W, Cout, ks, stride, pad, int(in_relu), int(relu),
-         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0), stream())
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0) | (CONV_Y_BLOCKED if out_blk else 0), stream())
     return out
 
 
-def conv2d_fwd_shortcut(x, w, bias, sc_x, sc_w, sc_bias, pad=1, in_relu=False, relu=False, wsrc=None, out_bf16=False):
-    """y = conv3x3(x) + bias + conv1x1(sc_x; sc_w, sc_bias) with the few-channel shortcut evaluated in the epilogue (agl_conv2d_fwd_shortcut)."""
-    N, Cin, H, W = x.shape
+def conv2d_fwd_shortcut(x, w, bias, sc_x, sc_w, sc_bias, pad=1, in_relu=False, relu=False, wsrc=None, out_bf16=False, out_blk=False):
+    """y = conv3x3(x) + bias + conv1x1(sc_x; sc_w, sc_bias) with the few-channel shortcut evaluated in the epilogue (agl_conv2d_fwd_shortcut).
+    x may be channel-blocked (then y can be, with out_blk)."""
+    xblk = is_blk(x)
+    N, Cin, H, W = nchw_shape(x)
     Cout, _, ks, _ = w.shape
     sc_cin = sc_x.shape[1]
     assert tuple(sc_x.shape) == (N, sc_cin, H, W) and sc_w.numel() == Cout * sc_cin
-    out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    if out_blk:
+        out_bf16 = True
+        out = torch.empty((N, Cout // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, 1, pad, 0)
     ws = workspace(need, x.device) if need else None
     pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, 1, pad, 0)
@@ -652,7 +696,8 @@ def conv2d_fwd_shortcut(x, w, bias, sc_x, sc_w, sc_bias, pad=1, in_relu=False, r
     call("agl_conv2d_fwd_shortcut", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv),
          ptr(bias), ptr(sc_x), ptr(sc_w), ptr(sc_bias), sc_cin, ptr(out, out.dtype), ws.data_ptr() if ws is not None else None,
          ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, pad, int(in_relu), int(relu),
-         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0), stream())
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if out_bf16 else 0) | (CONV_X_BLOCKED if xblk else 0) | (CONV_Y_BLOCKED if out_blk else 0),
+         stream())
     return out
 
 
@@ -829,11 +874,12 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     if w is None and pk is None:
         w = make_w()
     mb16 = pos_mask is not None and pos_mask.dtype == torch.bfloat16
+    mblk = is_blk(pos_mask)                # (a channel-blocked bf16 mask: the blocked h / block input of a discriminator block)
     db16 = dy.dtype == torch.bfloat16      # (the bf16-stored input of a transposed convolution: this call is its forward)
     call("agl_conv2d_bwd_data", ptr(dy, dy.dtype if db16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None,
          ptr(pos_mask, torch.bfloat16 if mb16 else torch.float32), ptr(out),
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad,
-         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0) | (CONV_X_BF16 if db16 else 0), stream())
+         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0) | (CONV_X_BF16 if db16 else 0) | (CONV_MASK_BLOCKED if mblk else 0), stream())
     return out
 
 
@@ -843,7 +889,8 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
     if dbias_accumulate is None:
         dbias_accumulate = accumulate
     N, Cout, OH, OW = dy.shape
-    _, Cin, H, W = x.shape
+    xblk = is_blk(x)
+    _, Cin, H, W = nchw_shape(x)
     if out is None:
         assert not accumulate
         out = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dy.device)
@@ -856,7 +903,8 @@ def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None,
     call("agl_conv2d_bwd_weight", ptr(dy, dy.dtype if db16 else torch.float32), ptr(x, x.dtype if xb16 else torch.float32), ptr(out), ptr(dbias),
          int(dbias_accumulate), C.addressof(done) if dbias is not None else None,
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up,
-         int(in_relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_DY_BF16 if db16 else 0), stream())
+         int(in_relu), int(accumulate), CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_DY_BF16 if db16 else 0) | (CONV_X_BLOCKED if xblk else 0),
+         stream())
     if dbias is not None and not done.value:
         assert not db16
         channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
@@ -1043,10 +1091,12 @@ def box2_bwd(dxb, mask=None):
 
 
 def avgpool2_fwd(x, in_relu=False):
-    """x fp32 or (a discriminator block output stored as bf16) bfloat16; the result is fp32."""
-    N, Cc, H, W = x.shape
+    """x fp32 or (a discriminator block output stored as bf16: NCHW or channel-blocked) bfloat16; the result is fp32 NCHW."""
+    N, Cc, H, W = nchw_shape(x)
     y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    if x.dtype == torch.bfloat16:
+    if is_blk(x):
+        call("agl_avgpool2_fwd_xblk", ptr(x, torch.bfloat16), ptr(y), N, Cc, H, W, int(in_relu), stream())
+    elif x.dtype == torch.bfloat16:
         call("agl_avgpool2_fwd_x16", ptr(x, torch.bfloat16), ptr(y), N * Cc, H, W, int(in_relu), stream())
     else:
         call("agl_avgpool2_fwd", ptr(x), ptr(y), N * Cc, H, W, int(in_relu), stream())
@@ -1055,11 +1105,14 @@ def avgpool2_fwd(x, in_relu=False):
 
 def avgpool2_bwd(dy, x_or_shape, in_relu=False, out=None, accumulate=False):
     x = x_or_shape if isinstance(x_or_shape, torch.Tensor) else None
-    shape = x.shape if x is not None else x_or_shape
+    shape = nchw_shape(x) if x is not None else x_or_shape
     N, Cc, H, W = shape
     if out is None:
         out = torch.empty(tuple(shape), dtype=torch.float32, device=dy.device)
-    if x is not None and x.dtype == torch.bfloat16:
+    if is_blk(x):
+        assert in_relu
+        call("agl_avgpool2_bwd_xblk", ptr(dy), ptr(x, torch.bfloat16), ptr(out), N, Cc, H, W, int(accumulate), stream())
+    elif x is not None and x.dtype == torch.bfloat16:
         assert in_relu
         call("agl_avgpool2_bwd_x16", ptr(dy), ptr(x, torch.bfloat16), ptr(out), N * Cc, H, W, int(accumulate), stream())
     else:

@@ -990,7 +990,9 @@ struct ConvOpts {
   bool y_bf16;       // AGL_CONV_Y_BF16 (1 << 18): agl_conv2d_fwd writes y as bf16 (few-input-channel stream kernel only)
   bool mask_bf16;    // AGL_CONV_MASK_BF16 (1 << 19): agl_conv2d_bwd_data reads pos_mask as bf16 ("same" patch kernel without a reduction split)
   bool dy_bf16;      // AGL_CONV_DY_BF16 (1 << 20): agl_conv2d_bwd_weight reads dy as bf16 (matrix-core kernel, bf16 arithmetic)
-  bool blocked;      // AGL_CONV_BLOCKED (1 << 21): the bf16 x and y of agl_conv2d_fwd are channel-blocked [N][C/8][H][W][8] (prototype)
+  bool x_blk;        // AGL_CONV_X_BLOCKED (1 << 21): the bf16 x is channel-blocked [N][C/8][H][W][8] (forward, weight gradient)
+  bool y_blk;        // AGL_CONV_Y_BLOCKED (1 << 22): agl_conv2d_fwd / _addend / _shortcut write y channel-blocked bf16
+  bool mask_blk;     // AGL_CONV_MASK_BLOCKED (1 << 23): the bf16 pos_mask of agl_conv2d_bwd_data is channel-blocked
 };
 constexpr int kPosMinN = 96;    // smallest image count for the position-major path
 static ConvOpts conv_opts(int flags) {
@@ -1009,10 +1011,12 @@ static ConvOpts conv_opts(int flags) {
   o.y_bf16 = (flags & (1 << 18)) != 0;
   o.mask_bf16 = (flags & (1 << 19)) != 0;
   o.dy_bf16 = (flags & (1 << 20)) != 0;
-  o.blocked = (flags & (1 << 21)) != 0;
+  o.x_blk = (flags & (1 << 21)) != 0;
+  o.y_blk = (flags & (1 << 22)) != 0;
+  o.mask_blk = (flags & (1 << 23)) != 0;
   return o;
 }
-constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, 0, 0, false, false, false, false};
+constexpr ConvOpts kDefaultOpts = {0, true, true, true, false, false, false, false, 0, 0, false, false, false, false, false, false, false};
 
 template <class P>
 int launch_igemm(P& p, int M, long Nc, int Z, hipStream_t st, const char* name, int prec, int big_tile = 0) {
@@ -1673,7 +1677,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr;
     if (fold) a.fold = *fold;
-    a.addend = addend; a.y_bf16 = co.y_bf16; a.x_bf16 = co.x_bf16;
+    a.addend = addend; a.y_bf16 = co.y_bf16; a.x_bf16 = co.x_bf16; a.x_blk = co.x_blk; a.y_blk = co.y_blk;
+    AGL_REQUIRE((!co.x_blk || co.x_bf16) && (!co.y_blk || co.y_bf16), "agl_conv2d_fwd: a blocked operand is a bf16 operand (AGL_CONV_X_BF16 / _Y_BF16)");
     a.sc_x = sc_x; a.sc_w = sc_w; a.sc_b = sc_b; a.sc_cin = sc_cin;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, folded input transform / addend)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd_fold: a shape the patch kernel does not take in this form (ask agl_conv2d_fwd_fold_ok)");
@@ -1695,8 +1700,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
     a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.x_bf16 = 1; a.y_bf16 = co.y_bf16;
-    a.blocked = co.blocked;
-    AGL_REQUIRE(!co.blocked || co.y_bf16, "agl_conv2d_fwd: AGL_CONV_BLOCKED needs AGL_CONV_X_BF16 and AGL_CONV_Y_BF16 (ask agl_conv2d_fwd_takes_blocked)");
+    a.x_blk = co.x_blk; a.y_blk = co.y_blk;
+    AGL_REQUIRE(!co.y_blk || co.y_bf16, "agl_conv2d_fwd: AGL_CONV_Y_BLOCKED needs AGL_CONV_Y_BF16 (ask agl_conv2d_fwd_takes_blocked)");
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv, bf16 input)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_fwd: AGL_CONV_X_BF16 on a shape the patch kernel does not take");
     g_last_pipe = 1;
@@ -1714,7 +1719,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
                              "agl_conv2d_fwd(small Cout)");
   if (Cin <= 4 && Cout >= 16 && stride == 1 && up_log2 == 0 && OH == H && OW == W && w && co.patch) {
     // few input channels, 1x1 / 3x3: a stream over the output (few.hip; exact fp32 on the vector units in every arithmetic mode)
-    const int frc = few_cin_fwd_try(x, w, bias, y, N, Cin, H, W, Cout, ks, in_relu, relu, accumulate, co.y_bf16, st,
+    const int frc = few_cin_fwd_try(x, w, bias, y, N, Cin, H, W, Cout, ks, in_relu, relu, accumulate, co.y_blk ? 2 : (co.y_bf16 ? 1 : 0), st,
                                     "agl_conv2d_fwd(few input channels)");
     if (frc >= 0) return frc;
   }
@@ -1725,10 +1730,12 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
     a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = Cin * ks * ks; a.w_sc = ks * ks; a.flip = 0; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
     a.stats = stats; a.stats_floats = stats_floats; a.stat_rows = stat_rows;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.y_bf16 = co.y_bf16;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.y_bf16 = co.y_bf16; a.y_blk = co.y_blk;
+    AGL_REQUIRE(!co.x_blk, "agl_conv2d_fwd: AGL_CONV_X_BLOCKED needs AGL_CONV_X_BF16");
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_fwd(pconv)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
+  AGL_REQUIRE(!co.y_blk, "agl_conv2d_fwd: AGL_CONV_Y_BLOCKED on a call no blocked-writing kernel takes (ask agl_conv2d_fwd_takes_blocked)");
   AGL_REQUIRE(!co.y_bf16, "agl_conv2d_fwd: AGL_CONV_Y_BF16 on a call no bf16-writing kernel takes (ask agl_conv2d_fwd_writes_bf16_y)");
   AGL_REQUIRE(w, "agl_conv2d_fwd: packed weights were given for a call that does not run on the LDS-patch kernel, and w is NULL "
                  "(ask agl_conv2d_fwd_packed_bytes first)");
@@ -1859,7 +1866,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
     a.x = dy; a.w = w; a.bias = nullptr; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = 4; a.stride = 2; a.pad = pad; a.up = 0; a.in_relu = 0; a.relu = relu; a.accumulate = accumulate;
     a.w_sm = 16; a.w_sc = Cin * 16; a.flip = 0; a.nsplit = 1; a.any_grid = co.any_grid;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = 1;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = 1; a.mask_blk = co.mask_blk;
     const int prc = pconvT_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv phases, bf16 mask)");
     AGL_REQUIRE(prc >= 0, "agl_conv2d_bwd_data: AGL_CONV_MASK_BF16 on a shape the phase kernel does not take in that form (ask agl_conv2d_bwd_data_takes_bf16_mask)");
     g_last_pipe = 1;
@@ -1873,7 +1880,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
     a.x = dy; a.w = w; a.bias = bias; a.pos_mask = pos_mask; a.y = dx; a.N = N; a.Cin = Cout; a.H = OH; a.W = OW; a.Cout = Cin;
     a.OH = IH; a.OW = IW; a.ks = ks; a.stride = 1; a.pad = ks - 1 - pad; a.up = 0; a.in_relu = 0; a.relu = relu;
     a.accumulate = accumulate; a.w_sm = ks * ks; a.w_sc = Cin * ks * ks; a.flip = 1; a.nsplit = co.prec == 1 ? 1 : 3; a.any_grid = co.any_grid; a.w8 = co.w8; a.prio = co.prio; a.ablate = co.ablate;
-    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = co.mask_bf16;
+    a.packed = packed_w; a.out_div = packed_w ? packed_div : nullptr; a.mask_bf16 = co.mask_bf16; a.mask_blk = co.mask_blk;
     const int prc = pconv_try(a, ws, ws_bytes, st, "agl_conv2d_bwd_data(pconv)");
     if (prc >= 0) { g_last_pipe = a.nsplit; return prc; }
   }
@@ -2205,7 +2212,7 @@ static int conv2d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     PBwwArgs a{};
     a.dy = dy; a.x = x; a.dw = dw; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks;
     a.stride = stride; a.pad = pad; a.up = up_log2; a.in_relu = in_relu; a.accumulate = accumulate; a.nsplit = co.prec == 1 ? 1 : 3;
-    a.x_bf16 = co.x_bf16; a.dy_bf16 = co.dy_bf16;
+    a.x_bf16 = co.x_bf16; a.dy_bf16 = co.dy_bf16; a.x_blk = co.x_blk;
     if (fold) a.fold = *fold;
     a.dbias = dbias; a.dbias_accumulate = dbias_accumulate; a.dbias_done = dbias_done;
     const int prc = pbww_try(a, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_bwd_weight(pbww, bf16 input)");
@@ -2323,13 +2330,15 @@ int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, 
     return (stride == 1 && 2 * pad == ks - 1 && pconv_vert_ws_bytes(N, Cin, H, W, Cout, ks, 1) > 0) ? 1 : 0;
   return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
 }
-// 1 when agl_conv2d_fwd takes AGL_CONV_BLOCKED (with AGL_CONV_BF16 | AGL_CONV_X_BF16 | AGL_CONV_Y_BF16) for these extents
+// 1 when agl_conv2d_fwd (/ _addend / _shortcut) takes the blocked operands the flags name (AGL_CONV_X_BLOCKED and / or AGL_CONV_Y_BLOCKED, with
+// AGL_CONV_BF16 and the matching _BF16 operand flags) for these extents
 int agl_conv2d_fwd_takes_blocked(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
   const ConvOpts co = conv_opts(flags);
-  if (co.prec != 1 || !co.patch || 2 * pad != ks - 1) return 0;
+  if (co.prec != 1 || !co.patch || !(co.x_blk || co.y_blk)) return 0;
   PConvArgs a{};
-  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = H; a.OW = W; a.ks = ks; a.stride = stride; a.pad = pad; a.up = 0;
-  a.nsplit = 1; a.any_grid = co.any_grid; a.x_bf16 = 1; a.y_bf16 = 1; a.blocked = 1;
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = (H + 2 * pad - ks) / stride + 1; a.OW = (W + 2 * pad - ks) / stride + 1;
+  a.ks = ks; a.stride = stride; a.pad = pad; a.up = 0;
+  a.nsplit = 1; a.any_grid = co.any_grid; a.x_bf16 = co.x_bf16; a.y_bf16 = co.y_bf16; a.x_blk = co.x_blk; a.y_blk = co.y_blk;
   return pconv_takes_blocked(a) ? 1 : 0;
 }
 // 1 when agl_conv2d_bwd_data with AGL_CONV_BF16 | AGL_CONV_X_BF16 (dy stored as bf16) runs these extents on a matrix-core kernel

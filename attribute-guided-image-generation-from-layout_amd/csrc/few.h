@@ -11,7 +11,7 @@ int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws,
 // Forward convolution with <= 4 input channels, 1x1 / 3x3, stride 1, "same" size (exact fp32 on the vector units): AGL_OK, -1 when
 // the shape is not taken, else an error code.
 int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int ks, int in_relu,
-                    int relu, int accumulate, int y_bf16, hipStream_t st, const char* name);      // y_bf16: y points to bf16 elements
+                    int relu, int accumulate, int y_bf16, hipStream_t st, const char* name);      // y_bf16: 1 = y points to bf16 elements, 2 = channel-blocked bf16
 // nn.Linear gradients (1x1 maps): dw[co][ci] (+)= sum_n dy[n][co] x[n][ci];  dx[n][ci] (+)= sum_co dy[n][co] w[co][ci] (masked by pos_mask > 0)
 // round_bf16: bf16 arithmetic mode (both operands rounded to bf16 before the fp32 multiply-add)
 int linear_bww_launch(const float* dy, const float* x, float* dw, int N, int Cin, int Cout, int in_relu, int accumulate, int round_bf16,

@@ -181,7 +181,9 @@ struct FewCinArgs {
 
 // OutT = __bf16: the output is written as bf16 (round to nearest even) for a consumer that is a bf16-mode convolution reading it with
 // AGL_CONV_X_BF16 / AGL_CONV_MASK_BF16 (no accumulation onto it in that form).
-template <int KS, int CIN, typename OutT>
+// YB (with OutT = __bf16): the output is channel-blocked bf16 [N][Cout/8][H][W][8] — a thread forms 8 channels x 4 pixels at a time and writes
+// four consecutive 16-byte pieces (Cout % 8 == 0).
+template <int KS, int CIN, typename OutT, bool YB = false>
 __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
   constexpr int KK = KS * KS, PADK = KS / 2, NW = CIN * KK;
   extern __shared__ __attribute__((aligned(16))) float lw[];       // [Cout][NW] (+ bias [Cout])
@@ -212,6 +214,38 @@ __global__ __launch_bounds__(256) void few_cin_fwd_k(FewCinArgs p) {
         xin[c][r][0] = l; xin[c][r][5] = rr;
       }
     }
+  if constexpr (YB) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    for (int cg = 0; cg < (p.Cout >> 3); ++cg) {
+      float a[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* wc = lw + (8 * cg + u) * NW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+          for (int r = 0; r < KS; ++r)
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+              const float wv = wc[(c * KS + r) * KS + k];
+              a0 = fmaf(wv, xin[c][r][k + 0], a0); a1 = fmaf(wv, xin[c][r][k + 1], a1);
+              a2 = fmaf(wv, xin[c][r][k + 2], a2); a3 = fmaf(wv, xin[c][r][k + 3], a3);
+            }
+        const float bb = lb[8 * cg + u];
+        a[u][0] = a0 + bb; a[u][1] = a1 + bb; a[u][2] = a2 + bb; a[u][3] = a3 + bb;
+      }
+      bf16x8_t* dst = reinterpret_cast<bf16x8_t*>(p.y) + (((long)n * (p.Cout >> 3) + cg) * p.H + iy) * p.W + ix0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8_t o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (__bf16)(p.relu ? fmaxf(a[u][j], 0.f) : a[u][j]);
+        dst[j] = o;
+      }
+    }
+    return;
+  }
   OutT* const yb = reinterpret_cast<OutT*>(p.y) + (long)n * p.Cout * HW + (long)iy * p.W + ix0;
   for (int co = 0; co < p.Cout; ++co) {
     const float* wc = lw + co * NW;
@@ -356,6 +390,7 @@ int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws,
 int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int ks, int in_relu,
                     int relu, int accumulate, int y_bf16, hipStream_t st, const char* name) {
   if (!(ks == 1 || ks == 3) || Cin < 1 || Cin > 4 || W % 4 != 0 || (relu && accumulate) || (y_bf16 && accumulate)) return -1;
+  if (y_bf16 == 2 && (Cout % 8 != 0 || ks != 3 || Cin != 3)) return -1;      // (channel-blocked bf16 output: the 3 -> C first convolution of a discriminator)
   const long lds = ((long)Cout * Cin * ks * ks + Cout) * 4;
   if (lds > 48 * 1024) return -1;
   if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return -1;
@@ -363,7 +398,8 @@ int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y,
   const dim3 g((unsigned)agl_cdiv((long)N * H * (W / 4), 256));
 #define FC_LAUNCH(KS_, C_)                                                                                       \
   do {                                                                                                          \
-    if (y_bf16) hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_, __bf16>), g, dim3(256), (size_t)lds, st, p);       \
+    if (y_bf16 == 2) { if (KS_ == 3 && C_ == 3) hipLaunchKernelGGL((few_cin_fwd_k<3, 3, __bf16, true>), g, dim3(256), (size_t)lds, st, p); } \
+    else if (y_bf16) hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_, __bf16>), g, dim3(256), (size_t)lds, st, p);   \
     else hipLaunchKernelGGL((few_cin_fwd_k<KS_, C_, float>), g, dim3(256), (size_t)lds, st, p);               \
   } while (0)
   if (ks == 1) { if (Cin == 1) FC_LAUNCH(1, 1); else if (Cin == 2) FC_LAUNCH(1, 2); else if (Cin == 3) FC_LAUNCH(1, 3); else FC_LAUNCH(1, 4); }

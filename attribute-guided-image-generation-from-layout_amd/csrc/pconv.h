@@ -28,8 +28,9 @@ struct PConvArgs {
   InFold fold;                      // optional (scale != NULL): transform of x while it is staged (stride-1 / stride-2 forward forms)
   int y_bf16;                       // y points to bf16 elements (AGL_CONV_Y_BF16; launches without a reduction split only)
   const float* addend;              // optional fp32 tensor shaped like y, added before the output ReLU (no reduction split)
-  int blocked;                      // x and y are CHANNEL-BLOCKED bf16 tensors [N][C/8][H][W][8] (AGL_CONV_BLOCKED; with x_bf16 and y_bf16; the 3x3
-                                    // stride-1 32 x 8-tile forms only: pconv_takes_blocked)
+  int x_blk, y_blk;                 // x / y are CHANNEL-BLOCKED bf16 tensors [N][C/8][H][W][8] (AGL_CONV_X_BLOCKED / _Y_BLOCKED, with x_bf16 / y_bf16;
+                                    // the forms pconv_takes_blocked lists)
+  int mask_blk;                     // pos_mask is a channel-blocked bf16 tensor shaped like the output (AGL_CONV_MASK_BLOCKED, with mask_bf16)
   const float* sc_x; const float* sc_w; const float* sc_b; int sc_cin;   // optional few-channel 1x1 shortcut added in the epilogue:
                                     // y += sc_b[m] + sum_c sc_w[m*sc_cin + c] * sc_x[n][c][pixel] (bf16 3x3 stride-1 forms, <= 64-channel tiles)
 };
@@ -53,7 +54,7 @@ long pconv_ws_bytes(int Cin, int Cout, int ks, int nsplit);
 long pconv_ws_bytes_split(int Cin, int Cout, int ks, int nsplit, long out_numel);
 // True when pconv_try would launch for these extents (given enough workspace).
 bool pconv_eligible(const PConvArgs& a);
-// True when pconv_try takes these extents with a.blocked (channel-blocked bf16 x and y)
+// True when pconv_try takes these extents with a.x_blk / a.y_blk (channel-blocked bf16 x and / or y)
 bool pconv_takes_blocked(const PConvArgs& a);
 // Reduction splits pconv_try would use for these extents (1: none), -1 when the shape is not eligible.
 int pconv_plan_splits(const PConvArgs& a);
@@ -85,6 +86,7 @@ struct PBwwArgs {
   int ks, stride, pad, up, in_relu, accumulate, nsplit;
   int x_bf16;                       // x points to bf16 elements (AGL_CONV_X_BF16; nsplit 1 only)
   int dy_bf16;                      // dy points to bf16 elements (AGL_CONV_DY_BF16; nsplit 1 only)
+  int x_blk;                        // x is a channel-blocked bf16 tensor [N][Cin/8][H][W][8] (AGL_CONV_X_BLOCKED, with x_bf16; 3x3 stride 1 and 4x4 stride 2)
   InFold fold;                      // optional transform of x while it is staged (as in PConvArgs)
   float* dbias; int dbias_accumulate; int* dbias_done;    // optional: also (+= when dbias_accumulate) the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
 };

@@ -106,7 +106,8 @@ struct PArgs {
                      // spectrally normalised layer: packed W_orig, divisor sigma)
   InFold fold;       // optional input transform of the staged patch (pconv.h): the normalise-modulate of the BatchNorm that reads x
   int y_bf16;        // y points to bf16 elements (plain epilogue only: no phases, no reduction split)
-  int blk;           // FEAT 64: x and y are channel-blocked bf16 tensors [N][C/8][H][W][8]
+  int blk;           // (host bookkeeping) FEAT 64 / 128: x / y are channel-blocked bf16 tensors [N][C/8][H][W][8]
+  int mask_blk;      // pos_mask (bf16, mask_bf16 set) is channel-blocked: element (n, m, y, x) at (((n * Cout/8 + m/8) * H + y) * W + x) * 8 + m%8
   const float* addend;   // optional fp32 tensor shaped like y, added to the result before the output ReLU (out-of-place accumulate)
   // optional few-channel 1x1 shortcut evaluated in the epilogue (FEAT 16): y += sc_b[m] + sum_c sc_w[m * sc_cin + c] * sc_x[img][c][pixel],
   // sc_x an (N, sc_cin <= 4, OH, OW) fp32 tensor — the learnable shortcut of the discriminators' first block (discriminator.py:43-44, :58-60)
@@ -343,8 +344,11 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // 64: channel-blocked bf16 tensors, x and y as [N][C/8][H][W][8] (PROTOTYPE, one family: DESIGN §3.3).  A staged piece — the 8 channels
   // of a pixel — is ONE aligned 16-byte load that goes to LDS as it is (no conversion, no per-channel element loads: a 16-channel chunk
   // of the 34 x 10 patch is 100 cache-line visits instead of 320), and the epilogue stores 8 channels of a pixel as one 16-byte piece.
-  constexpr bool BLK = (FEAT & 64) != 0;
-  static_assert(!BLK || (NSPL == 1 && !PHS && !VERT && S == 1 && FEAT == 64), "blocked layout: plain bf16 stride-1 form");
+  constexpr bool BLK = (FEAT & 64) != 0;       // x is channel-blocked bf16 (XBLK)
+  // 128: y is written channel-blocked bf16 [N][Cout/8][OH][OW][8] straight from the accumulators (half a piece per lane, no LDS transpose),
+  // with the optional fp32 NCHW addend / the few-channel shortcut (FEAT 16) / bias / ReLU applied before the one rounding
+  constexpr bool YBLK = (FEAT & 128) != 0;
+  static_assert(!(BLK || YBLK) || (NSPL == 1 && !PHS && !VERT), "blocked layout: bf16 arithmetic, plain (non-phase) forms");
   constexpr int KSW = VERT ? 1 : KS;           // window columns
   static_assert(!VERT || (S == 1 && !PHS && TG == KS), "vertical window");
   constexpr int NT = NTH;                      // (shadows the file-level 256)
@@ -814,10 +818,16 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
-      if constexpr (BLK) {
+      if constexpr (YBLK) {
         const int jq = wn * (BN / WNW) + 32 * jt + l31;
         const int tiq = jq / (TH * TW), rq = jq - tiq * (TH * TW), pyq = rq / TW, pxq = rq - pyq * TW;
         const int imq = img0 + tiq;
+        const long pixq = (long)(ty0 + pyq) * p.OW + tx0 + pxq;
+        float scq[F_SC ? 4 : 1];      // the shortcut's input at this lane's pixel, per input channel
+        if constexpr (F_SC) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) scq[c] = (p.sc_x && c < p.sc_cin && imq < p.N) ? p.sc_x[((long)imq * p.sc_cin + c) * OHW + pixq] : 0.f;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int mch = bm0 + wm * (BM / 2) + 32 * i + 8 * g;      // first channel of the piece
@@ -826,7 +836,18 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             bf16x4 ob;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              float t = acc[0][i][jt][4 * g + q] * osc + (p.bias ? p.bias[mch + 4 * lh + q] : 0.f);
+              const int m = mch + 4 * lh + q;
+              float t = acc[0][i][jt][4 * g + q] * osc + (p.bias ? p.bias[m] : 0.f);
+              if (p.addend) t += p.addend[((long)imq * p.Cout + m) * OHW + pixq];      // (fp32 NCHW: consecutive lanes, consecutive pixels)
+              if constexpr (F_SC) {
+                if (p.sc_x) {
+                  float sv = p.sc_b ? p.sc_b[m] : 0.f;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    if (c < p.sc_cin) sv = fmaf(p.sc_w[m * p.sc_cin + c], scq[c], sv);
+                  t += sv;
+                }
+              }
               if (p.relu) t = fmaxf(t, 0.f);
               ob[q] = (__bf16)t;
             }
@@ -885,7 +906,14 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
             if (p.pos_mask) {
               f4u m0, m1;
               if (F_PMASK16 && p.mask_bf16) {      // eight bf16 in one 16-byte load (widened by a shift: sign and zero are the stored value's)
-                const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.pos_mask) + ob + (long)m * OHW2);
+                uint4 b;
+                if (p.mask_blk) {      // channel-blocked mask: eight pixels of channel m, 16 bytes apart
+                  const unsigned short* q = reinterpret_cast<const unsigned short*>(p.pos_mask) +
+                      ((((long)img * (p.Cout >> 3) + (m >> 3)) * p.oh2 + 2 * (ty0 + py) + ph_y) * p.ow2 + 2 * (tx0 + px)) * 8 + (m & 7);
+                  b.x = (unsigned)q[0] | ((unsigned)q[8] << 16); b.y = (unsigned)q[16] | ((unsigned)q[24] << 16);
+                  b.z = (unsigned)q[32] | ((unsigned)q[40] << 16); b.w = (unsigned)q[48] | ((unsigned)q[56] << 16);
+                } else
+                b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.pos_mask) + ob + (long)m * OHW2);
                 m0 = f4u{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
                          __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
                 m1 = f4u{__builtin_bit_cast(float, b.z << 16), __builtin_bit_cast(float, b.z & 0xffff0000u),
@@ -973,6 +1001,13 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
           uint2 b = {0u, 0u};
+          if (p.mask_blk) {      // channel-blocked mask: this lane's four pixels of channel m lie 16 bytes apart (a wave's rows share 512-byte runs)
+            if (m < p.Cout && img < p.N) {
+              const unsigned short* q = mk + ((((long)img * (p.Cout >> 3) + (m >> 3)) * p.OH + ty0 + py) * p.OW + tx0 + px) * 8 + (m & 7);
+              b.x = (unsigned)q[0] | ((unsigned)q[8] << 16);
+              b.y = (unsigned)q[16] | ((unsigned)q[24] << 16);
+            }
+          } else
           if (m < p.Cout && img < p.N) b = *reinterpret_cast<const uint2*>(mk + pbase + (long)m * OHW);
           msk[ps] = float4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
                            __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
@@ -1153,6 +1188,7 @@ struct WArgs {
   unsigned x_bytes, dy_bytes;
   int x_bf16;             // x is stored as bf16 (see PArgs)
   int dy_bf16;            // dy is stored as bf16 (the bf16-stored input of a transposed convolution, whose weight gradient has it in this role)
+  int x_blk;              // XB instantiations: x is channel-blocked bf16 [N][Cin/8][H][W][8]
   InFold fold;            // optional input transform of x (pconv.h): the normalise-modulate of the BatchNorm that reads x, as in pconv_k
   int xgyz, xchunk, xitems, xgy;      // XCD-aware workgroup order (xchunk > 0): 1-D grid, see pbww_k
 };
@@ -1164,8 +1200,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ceil(KS^2/TSUB) passes by different workgroups (blockIdx.y = channel block * passes + pass), each staging the same tiles.
 // AUX: the bf16 dy operand (WArgs::dy_bf16) and the input transform of x (WArgs::fold) compiled in — the 4x4 / stride-2 family only
 // (weight gradients of ConvTranspose2d(4, 2, 1) and of the folded encoder convolutions); see pconv_k's FEAT for why not everywhere.
-template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS, bool AUX = false>
+// XB: x is a channel-blocked bf16 tensor: a staged item — the 8 channels of a patch pixel — is ONE 16-byte load that goes to LDS as it is
+template <int KS, int S, int TW, int TH, int TI, int RT, int CT, int NSPL, int TSUB = KS * KS, bool AUX = false, bool XB = false>
 __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(WArgs p) {
+  static_assert(!XB || (NSPL == 1 && !AUX), "blocked x: bf16 arithmetic, no input transform");
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
   static_assert((NPX == 128 || NPX == 64) && TW >= 4, "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy pieces are two full rows)
@@ -1238,7 +1276,8 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   constexpr int ND = BMCO * (NPX / 8), DR = (ND + NT - 1) / NT;          // dy items (output channel, 8 consecutive pixels)
   constexpr int NXI = NQ * (BC / 8), XR = (NXI + NT - 1) / NT;           // x items (channel octet, patch pixel)
   float4 pdy[DR][2];
-  float px[XR][8];
+  float px[XB ? 1 : XR][8];
+  u32x4 pxq[XB ? XR : 1];      // blocked x: the pieces as they are stored
   bool pxin[AUX ? XR : 1];           // (fold) the staged patch pixel lies inside the map: padding must stay zero
   auto tile_origin = [&](int tile, int& img0, int& ty0, int& tx0) {
     if constexpr (TI == 1) {
@@ -1282,6 +1321,12 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int ti = q / IMGP, r2 = q - ti * IMGP, yy = r2 / PW, xx = r2 - yy * PW;
       const int img = img0 + ti, ly = S * ty0 - p.pad + yy, lx = S * tx0 - p.pad + xx;
       const bool ok = img < p.N && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+      if constexpr (XB) {
+        const long idx = ok ? ((long)((img * (p.Cin >> 3) + (c0 >> 3) + oc) * p.H + ly) * p.W + lx) : 0;
+        const u32x4 v = reinterpret_cast<const u32x4*>(p.x)[idx];
+        pxq[sl] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        return;
+      }
       const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
       if constexpr (AUX) pxin[sl] = ok;
       if (p.x_bf16) {
@@ -1339,6 +1384,15 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       const int e = tid + NT * r;
       if (NXI % NT != 0 && e >= NXI) return;
       const int oc = e / NQ, q = e - oc * NQ;
+      if constexpr (XB) {
+        u32x4 v = pxq[sl];
+        if (p.in_relu) {      // ReLU on the stored bf16 pairs: a set sign bit clears its 16-bit half
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) v[qq] &= ~(((v[qq] >> 15) & 0x00010001u) * 0xFFFFu);
+        }
+        *reinterpret_cast<u32x4*>(Xl + q * XROW + oc * 16) = v;
+        return;
+      }
       if constexpr (H16) {      // (input transform and ReLU already applied to the registers by prep_tile)
         f16x8 hi, lo;
 #pragma unroll
@@ -1642,11 +1696,21 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
 }
 
 bool pconv_eligible(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0; }
-bool pconv_takes_blocked(const PConvArgs& a) {      // prototype: 3x3 stride-1 "same", bf16 arithmetic, maps of >= 8 x 8 pixels, no reduction split
+// Channel-blocked bf16 operands (a.x_blk / a.y_blk: [N][C/8][H][W][8]) — the forms compiled for them (pconv_k FEAT 64 / 128), bf16 arithmetic:
+//   x and y blocked : 3x3 stride 1 (bias, input ReLU, output ReLU; with the few-channel shortcut of FEAT 16 on 64-channel tiles)
+//   x blocked       : 4x4 stride 2 forward, fp32 NCHW output (the pooled second convolution of a discriminator block)
+//   y blocked       : 1x1 with an fp32 NCHW x and an optional fp32 NCHW addend (the shortcut + sum of a discriminator block)
+// No reduction split, no statistics rows, no input transform, no in-place accumulation, no mask.
+bool pconv_takes_blocked(const PConvArgs& a) {
   PConvPlan pl;
-  if (pconv_plan(a, pl) != 0) return false;
-  return a.nsplit == 1 && a.ks == 3 && a.stride == 1 && a.up == 0 && a.x_bf16 && a.y_bf16 && !a.accumulate && !a.pos_mask && !a.addend && !a.sc_x &&
-         !a.fold.scale && !a.stats && pl.splits == 1 && pl.geo != 2 && a.Cin % 16 == 0 && a.Cout % 8 == 0;
+  if (!(a.x_blk || a.y_blk) || pconv_plan(a, pl) != 0) return false;
+  if (a.nsplit != 1 || a.up != 0 || a.accumulate || a.pos_mask || a.fold.scale || a.stats || pl.splits != 1) return false;
+  if (a.x_blk && !(a.x_bf16 && a.Cin % 16 == 0)) return false;
+  if (a.y_blk && !(a.y_bf16 && a.Cout % 8 == 0)) return false;
+  if (a.sc_x && !(a.x_blk && a.y_blk)) return false;
+  if (a.x_blk && a.y_blk) return a.ks == 3 && a.stride == 1 && pl.geo != 2;
+  if (a.x_blk) return a.ks == 4 && a.stride == 2 && pl.geo != 5 && !a.addend && !a.sc_x && !a.y_bf16;
+  return a.ks == 1 && !a.x_bf16 && !a.sc_x;      // y blocked only
 }
 int pconv_plan_splits(const PConvArgs& a) { PConvPlan pl; return pconv_plan(a, pl) == 0 ? pl.splits : -1; }
 long pconv_stat_rows_max(int N, int OH, int OW) { return 2L * N * ((long)(OH * OW + 63) / 64) + 4; }   // (+4: the rounded-up last tile of the 4-column form)
@@ -1699,6 +1763,9 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const bool fam42 = s2 && a.ks == 4, fam5 = !s2 && a.ks == 5 && a.nsplit == 1, famy = !s2 && a.nsplit == 1 && (a.ks == 3 || a.ks == 1);
   if (a.fold.scale && !fam42) return -1;
   if ((a.y_bf16 || a.addend) && !famy) return -1;
+  if (a.x_blk || a.y_blk) {      // (checked again below; here: keep the statistics rows off a blocked launch)
+    if (a.stats) return -1;
+  }
   if ((fam42 || fam5) && pl.splits == 1 && a.stats && !a.relu && !a.accumulate && !a.pos_mask && wcols * ptiles * a.Cout * 3 <= a.stats_floats) {
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
@@ -1707,8 +1774,9 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   const bool featsc = a.sc_x != nullptr;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
-  p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend; p.blk = a.blocked;
-  if (a.blocked && !pconv_takes_blocked(a)) return -1;
+  p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend; p.blk = a.x_blk | (a.y_blk << 1); p.mask_blk = a.mask_blk;
+  if ((a.x_blk || a.y_blk) && !pconv_takes_blocked(a)) return -1;
+  if (a.mask_blk && !a.mask_bf16) return -1;
   p.sc_x = a.sc_x; p.sc_w = a.sc_w; p.sc_b = a.sc_b; p.sc_cin = a.sc_cin;
   p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * KK * mpad);      // (read by the H16 instantiations only)
   if (a.sc_x && !(a.ks == 3 && !s2 && a.nsplit == 1 && bm == 64 && geo != 2 && pl.splits == 1 && a.sc_cin >= 1 && a.sc_cin <= 4 && a.OW % 4 == 0))
@@ -1773,9 +1841,14 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     else PC_LAUNCH_F(F_, 1, 1, 4, 4, 8, BM_, NS_, 1);                                                    \
   } while (0)
   if (s2) {
-    if (a.ks == 4) { if (feat42) PC_STRIDE2(3, 4, 4); else PC_STRIDE2(0, 4, 4); } else PC_STRIDE2(0, 3, 3);
+    if (a.ks == 4 && a.x_blk) {      // blocked bf16 x, fp32 NCHW y
+      if (bm == 128) { if (geo == 0) PC_LAUNCH_F(64, 4, 2, 16, 8, 1, 128, 1, 4); else if (geo == 1) PC_LAUNCH_F(64, 4, 2, 8, 8, 2, 128, 1, 4); else PC_LAUNCH_F(64, 4, 2, 4, 4, 8, 128, 1, 4); }
+      else { if (geo == 0) PC_LAUNCH_F(64, 4, 2, 16, 8, 1, 64, 1, 4); else if (geo == 1) PC_LAUNCH_F(64, 4, 2, 8, 8, 2, 64, 1, 4); else PC_LAUNCH_F(64, 4, 2, 4, 4, 8, 64, 1, 4); }
+    }
+    else if (a.ks == 4) { if (feat42) PC_STRIDE2(3, 4, 4); else PC_STRIDE2(0, 4, 4); } else PC_STRIDE2(0, 3, 3);
   } else if (a.ks == 1) {
     if (a.nsplit == 3) { if (bm == 128) PC_1X1(0, 128, SPL); else PC_1X1(0, 64, SPL); }
+    else if (a.y_blk) { if (bm == 128) PC_1X1(128, 128, 1); else PC_1X1(128, 64, 1); }
     else if (featy) { if (bm == 128) PC_1X1(4, 128, 1); else PC_1X1(4, 64, 1); }
     else { if (bm == 128) PC_1X1(0, 128, 1); else PC_1X1(0, 64, 1); }
   } else if (SPL == 3 && a.ablate > 0 && a.ks == 3 && a.nsplit == 3 && wide && w32) {      // diagnostic builds of ONE geometry (tools/ablate.sh)
@@ -1821,8 +1894,9 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
       }
       else if (wide) { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 16, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 16, 64, 1, 9); }
       else { if (bm == 128) PC_LAUNCH(3, 1, 4, 4, 8, 128, 1, 9); else PC_LAUNCH(3, 1, 4, 4, 8, 64, 1, 9); }
-    } else if (a.nsplit == 1 && a.blocked) {      // (pconv_takes_blocked)
-      if (bm == 128) PC_SHAPES1F(64, 3, 128, 9); else PC_SHAPES1F(64, 3, 64, 9);
+    } else if (a.nsplit == 1 && a.x_blk && a.y_blk && featsc) { PC_SHAPES1F(208, 3, 64, 9);      // (pconv_takes_blocked)
+    } else if (a.nsplit == 1 && a.x_blk && a.y_blk) {
+      if (bm == 128) PC_SHAPES1F(192, 3, 128, 9); else PC_SHAPES1F(192, 3, 64, 9);
     } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
     else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
@@ -1977,7 +2051,7 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
-  p.wexp = nullptr; p.blk = 0;
+  p.wexp = nullptr; p.blk = 0; p.mask_blk = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * (a.x_bf16 ? 2 : 4));
   if (a.x_bf16 && a.nsplit != 1) return -1;
   if (a.nsplit == 1) {
@@ -2069,6 +2143,8 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   if (splits > 1) { p.slabs = (float*)((char*)ws + packed); p.cps = agl_cdiv(nch, splits); splits = agl_cdiv(nch, p.cps); }
   p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * 16 * mpad);
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
+  p.blk = 0; p.mask_blk = a.mask_blk;
+  if (a.mask_blk && !a.mask_bf16) return -1;
   if (a.x_bf16 && a.nsplit != 1) return -1;
   // bf16 ReLU mask: the paired-phase epilogue of the bf16 instantiations (16-byte pieces of 8 mask elements), no reduction split, even size
   if (a.mask_bf16 && (a.nsplit != 1 || !a.pos_mask || splits > 1 || geo == 3 || a.OH != 2 * a.H)) return -1;
@@ -2218,7 +2294,9 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   p.dy = a.dy; p.x = a.x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   if (a.ks == 1) { p.H = p.OH = oh; p.W = p.OW = ow; }
   p.pad = a.pad; p.up = a.up; p.in_relu = a.in_relu; p.tiles = (int)tiles; p.tiles_per_split = tps;
-  p.x_bf16 = a.x_bf16; p.dy_bf16 = a.dy_bf16; p.fold = a.fold;
+  p.x_bf16 = a.x_bf16; p.dy_bf16 = a.dy_bf16; p.fold = a.fold; p.x_blk = a.x_blk;
+  if (a.x_blk && !(a.x_bf16 && a.nsplit == 1 && a.up == 0 && !a.dy_bf16 && !a.fold.scale && a.Cin % 16 == 0 &&
+                   ((a.ks == 3 && a.stride == 1) || (a.ks == 4 && a.stride == 2)))) return -1;
   if (a.dy_bf16 && (a.nsplit != 1 || (a.OW % 8 != 0 && !(a.OW == 4 && a.OH == 4)))) return -1;      // (16-byte pieces of 8 bf16)
   const bool aux = a.dy_bf16 || a.fold.scale != nullptr;
   if (aux && !(a.ks == 4 && a.stride == 2)) return -1;      // (compiled into the 4x4 / stride-2 instantiations only)
@@ -2252,8 +2330,19 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     if (half == 5) hipLaunchKernelGGL((pbww_k<KS_, 1, 32, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);            \
     else PW_LAUNCH(KS_, 1, RT_, CT_, NS_);                                                                          \
   } while (0)
+#define PW_LAUNCH_XB(KS_, S_)                                                                                       \
+  do {                                                                                                              \
+    if (half == 5) hipLaunchKernelGGL((pbww_k<KS_, S_, 32, 4, 1, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);        \
+    else if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);    \
+    else if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);    \
+    else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);    \
+    else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);   \
+    else hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 8, 1, 1, 1, 1, KS_ * KS_, false, true>), g, dim3(NT), 0, st, p);                  \
+  } while (0)
   // (bf16 mode launches the 64 x 16 block only — pbww_plan; 1x1 keeps its 64 x 32 block)
-  if (a.stride == 2) {
+  if (a.x_blk) {      // channel-blocked bf16 x (checked above: 3x3 stride 1 or 4x4 stride 2, bf16 arithmetic)
+    if (a.stride == 2) PW_LAUNCH_XB(4, 2); else PW_LAUNCH_XB(3, 1);
+  } else if (a.stride == 2) {
     if (a.ks == 4 && aux) { if (a.nsplit == 3) PW_LAUNCH_AUX(4, 2, 1, 1, SPL); else PW_LAUNCH_AUX(4, 2, 1, 1, 1); }
     else if (a.ks == 4) { if (a.nsplit == 3) PW_LAUNCH(4, 2, 1, 1, SPL); else PW_LAUNCH(4, 2, 1, 1, 1); }
     else { if (a.nsplit == 3) PW_LAUNCH(3, 2, 1, 1, SPL); else PW_LAUNCH(3, 2, 1, 1, 1); }
@@ -2269,6 +2358,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
     else if (half == 3) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 1, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);
   }
+#undef PW_LAUNCH_XB
 #undef PW_LAUNCH1
 #undef PW_LAUNCH_AUX
 #undef PW_LAUNCH

@@ -354,6 +354,80 @@ __global__ void avgpool2_bwd4_m16_k(const float* __restrict__ dy, const unsigned
   *reinterpret_cast<float4*>(dx + o) = v;
 }
 
+// ---- channel-blocked bf16 tensors [N][C/8][H][W][8] (the discriminators' block chain in bf16 arithmetic) -----------------------
+// fp32 / bf16 NCHW -> blocked bf16: a thread owns one piece (8 channels of one pixel): 8 loads a channel stride apart (consecutive threads,
+// consecutive pixels: coalesced per channel), one 16-byte store
+template <bool IN16>
+__global__ void to_blocked_k(const void* __restrict__ xv, uint4* __restrict__ y, long NG, int HW) {      // NG = N * C / 8
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NG * HW) return;
+  const long g = i / HW, pix = i - g * HW;
+  unsigned short h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long o = (g * 8 + j) * HW + pix;
+    if constexpr (IN16) h[j] = reinterpret_cast<const unsigned short*>(xv)[o];
+    else h[j] = __builtin_bit_cast(unsigned short, (__bf16)reinterpret_cast<const float*>(xv)[o]);
+  }
+  y[i] = uint4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16),
+               (unsigned)h[6] | ((unsigned)h[7] << 16)};
+}
+// avg_pool2(relu?(x)) of a blocked bf16 x into an fp32 NCHW y: a thread owns 8 channels x 4 output pixels of one output row — it reads
+// 2 rows x 8 pieces (16 bytes each, consecutive) and writes one 16-byte store per channel (same order of additions as avgpool2_fwd_k)
+__global__ void avgpool2_fwd_blk_k(const uint4* __restrict__ x, float* __restrict__ y, long NG, int H, int W, int in_relu) {
+  const unsigned OH = H / 2, OW = W / 2, Q = W / 8;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NG * OH * Q) return;
+  const unsigned q = (unsigned)(i % Q);
+  const long t = i / Q;
+  const unsigned oh = (unsigned)(t % OH);
+  const long g = t / OH;
+  float acc[8][4];
+  float r[2][8][8];      // [row][pixel][channel]
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int px = 0; px < 8; ++px) {
+      const uint4 b = x[(g * H + 2 * oh + k) * W + 8 * q + px];
+      const unsigned u[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = __builtin_bit_cast(float, u[j] << 16), hi = __builtin_bit_cast(float, u[j] & 0xffff0000u);
+        if (in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+        r[k][px][2 * j] = lo; r[k][px][2 * j + 1] = hi;
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[c][o] = (r[0][2 * o][c] + r[0][2 * o + 1][c] + r[1][2 * o][c] + r[1][2 * o + 1][c]) * 0.25f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    *reinterpret_cast<float4*>(y + ((g * 8 + c) * OH + oh) * (long)OW + 4 * q) = float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+}
+// avgpool2_bwd4_m16_k with the ReLU mask read from a blocked bf16 x: the four pixels of a thread lie 16 bytes apart
+__global__ void avgpool2_bwd4_mblk_k(const float* __restrict__ dy, const unsigned short* __restrict__ x, float* __restrict__ dx, long NC, int C, int H,
+                                     int W, int accumulate) {
+  const unsigned OW = W / 2, W4 = W / 4;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)(NC * H * W4)) return;
+  const unsigned w4 = i % W4, t = i / W4, h = t % H, nc = t / H;
+  const float2 d = *reinterpret_cast<const float2*>(dy + (long)nc * (H / 2) * OW + (long)(h / 2) * OW + 2 * w4);
+  float4 v = {0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y};
+  const long o = 4L * i;
+  const unsigned n = nc / C, c = nc - n * C;
+  const unsigned short* m = x + ((((long)n * (C >> 3) + (c >> 3)) * H + h) * W + 4 * w4) * 8 + (c & 7);
+  if (!(__builtin_bit_cast(float, (unsigned)m[0] << 16) > 0.f)) v.x = 0.f;
+  if (!(__builtin_bit_cast(float, (unsigned)m[8] << 16) > 0.f)) v.y = 0.f;
+  if (!(__builtin_bit_cast(float, (unsigned)m[16] << 16) > 0.f)) v.z = 0.f;
+  if (!(__builtin_bit_cast(float, (unsigned)m[24] << 16) > 0.f)) v.w = 0.f;
+  if (accumulate) {
+    const float4 ov = *reinterpret_cast<const float4*>(dx + o);
+    v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+  }
+  *reinterpret_cast<float4*>(dx + o) = v;
+}
+
 // nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
 __global__ void upsample_fwd_k(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int k) {
   const unsigned OH = H << k, OW = W << k;
@@ -904,6 +978,34 @@ int agl_avgpool2_fwd_x16(const void* x_bf16, float* y, long NC, int H, int W, in
               (((uintptr_t)x_bf16 | (uintptr_t)y) & 15) == 0, "agl_avgpool2_fwd_x16: bad argument (W % 8 == 0, even H, 16-byte aligned)");
   LAUNCH1D(avgpool2_fwd_w_k<true>, NC * (H / 2) * (W / 8), x_bf16, y, NC, H, W, in_relu);
   AGL_CHECK_LAUNCH("agl_avgpool2_fwd_x16");
+  return AGL_OK;
+}
+// Channel-blocked bf16 tensors (include/agl.h): NCHW fp32 (x_bf16 = 0) or bf16 (1) -> [N][C/8][H][W][8] bf16
+int agl_to_blocked(const void* x, void* y_blk, int N, int C, int H, int W, int x_bf16, void* stream) {
+  AGL_REQUIRE(x && y_blk && N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && (long)N * C * H * W < (1L << 31) && ((uintptr_t)y_blk & 15) == 0,
+              "agl_to_blocked: bad argument (C % 8 == 0, 16-byte aligned output)");
+  const long NG = (long)N * (C / 8);
+  if (x_bf16) LAUNCH1D(to_blocked_k<true>, NG * H * W, x, (uint4*)y_blk, NG, H * W);
+  else LAUNCH1D(to_blocked_k<false>, NG * H * W, x, (uint4*)y_blk, NG, H * W);
+  AGL_CHECK_LAUNCH("agl_to_blocked");
+  return AGL_OK;
+}
+// y (fp32 NCHW, N x C x H/2 x W/2) = avg_pool2(relu?(x)) of a channel-blocked bf16 x.  W % 8 == 0, even H, C % 8 == 0.
+int agl_avgpool2_fwd_xblk(const void* x_blk, float* y, int N, int C, int H, int W, int in_relu, void* stream) {
+  AGL_REQUIRE(x_blk && y && N > 0 && C % 8 == 0 && H >= 2 && H % 2 == 0 && W >= 8 && W % 8 == 0 && (long)N * C * H * W < (1L << 31) &&
+              (((uintptr_t)x_blk | (uintptr_t)y) & 15) == 0, "agl_avgpool2_fwd_xblk: bad argument (C % 8 == 0, W % 8 == 0, even H, 16-byte aligned)");
+  const long NG = (long)N * (C / 8);
+  LAUNCH1D(avgpool2_fwd_blk_k, NG * (H / 2) * (W / 8), (const uint4*)x_blk, y, NG, H, W, in_relu);
+  AGL_CHECK_LAUNCH("agl_avgpool2_fwd_xblk");
+  return AGL_OK;
+}
+// Backward of avg_pool2(relu(x)) with the mask read from a channel-blocked bf16 x: dx (fp32 NCHW) (+)= 0.25 * dy where x > 0
+int agl_avgpool2_bwd_xblk(const float* dy, const void* x_blk, float* dx, int N, int C, int H, int W, int accumulate, void* stream) {
+  AGL_REQUIRE(dy && x_blk && dx && N > 0 && C % 8 == 0 && H >= 2 && H % 2 == 0 && W % 4 == 0 && (long)N * C * H * W < (1L << 31),
+              "agl_avgpool2_bwd_xblk: bad argument");
+  const long NC = (long)N * C;
+  LAUNCH1D(avgpool2_bwd4_mblk_k, NC * H * (W / 4), dy, (const unsigned short*)x_blk, dx, NC, C, H, W, accumulate);
+  AGL_CHECK_LAUNCH("agl_avgpool2_bwd_xblk");
   return AGL_OK;
 }
 // Backward of avg_pool2(relu(x)) with x stored as bf16 (read for the mask only): dx (+)= 0.25 * dy where x > 0.  W % 4 == 0, even H.

@@ -132,13 +132,28 @@ int agl_conv2d_bwd_data_takes_bf16_mask(int N, int Cin, int IH, int IW, int Cout
  * whose forward IS this call): agl_conv2d_bwd_data_takes_bf16_dy;  AGL_CONV_DY_BF16 on agl_conv2d_bwd_weight: dy holds bf16 (the
  * same tensor in the weight gradient of that transposed convolution): agl_conv2d_bwd_weight_takes_bf16_dy. */
 int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
-/* PROTOTYPE (ABI 6): channel-blocked bf16 activations.  With AGL_CONV_BLOCKED (and AGL_CONV_BF16 | AGL_CONV_X_BF16 | AGL_CONV_Y_BF16)
- * agl_conv2d_fwd reads x and writes y as [N][C/8][H][W][8] bf16 tensors: the 8 channels of a pixel are one 16-byte piece, which is what
- * the matrix-core kernel stages and what its epilogue can store whole (the NCHW staging pass is bound by the cache lines
- * it visits).  One family so far — 3x3 stride-1 "same" on maps of >= 8 x 8 pixels, Cin % 16 == 0, Cout % 8 == 0, bias / ReLU / input
- * ReLU; no network uses it yet.  Reference counterpart: the same nn.Conv2d call (models/discriminator.py:70-79) on a permuted tensor. */
-#define AGL_CONV_BLOCKED (1 << 21)
+/* Channel-blocked bf16 activations (ABI 7): a tensor [N][C/8][H][W][8] of bf16 — the 8 channels of a pixel are one 16-byte piece, which is
+ * what the matrix-core kernels stage (one aligned load per piece instead of eight element loads a channel stride apart, no conversion)
+ * and what their epilogue stores whole.  Used inside the discriminators' block chain (agl/dtrunk.py: models/discriminator.py:29-99 with
+ * h = relu(c1(.)) and the block outputs in this layout); reference counterpart of every call: the same nn.Conv2d / avg_pool2d on a
+ * permuted tensor.  Per-operand flags (each implies the matching _BF16 flag, which must be set too; bf16 arithmetic only):
+ *   AGL_CONV_X_BLOCKED     x of agl_conv2d_fwd / _addend / _shortcut and of agl_conv2d_bwd_weight (3x3 stride 1, 4x4 stride 2)
+ *   AGL_CONV_Y_BLOCKED     y of agl_conv2d_fwd (3x3 stride 1 with a blocked x; the <= 4-input-channel 3x3 stream kernel), of
+ *                          agl_conv2d_fwd_addend (1x1, fp32 NCHW x and addend) and of agl_conv2d_fwd_shortcut
+ *   AGL_CONV_MASK_BLOCKED  pos_mask of agl_conv2d_bwd_data (with AGL_CONV_MASK_BF16; dy and dx stay fp32 NCHW)
+ * agl_conv2d_fwd_takes_blocked says whether the forward forms exist for the extents; the weight gradient and the masked input
+ * gradient take a blocked operand whenever they take the bf16 one (agl_conv2d_bwd_weight_takes_bf16_x / _bwd_data_takes_bf16_mask)
+ * with ks 3 / stride 1 or ks 4 / stride 2. */
+#define AGL_CONV_X_BLOCKED (1 << 21)
+#define AGL_CONV_Y_BLOCKED (1 << 22)
+#define AGL_CONV_MASK_BLOCKED (1 << 23)
+#define AGL_CONV_BLOCKED (AGL_CONV_X_BLOCKED | AGL_CONV_Y_BLOCKED)
 int agl_conv2d_fwd_takes_blocked(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
+/* NCHW fp32 (x_bf16 = 0) or bf16 (1) -> channel-blocked bf16; avg_pool2(relu?(x)) of a blocked x into an fp32 NCHW y (the shortcut's pool,
+ * discriminator.py:58-60, :97-99); the backward of that pool with the ReLU mask read from the blocked x (dy, dx fp32 NCHW). */
+int agl_to_blocked(const void* x, void* y_blk, int N, int C, int H, int W, int x_bf16, void* stream);
+int agl_avgpool2_fwd_xblk(const void* x_blk, float* y, int N, int C, int H, int W, int in_relu, void* stream);
+int agl_avgpool2_bwd_xblk(const float* dy, const void* x_blk, float* dx, int N, int C, int H, int W, int accumulate, void* stream);
 int agl_conv2d_fwd_writes_bf16_y(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int relu, int accumulate,
                                  int flags);
 int agl_conv2d_bwd_data_takes_bf16_dy(int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);

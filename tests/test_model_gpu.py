@@ -132,6 +132,50 @@ def test_discriminator_vs_oracle(which):
 
 
 @pytest.mark.parametrize("which", ["img", "obj", "att128"])
+def test_block_chain_node_with_channel_blocked_tensors_is_bit_identical(which):
+    """agl.dtrunk with its bf16 tensors channel-blocked (D_BLOCKED, the default) against the same node with NCHW bf16 tensors (the
+    round-4 form): the launches stage and store different layouts of the same values, so the logits, the input gradient, every parameter
+    gradient and the spectral-norm state must agree BIT FOR BIT — at config-3 extents, where every covered block takes the blocked form."""
+    import copy
+    from agl import dtrunk as T
+    from agl import lib as L
+    nets = build_nets(which == "att128")
+    net = {"img": nets[1], "obj": nets[2], "att128": nets[3]}[which]
+    shape = {"img": (32, 3, 128, 128), "obj": (210, 3, 64, 64), "att128": (96, 3, 64, 64)}[which]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    res = {}
+    for blocked in (True, False):
+        nd = copy.deepcopy(net)
+        xg = x.to(DEV).requires_grad_(True)
+        prev, T.D_BLOCKED = T.D_BLOCKED, blocked
+        T._cover_memo.clear(); T._blocked_memo.clear()
+        try:
+            with L.conv_flags(L.CONV_BF16):
+                yg = [nd(xg)] if which != "obj" else list(nd(xg))
+                if blocked:
+                    kinds = ["first_down" if which == "img" else "first_flat"] + ["down"] * (len(nd.main) - 1)
+                    chans = [(3, 64)] + [(64 << k, 128 << k) for k in range(4)] + ([(1024, 1024)] if which == "att128" else [])
+                    k0, k1, o16 = T.cover(kinds, chans, shape[0], shape[2], shape[3])
+                    assert T.blocked_ok(kinds, chans, k0, k1, o16, shape[0], shape[2], shape[3]), "the blocked form must be taken at these extents"
+                cots = [torch.randn(t.shape, generator=torch.Generator().manual_seed(4)).to(DEV) for t in yg]
+                torch.autograd.backward(yg, cots)
+        finally:
+            T.D_BLOCKED = prev
+            T._cover_memo.clear(); T._blocked_memo.clear()
+        torch.cuda.synchronize()
+        res[blocked] = ([t.detach() for t in yg], xg.grad, {k: q.grad for k, q in nd.named_parameters()},
+                        {k: v for k, v in nd.state_dict().items() if k.endswith(("weight_u", "weight_v"))})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b), ("logits", float((a - b).abs().max()))
+    assert torch.equal(res[True][1], res[False][1]), ("input gradient", float((res[True][1] - res[False][1]).abs().max()))
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), ("gradient", k, float((res[True][2][k] - res[False][2][k]).abs().max()))
+    for k in res[True][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), ("spectral-norm state", k)
+
+
+@pytest.mark.parametrize("which", ["img", "obj", "att128"])
 def test_discriminator_block_chain_as_one_node_with_bf16_activations(which):
     """VERDICT r3 item 1 for the discriminators (agl.dtrunk): in bf16 arithmetic a prefix of the block chain runs as ONE autograd node
     whose internal activations — h = relu(c1(.)) of every block and the block outputs that only convolutions and the shortcut's

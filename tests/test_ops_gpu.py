@@ -1356,6 +1356,87 @@ def test_channel_blocked_bf16_convolution_prototype(case, in_relu, relu, bias):
     close(L.from_blocked(yb).float(), ref, 1e-2, "blocked bf16 convolution vs torch on bf16-rounded operands")
 
 
+@pytest.mark.parametrize("case", [(6, 64, 32, 128), (5, 128, 16, 256), (9, 64, 8, 64), (3, 64, 64, 64), (17, 256, 8, 512)])
+def test_channel_blocked_forms_of_a_discriminator_block_equal_the_nchw_bf16_forms(case):
+    """Every launch of a discriminator block with its bf16 tensors channel-blocked ([N][C/8][H][W][8], include/agl.h AGL_CONV_X_BLOCKED /
+    _Y_BLOCKED / _MASK_BLOCKED; agl/dtrunk.py) against the same launch on NCHW bf16 tensors: the staged pieces, the products, the order
+    of accumulation and the one rounding of the output are the same, so every result must agree BIT FOR BIT —
+      forward : c1 3x3 (blocked -> blocked, input ReLU, bias, ReLU), pooled 4x4 / stride 2 (blocked -> fp32 NCHW), 1x1 + fp32 addend
+                (fp32 NCHW -> blocked), the shortcut's average pool of a blocked tensor, agl_to_blocked;
+      backward: both weight gradients with a blocked x, both input gradients with a blocked ReLU mask, the pool's backward."""
+    from agl import lib as L
+    N, C, H, Cout = case
+    r16 = lambda t: t.to(torch.bfloat16)
+    o, w1, b1 = rn(N, C, H, H), rn(C, C, 3, 3, seed=1) * (1.0 / (C * 9) ** 0.5), rn(C, seed=2)
+    w4, b2 = rn(Cout, C, 4, 4, seed=3) * (1.0 / (C * 16) ** 0.5), rn(Cout, seed=4)
+    wsc, bsc = rn(Cout, C, 1, 1, seed=5) * (1.0 / C ** 0.5), rn(Cout, seed=6)
+    d = rn(N, Cout, H // 2, H // 2, seed=7)
+    dh_in = rn(N, C, H, H, seed=8)
+    with L.conv_flags(L.CONV_BF16 | L.CONV_ANY_GRID):
+        od = dev(o)
+        o16 = r16(od)
+        ob = L.to_blocked_dev(od)
+        assert torch.equal(ob, L.to_blocked(od)) and torch.equal(L.to_blocked_dev(o16), ob) and torch.equal(L.from_blocked(ob), o16)
+        # forward
+        h16 = L.conv2d_fwd(o16, dev(w1), dev(b1), 1, 1, 0, True, True, out_bf16=True)
+        hb = L.conv2d_fwd(ob, dev(w1), dev(b1), 1, 1, 0, True, True, out_blk=True)
+        assert L.is_blk(hb) and torch.equal(L.from_blocked(hb), h16), "c1: blocked in / out"
+        s16, sb = L.avgpool2_fwd(o16, True), L.avgpool2_fwd(ob, True)
+        assert torch.equal(s16, sb), "average pool of a blocked tensor"
+        hp16 = L.conv2d_fwd(h16, dev(w4), dev(b2), 2, 1)
+        hpb = L.conv2d_fwd(hb, dev(w4), dev(b2), 2, 1)
+        assert hpb.dtype == torch.float32 and torch.equal(hp16, hpb), "pooled 4x4 / stride 2: blocked x"
+        out16 = L.conv2d_fwd_addend(s16, dev(wsc), dev(bsc), hp16, 1, 0, out_bf16=True)
+        outb = L.conv2d_fwd_addend(s16, dev(wsc), dev(bsc), hp16, 1, 0, out_blk=True)
+        assert L.is_blk(outb) and torch.equal(L.from_blocked(outb), out16), "1x1 + addend: blocked y"
+        # backward
+        dd, dhd = dev(d), dev(dh_in)
+        dh16 = L.conv2d_bwd_data(dd, dev(w4), (H, H), 2, 1, pos_mask=h16)
+        dhb = L.conv2d_bwd_data(dd, dev(w4), (H, H), 2, 1, pos_mask=hb)
+        assert torch.equal(dh16, dhb), "4x4 / stride-2 input gradient: blocked mask"
+        dw4_16, dw4_b = L.conv2d_bwd_weight(dd, h16, 4, 2, 1), L.conv2d_bwd_weight(dd, hb, 4, 2, 1)
+        assert torch.equal(dw4_16, dw4_b), "4x4 / stride-2 weight gradient: blocked x"
+        dw1_16, dw1_b = L.conv2d_bwd_weight(dhd, o16, 3, 1, 1, in_relu=True), L.conv2d_bwd_weight(dhd, ob, 3, 1, 1, in_relu=True)
+        assert torch.equal(dw1_16, dw1_b), "3x3 weight gradient: blocked x, input ReLU"
+        ds = dev(rn(N, C, H // 2, H // 2, seed=9))
+        do16 = L.avgpool2_bwd(ds, o16, True)
+        dob = L.avgpool2_bwd(ds, ob, True)
+        assert torch.equal(do16, dob), "pool backward: blocked mask"
+        do16 = L.conv2d_bwd_data(dhd, dev(w1), (H, H), 1, 1, pos_mask=o16, out=do16, accumulate=True)
+        dob = L.conv2d_bwd_data(dhd, dev(w1), (H, H), 1, 1, pos_mask=ob, out=dob, accumulate=True)
+        assert torch.equal(do16, dob), "3x3 input gradient: blocked mask, accumulate"
+    # and the chain equals torch on bf16-rounded operands within the bf16 bars
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    h_ref = torch.relu(TF.conv2d(torch.relu(r(o)), r(w1), b1, padding=1))
+    close(L.from_blocked(hb).float(), h_ref, 1e-2, "c1 vs torch")
+    hp_ref = TF.conv2d(r(h_ref), r(w4), b2, stride=2, padding=1)
+    close(hpb, hp_ref, 2e-2, "pooled convolution vs torch")
+
+
+def test_first_block_of_a_flat_discriminator_with_channel_blocked_tensors():
+    """The first block of the object / attribute discriminator (3 -> 64 on the crop, no down-sampling) with h and the block output
+    channel-blocked: the few-input-channel stream kernel writes blocked pieces, the second convolution reads blocked h and writes the
+    blocked sum with the 3-channel shortcut evaluated in its epilogue; h as the blocked x of the weight gradient and as the blocked mask of
+    the input gradient.  Bit identity with the NCHW bf16 launches."""
+    from agl import lib as L
+    N, C, H = 7, 64, 32
+    x, w1, b1 = rn(N, 3, H, H), rn(C, 3, 3, 3, seed=1) * 0.2, rn(C, seed=2)
+    w2, b2 = rn(C, C, 3, 3, seed=3) * (1.0 / (C * 9) ** 0.5), rn(C, seed=4)
+    wsc, bsc = rn(C, 3, seed=5) * 0.5, rn(C, seed=6)
+    d = rn(N, C, H, H, seed=7)
+    with L.conv_flags(L.CONV_BF16 | L.CONV_ANY_GRID):
+        xd = dev(x)
+        h16 = L.conv2d_fwd(xd, dev(w1), dev(b1), 1, 1, 0, False, True, out_bf16=True)
+        hb = L.conv2d_fwd(xd, dev(w1), dev(b1), 1, 1, 0, False, True, out_blk=True)
+        assert L.is_blk(hb) and torch.equal(L.from_blocked(hb), h16), "3 -> C stream kernel: blocked y"
+        o16 = L.conv2d_fwd_shortcut(h16, dev(w2), dev(b2), xd, dev(wsc), dev(bsc), 1, out_bf16=True)
+        ob = L.conv2d_fwd_shortcut(hb, dev(w2), dev(b2), xd, dev(wsc), dev(bsc), 1, out_blk=True)
+        assert L.is_blk(ob) and torch.equal(L.from_blocked(ob), o16), "second convolution + shortcut: blocked x and y"
+        dd = dev(d)
+        assert torch.equal(L.conv2d_bwd_data(dd, dev(w2), (H, H), 1, 1, pos_mask=h16), L.conv2d_bwd_data(dd, dev(w2), (H, H), 1, 1, pos_mask=hb))
+        assert torch.equal(L.conv2d_bwd_weight(dd, h16, 3, 1, 1), L.conv2d_bwd_weight(dd, hb, 3, 1, 1))
+
+
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
 def test_odd_sized_input_gradient_on_concurrent_streams(mode):
     """The training step runs the three generator branches' layout encoders on three streams, so three of these launches (paired-phase
