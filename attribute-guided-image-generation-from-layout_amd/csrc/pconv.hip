@@ -348,6 +348,9 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // 128: y is written channel-blocked bf16 [N][Cout/8][OH][OW][8] straight from the accumulators (half a piece per lane, no LDS transpose),
   // with the optional fp32 NCHW addend / the few-channel shortcut (FEAT 16) / bias / ReLU applied before the one rounding
   constexpr bool YBLK = (FEAT & 128) != 0;
+  // 256: channel-blocked bf16 pos_mask in the plain epilogue, applied to the accumulators before the transpose (the paired-phase kernels
+  // have it with FEAT 8).  Its own instantiations: in the featureless 3x3 kernel the code cost registers and a resident workgroup.
+  constexpr bool F_MBLK = (FEAT & 256) != 0;
   static_assert(!(BLK || YBLK) || (NSPL == 1 && !PHS && !VERT), "blocked layout: bf16 arithmetic, plain (non-phase) forms");
   constexpr int KSW = VERT ? 1 : KS;           // window columns
   static_assert(!VERT || (S == 1 && !PHS && TG == KS), "vertical window");
@@ -789,7 +792,68 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   // Each wave transposes its tiles through its own LDS scratch (the staging buffers are free after the loop's last barrier):
   // afterwards a lane holds 4 consecutive pixels of one channel and every tile takes 4 sixteen-byte stores (and 16-byte
   // loads for the optional mask / accumulate operands, issued together — no per-element load-then-wait chains).
+  // Channel-blocked ReLU mask (p.mask_blk; input gradients of a discriminator block, no bias): applied to the ACCUMULATORS, whose layout is
+  // the mask's — a lane holds channels 8g + 4*lh + q of one pixel, i.e. one 8-byte half of the mask's 16-byte piece per g: four coalesced
+  // 8-byte loads per tile (a wave covers 32 consecutive pieces) instead of four 2-byte loads 16 bytes apart per channel row after the
+  // transpose.  Paired phases: pixel (a, b) of column phase pw is output pixel (2a + ph, 2b + pw).
+  bool mask_done = false;
+  if constexpr ((!PHS && F_MBLK) || (PAIR && F_PMASK16)) {
+    if (p.pos_mask && p.mask_bf16 && p.mask_blk) {
+      mask_done = true;
+      const uint2* const mk = reinterpret_cast<const uint2*>(p.pos_mask);
+      const int mh = PHS ? p.oh2 : p.OH, mw = PHS ? p.ow2 : p.OW;
+      const long gstride = (long)mh * mw * 2;      // uint2 units between consecutive 8-channel groups
+#pragma unroll
+      for (int jt = 0; jt < WTN; ++jt) {
+        const int jq = wn * (BN / WNW) + 32 * jt + l31;
+        const int tiq = jq / (TH * TW), rq = jq - tiq * (TH * TW), pyq = rq / TW, pxq = rq - pyq * TW;
+        const int imq = img0 + tiq;
+#pragma unroll
+        for (int w = 0; w < NPW; ++w) {
+          const int yy = PHS ? 2 * (ty0 + pyq) + ph_y : ty0 + pyq, xx = PHS ? 2 * (tx0 + pxq) + w : tx0 + pxq;
+          // all loads of the tile first (clamped addresses, no branches around them), then the selects: one wait, not sixteen
+          uint2 mb[WTM][4];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int mch = bm0 + wm * (BM / 2) + 32 * i + 8 * g;
+              const bool ok = mch < p.Cout && imq < p.N;
+              const long idx = ok ? ((((long)imq * (p.Cout >> 3) + (mch >> 3)) * mh + yy) * mw + xx) * 2 + lh : 0;
+              const uint2 v = mk[idx];
+              mb[i][g] = ok ? v : uint2{0x3f803f80u, 0x3f803f80u};      // (outside the tensor: nothing to mask, nothing is stored)
+            }
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const uint2 b2 = mb[i][g];
+              if (!(__builtin_bit_cast(float, b2.x << 16) > 0.f)) accs[w][0][i][jt][4 * g + 0] = 0.f;
+              if (!(__builtin_bit_cast(float, b2.x & 0xffff0000u) > 0.f)) accs[w][0][i][jt][4 * g + 1] = 0.f;
+              if (!(__builtin_bit_cast(float, b2.y << 16) > 0.f)) accs[w][0][i][jt][4 * g + 2] = 0.f;
+              if (!(__builtin_bit_cast(float, b2.y & 0xffff0000u) > 0.f)) accs[w][0][i][jt][4 * g + 3] = 0.f;
+            }
+        }
+      }
+      (void)gstride;
+    }
+  }
   float* const ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_PITCH);
+  // YBLK: a lane finishes 16 channels of one pixel, so the per-channel constants (bias; the shortcut's bias and <= 4 weights) would be
+  // 16 x 6 broadcast loads from global memory per tile — they are staged once per workgroup in LDS instead ([BM][8] floats; the staging
+  // buffers are free after the loop's last barrier)
+  float* const ytab = reinterpret_cast<float*>(lds);
+  if constexpr (YBLK) {
+    for (int e = tid; e < BM; e += NT) {
+      const int m = bm0 + e;
+      const bool ok = m < p.Cout;
+      ytab[8 * e + 0] = (ok && p.bias) ? p.bias[m] : 0.f;
+      ytab[8 * e + 1] = (F_SC && ok && p.sc_x && p.sc_b) ? p.sc_b[m] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ytab[8 * e + 2 + c] = (F_SC && ok && p.sc_x && c < p.sc_cin) ? p.sc_w[m * p.sc_cin + c] : 0.f;
+    }
+    __syncthreads();
+  }
   const long OHW = (long)p.OH * p.OW;
   const float osc = (p.odiv && !p.slabs) ? 1.0f / *p.odiv : 1.0f;     // (slabs carry raw sums: the slab reduction divides)
   const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8*pass, columns ec..ec+3
@@ -828,6 +892,16 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) scq[c] = (p.sc_x && c < p.sc_cin && imq < p.N) ? p.sc_x[((long)imq * p.sc_cin + c) * OHW + pixq] : 0.f;
         }
+        float ad[4][4];      // the addend's 16 values of this lane, all loads issued before the first use (clamped addresses)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = bm0 + wm * (BM / 2) + 32 * i + 8 * g + 4 * lh + q;
+            const bool ok = p.addend != nullptr && m < p.Cout && imq < p.N;
+            const float v = (p.addend ? p.addend : reinterpret_cast<const float*>(p.wp))[ok ? ((long)imq * p.Cout + m) * OHW + pixq : 0];
+            ad[g][q] = ok ? v : 0.f;
+          }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int mch = bm0 + wm * (BM / 2) + 32 * i + 8 * g;      // first channel of the piece
@@ -837,16 +911,14 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int m = mch + 4 * lh + q;
-              float t = acc[0][i][jt][4 * g + q] * osc + (p.bias ? p.bias[m] : 0.f);
-              if (p.addend) t += p.addend[((long)imq * p.Cout + m) * OHW + pixq];      // (fp32 NCHW: consecutive lanes, consecutive pixels)
+              const float* const tb = ytab + 8 * (m - bm0);
+              float t = acc[0][i][jt][4 * g + q] * osc + tb[0];
+              t += ad[g][q];      // (fp32 NCHW addend: consecutive lanes read consecutive pixels)
               if constexpr (F_SC) {
-                if (p.sc_x) {
-                  float sv = p.sc_b ? p.sc_b[m] : 0.f;
+                float sv = tb[1];
 #pragma unroll
-                  for (int c = 0; c < 4; ++c)
-                    if (c < p.sc_cin) sv = fmaf(p.sc_w[m * p.sc_cin + c], scq[c], sv);
-                  t += sv;
-                }
+                for (int c = 0; c < 4; ++c) sv = fmaf(tb[2 + c], scq[c], sv);      // (zero weights beyond sc_cin / without a shortcut)
+                t += sv;
               }
               if (p.relu) t = fmaxf(t, 0.f);
               ob[q] = (__bf16)t;
@@ -903,17 +975,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
               *reinterpret_cast<f4u*>(sd + 4) = f4u{v[ps].z, v1[ps].z, v[ps].w, v1[ps].w};
               continue;
             }
-            if (p.pos_mask) {
+            if (p.pos_mask && !mask_done) {
               f4u m0, m1;
               if (F_PMASK16 && p.mask_bf16) {      // eight bf16 in one 16-byte load (widened by a shift: sign and zero are the stored value's)
-                uint4 b;
-                if (p.mask_blk) {      // channel-blocked mask: eight pixels of channel m, 16 bytes apart
-                  const unsigned short* q = reinterpret_cast<const unsigned short*>(p.pos_mask) +
-                      ((((long)img * (p.Cout >> 3) + (m >> 3)) * p.oh2 + 2 * (ty0 + py) + ph_y) * p.ow2 + 2 * (tx0 + px)) * 8 + (m & 7);
-                  b.x = (unsigned)q[0] | ((unsigned)q[8] << 16); b.y = (unsigned)q[16] | ((unsigned)q[24] << 16);
-                  b.z = (unsigned)q[32] | ((unsigned)q[40] << 16); b.w = (unsigned)q[48] | ((unsigned)q[56] << 16);
-                } else
-                b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.pos_mask) + ob + (long)m * OHW2);
+                const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.pos_mask) + ob + (long)m * OHW2);
                 m0 = f4u{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
                          __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
                 m1 = f4u{__builtin_bit_cast(float, b.z << 16), __builtin_bit_cast(float, b.z & 0xffff0000u),
@@ -995,24 +1060,17 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
           old[ps] = (m < p.Cout && img < p.N) ? *reinterpret_cast<const float4*>(src + pbase + (long)m * OHW) : float4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      if (p.pos_mask && p.mask_bf16) {      // (bf16 -> fp32 is a shift: sign and zero are those of the stored value)
+      if (p.pos_mask && p.mask_bf16 && !mask_done) {      // (bf16 -> fp32 is a shift: sign and zero are those of the stored value)
         const unsigned short* const mk = reinterpret_cast<const unsigned short*>(p.pos_mask);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
           uint2 b = {0u, 0u};
-          if (p.mask_blk) {      // channel-blocked mask: this lane's four pixels of channel m lie 16 bytes apart (a wave's rows share 512-byte runs)
-            if (m < p.Cout && img < p.N) {
-              const unsigned short* q = mk + ((((long)img * (p.Cout >> 3) + (m >> 3)) * p.OH + ty0 + py) * p.OW + tx0 + px) * 8 + (m & 7);
-              b.x = (unsigned)q[0] | ((unsigned)q[8] << 16);
-              b.y = (unsigned)q[16] | ((unsigned)q[24] << 16);
-            }
-          } else
           if (m < p.Cout && img < p.N) b = *reinterpret_cast<const uint2*>(mk + pbase + (long)m * OHW);
           msk[ps] = float4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
                            __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
         }
-      } else if (p.pos_mask) {
+      } else if (p.pos_mask && !mask_done) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int m = mb + 8 * ps;
@@ -1025,7 +1083,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         if (m < p.Cout && img < p.N) {
           float4 o = v[ps];
           if (p.bias) { const float bb = p.bias[m]; o.x += bb; o.y += bb; o.z += bb; o.w += bb; }
-          if (p.pos_mask) {
+          if (p.pos_mask && !mask_done) {
             if (!(msk[ps].x > 0.f)) o.x = 0.f;
             if (!(msk[ps].y > 0.f)) o.y = 0.f;
             if (!(msk[ps].z > 0.f)) o.z = 0.f;
@@ -1776,7 +1834,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
   p.fold = a.fold; p.y_bf16 = a.y_bf16; p.addend = a.addend; p.blk = a.x_blk | (a.y_blk << 1); p.mask_blk = a.mask_blk;
   if ((a.x_blk || a.y_blk) && !pconv_takes_blocked(a)) return -1;
-  if (a.mask_blk && !a.mask_bf16) return -1;
+  if (a.mask_blk && (!a.mask_bf16 || a.bias)) return -1;      // (a blocked mask is applied to the accumulators, before any bias)
+  if (a.mask_blk && !(a.ks == 3 && !s2 && a.nsplit == 1 && geo != 2 && !featy && !featsc && !a.x_blk && !a.y_blk)) return -1;      // (FEAT 256 instantiations)
   p.sc_x = a.sc_x; p.sc_w = a.sc_w; p.sc_b = a.sc_b; p.sc_cin = a.sc_cin;
   p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * KK * mpad);      // (read by the H16 instantiations only)
   if (a.sc_x && !(a.ks == 3 && !s2 && a.nsplit == 1 && bm == 64 && geo != 2 && pl.splits == 1 && a.sc_cin >= 1 && a.sc_cin <= 4 && a.OW % 4 == 0))
@@ -1897,6 +1956,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     } else if (a.nsplit == 1 && a.x_blk && a.y_blk && featsc) { PC_SHAPES1F(208, 3, 64, 9);      // (pconv_takes_blocked)
     } else if (a.nsplit == 1 && a.x_blk && a.y_blk) {
       if (bm == 128) PC_SHAPES1F(192, 3, 128, 9); else PC_SHAPES1F(192, 3, 64, 9);
+    } else if (a.nsplit == 1 && a.mask_blk) { if (bm == 128) PC_SHAPES1F(256, 3, 128, 9); else PC_SHAPES1F(256, 3, 64, 9);
     } else if (a.nsplit == 1 && featsc) { PC_SHAPES1F(20, 3, 64, 9); }
     else if (a.nsplit == 1 && featy) { if (bm == 128) PC_SHAPES1F(4, 3, 128, 9); else PC_SHAPES1F(4, 3, 64, 9); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(3, 128, 9); else PC_SHAPES1(3, 64, 9); }
@@ -2144,7 +2204,7 @@ int pconvT_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, cons
   p.wexp = reinterpret_cast<const int*>(wp + (long)pack_planes(a.nsplit) * nch * 2 * 16 * mpad);
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
   p.blk = 0; p.mask_blk = a.mask_blk;
-  if (a.mask_blk && !a.mask_bf16) return -1;
+  if (a.mask_blk && (!a.mask_bf16 || a.bias)) return -1;      // (a blocked mask is applied to the accumulators, before any bias)
   if (a.x_bf16 && a.nsplit != 1) return -1;
   // bf16 ReLU mask: the paired-phase epilogue of the bf16 instantiations (16-byte pieces of 8 mask elements), no reduction split, even size
   if (a.mask_bf16 && (a.nsplit != 1 || !a.pos_mask || splits > 1 || geo == 3 || a.OH != 2 * a.H)) return -1;

@@ -372,60 +372,61 @@ __global__ void to_blocked_k(const void* __restrict__ xv, uint4* __restrict__ y,
   y[i] = uint4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16),
                (unsigned)h[6] | ((unsigned)h[7] << 16)};
 }
-// avg_pool2(relu?(x)) of a blocked bf16 x into an fp32 NCHW y: a thread owns 8 channels x 4 output pixels of one output row — it reads
-// 2 rows x 8 pieces (16 bytes each, consecutive) and writes one 16-byte store per channel (same order of additions as avgpool2_fwd_k)
+// avg_pool2(relu?(x)) of a blocked bf16 x into an fp32 NCHW y: a thread owns one output pixel of 8 channels — four 16-byte pieces in
+// (consecutive threads: consecutive 32-byte runs), eight 4-byte stores out, each coalesced along x across the threads (same order of
+// additions as avgpool2_fwd_k)
 __global__ void avgpool2_fwd_blk_k(const uint4* __restrict__ x, float* __restrict__ y, long NG, int H, int W, int in_relu) {
-  const unsigned OH = H / 2, OW = W / 2, Q = W / 8;
+  const unsigned OH = H / 2, OW = W / 2;
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= NG * OH * Q) return;
-  const unsigned q = (unsigned)(i % Q);
-  const long t = i / Q;
-  const unsigned oh = (unsigned)(t % OH);
+  if (i >= NG * OH * OW) return;
+  const unsigned ox = (unsigned)(i % OW);
+  const long t = i / OW;
+  const unsigned oy = (unsigned)(t % OH);
   const long g = t / OH;
-  float acc[8][4];
-  float r[2][8][8];      // [row][pixel][channel]
+  float v[4][8];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 4; ++k) {
+    const uint4 b = x[(g * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)];
+    const unsigned u[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int px = 0; px < 8; ++px) {
-      const uint4 b = x[(g * H + 2 * oh + k) * W + 8 * q + px];
-      const unsigned u[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo = __builtin_bit_cast(float, u[j] << 16), hi = __builtin_bit_cast(float, u[j] & 0xffff0000u);
-        if (in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        r[k][px][2 * j] = lo; r[k][px][2 * j + 1] = hi;
-      }
+    for (int j = 0; j < 4; ++j) {
+      float lo = __builtin_bit_cast(float, u[j] << 16), hi = __builtin_bit_cast(float, u[j] & 0xffff0000u);
+      if (in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+      v[k][2 * j] = lo; v[k][2 * j + 1] = hi;
     }
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[c][o] = (r[0][2 * o][c] + r[0][2 * o + 1][c] + r[1][2 * o][c] + r[1][2 * o + 1][c]) * 0.25f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    *reinterpret_cast<float4*>(y + ((g * 8 + c) * OH + oh) * (long)OW + 4 * q) = float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
-}
-// avgpool2_bwd4_m16_k with the ReLU mask read from a blocked bf16 x: the four pixels of a thread lie 16 bytes apart
-__global__ void avgpool2_bwd4_mblk_k(const float* __restrict__ dy, const unsigned short* __restrict__ x, float* __restrict__ dx, long NC, int C, int H,
-                                     int W, int accumulate) {
-  const unsigned OW = W / 2, W4 = W / 4;
-  const unsigned i = blockIdx.x * TPB + threadIdx.x;
-  if (i >= (unsigned)(NC * H * W4)) return;
-  const unsigned w4 = i % W4, t = i / W4, h = t % H, nc = t / H;
-  const float2 d = *reinterpret_cast<const float2*>(dy + (long)nc * (H / 2) * OW + (long)(h / 2) * OW + 2 * w4);
-  float4 v = {0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y};
-  const long o = 4L * i;
-  const unsigned n = nc / C, c = nc - n * C;
-  const unsigned short* m = x + ((((long)n * (C >> 3) + (c >> 3)) * H + h) * W + 4 * w4) * 8 + (c & 7);
-  if (!(__builtin_bit_cast(float, (unsigned)m[0] << 16) > 0.f)) v.x = 0.f;
-  if (!(__builtin_bit_cast(float, (unsigned)m[8] << 16) > 0.f)) v.y = 0.f;
-  if (!(__builtin_bit_cast(float, (unsigned)m[16] << 16) > 0.f)) v.z = 0.f;
-  if (!(__builtin_bit_cast(float, (unsigned)m[24] << 16) > 0.f)) v.w = 0.f;
-  if (accumulate) {
-    const float4 ov = *reinterpret_cast<const float4*>(dx + o);
-    v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
   }
-  *reinterpret_cast<float4*>(dx + o) = v;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) y[((g * 8 + c) * OH + oy) * (long)OW + ox] = (v[0][c] + v[1][c] + v[2][c] + v[3][c]) * 0.25f;
+}
+// Backward of that pool with the ReLU mask read from the blocked x: a thread owns four consecutive input pixels of 8 channels — four mask
+// pieces (64 contiguous bytes), one 8-byte dy load and one 16-byte store per channel.  W % 4 == 0.
+__global__ void avgpool2_bwd_mblk_k(const float* __restrict__ dy, const uint4* __restrict__ x, float* __restrict__ dx, long NG, int H, int W,
+                                    int accumulate) {
+  const unsigned OH = H / 2, OW = W / 2, W4 = W / 4;
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= NG * H * W4) return;
+  const unsigned x4 = (unsigned)(i % W4);
+  const long t = i / W4;
+  const unsigned Y = (unsigned)(t % H);
+  const long g = t / H;
+  uint4 mb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mb[k] = x[(g * H + Y) * W + 4 * x4 + k];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float2 d = *reinterpret_cast<const float2*>(dy + ((g * 8 + c) * OH + (Y >> 1)) * (long)OW + 2 * x4);
+    float4 v = {0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y};
+    float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned u = reinterpret_cast<const unsigned*>(&mb[k])[c >> 1];
+      const float mval = __builtin_bit_cast(float, (c & 1) ? (u & 0xffff0000u) : (u << 16));
+      if (!(mval > 0.f)) vv[k] = 0.f;
+    }
+    float4* o = reinterpret_cast<float4*>(dx + ((g * 8 + c) * H + Y) * (long)W + 4 * x4);
+    if (accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+    *o = v;
+  }
 }
 
 // nearest up-sampling by 2^k (F.interpolate(mode='nearest') with integer factor) and its adjoint
@@ -995,7 +996,7 @@ int agl_avgpool2_fwd_xblk(const void* x_blk, float* y, int N, int C, int H, int 
   AGL_REQUIRE(x_blk && y && N > 0 && C % 8 == 0 && H >= 2 && H % 2 == 0 && W >= 8 && W % 8 == 0 && (long)N * C * H * W < (1L << 31) &&
               (((uintptr_t)x_blk | (uintptr_t)y) & 15) == 0, "agl_avgpool2_fwd_xblk: bad argument (C % 8 == 0, W % 8 == 0, even H, 16-byte aligned)");
   const long NG = (long)N * (C / 8);
-  LAUNCH1D(avgpool2_fwd_blk_k, NG * (H / 2) * (W / 8), (const uint4*)x_blk, y, NG, H, W, in_relu);
+  LAUNCH1D(avgpool2_fwd_blk_k, NG * (H / 2) * (W / 2), (const uint4*)x_blk, y, NG, H, W, in_relu);
   AGL_CHECK_LAUNCH("agl_avgpool2_fwd_xblk");
   return AGL_OK;
 }
@@ -1003,8 +1004,8 @@ int agl_avgpool2_fwd_xblk(const void* x_blk, float* y, int N, int C, int H, int 
 int agl_avgpool2_bwd_xblk(const float* dy, const void* x_blk, float* dx, int N, int C, int H, int W, int accumulate, void* stream) {
   AGL_REQUIRE(dy && x_blk && dx && N > 0 && C % 8 == 0 && H >= 2 && H % 2 == 0 && W % 4 == 0 && (long)N * C * H * W < (1L << 31),
               "agl_avgpool2_bwd_xblk: bad argument");
-  const long NC = (long)N * C;
-  LAUNCH1D(avgpool2_bwd4_mblk_k, NC * H * (W / 4), dy, (const unsigned short*)x_blk, dx, NC, C, H, W, accumulate);
+  const long NG = (long)N * (C / 8);
+  LAUNCH1D(avgpool2_bwd_mblk_k, NG * H * (W / 4), dy, (const uint4*)x_blk, dx, NG, H, W, accumulate);
   AGL_CHECK_LAUNCH("agl_avgpool2_bwd_xblk");
   return AGL_OK;
 }
