@@ -13,6 +13,18 @@ if os.environ.get("AGL_PRIO"): L.CONV_FLAGS |= int(os.environ["AGL_PRIO"]) << 14
 if os.environ.get("AGL_ABLATE"): L.CONV_FLAGS |= int(os.environ["AGL_ABLATE"]) << 9
 x = torch.randn(B, Cin, H, H, device="cuda:0"); w = torch.randn(Cout, Cin, ks, ks, device="cuda:0") * 0.05
 y = L.conv2d_fwd(x, w, None, s, p); dy = torch.randn_like(y)
+if os.environ.get("AGL_BLOCKED"):      # channel-blocked bf16 x (and y for 3x3 stride 1): the forms of the discriminators' block chain
+    xb = L.to_blocked_dev(x)
+    wsrc = L.WeightSrc(torch.nn.Parameter(w), lambda: 0)
+    fwd = lambda: L.conv2d_fwd(xb, w, None, s, p, in_relu=True, relu=(ks == 3), out_blk=(ks == 3 and s == 1), wsrc=wsrc)
+    for _ in range(25): fwd()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fwd()
+    e1.record(); torch.cuda.synchronize()
+    print("%s blocked fwd: %.1f us per call" % (sys.argv[1:8], 1e3 * e0.elapsed_time(e1) / 20))
+    sys.exit(0)
 for _ in range(5):
     if which == "fwd": L.conv2d_fwd(x, w, None, s, p)
     elif which == "bwd_data": L.conv2d_bwd_data(dy, w, (H, H), s, p)
