@@ -302,6 +302,7 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
             tr.finish()
             fence()
             log, L.EVENT_LOG = L.EVENT_LOG, None
+            packs_step, fused_step = L.PACK_STATS["packs"] - packs0, L.PACK_STATS["fused"] - fused0      # (of the instrumented step alone)
             # the same one-stream schedule without the per-launch events: its step time over the timed (concurrent) schedule's is the
             # overlap the chains on several streams buy — what a kernel-stats profile, which serialises them, cannot show
             t1 = time.perf_counter()
@@ -388,8 +389,8 @@ def run_workload(a, res, dtype, per_gpu, steps, warmup, dev, rank, world, dist):
                 "launches_per_step": len(conv), "kernel_ms_per_step": round(conv_ms, 3),
                 "executed_flops_per_step": executed, "algorithmic_flops_per_step": flops_step,
                 "algorithmic_equiv_tflops": round(flops_step / (conv_ms * 1e-3) / 1e12, 3),
-                "weight_packs_per_step": L.PACK_STATS["packs"] - packs0,      # individual pack launches (derived weights: ConvLSTM halves, pooled filters)
-                "fused_repacks_per_step": L.PACK_STATS["fused"] - fused0}      # launches of agl.lib.PackPlan.repack in the instrumented step (one per arena)
+                "weight_packs_per_step": packs_step,      # individual pack launches (derived weights: ConvLSTM halves, pooled filters)
+                "fused_repacks_per_step": fused_step}     # launches of agl.lib.PackPlan.repack in the instrumented step (one per arena)
         nrm = [e for e in log if e[0] in NORM_NAMES]
         nrm_ms = sum(e[1].elapsed_time(e[2]) for e in nrm)
         nbytes = sum(e[3] for e in nrm)
