@@ -14,12 +14,16 @@ call at N=64); this runs 3 + 3*(T-1) convolutions.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import numpy as np
 import torch
 
 from . import lib as L
+
+
+DEFER_SUM = os.environ.get("AGL_CLSTM_DEFER", "1") != "0"     # False: every recurrence convolution finishes its own reduction split (tests: identical results, one launch more per step)
 
 
 class SequencePlan:
@@ -105,7 +109,8 @@ class _LayoutConvLSTM(torch.autograd.Function):
                     cch = cprev = None
                 else:
                     po = plan.off[t - 1]
-                    cch = L.conv2d_fwd(H[po:po + n], Wh, None, 1, 2, wsrc=sh)
+                    # (a reduction split's partial outputs are added by the gate kernel: no epilogue launch between the two)
+                    cch = L.conv2d_fwd(H[po:po + n], Wh, None, 1, 2, wsrc=sh, defer=DEFER_SUM)
                     cprev = Cs[po:po + n]
                 L.lstm_gates_fwd(src, rows, cch, cprev, H[o:o + n], Cs[o:o + n], gates[o:o + n], n, hid, S)
             saved += [X, Wx, Wh, H, Cs, gates]
@@ -142,7 +147,8 @@ class _LayoutConvLSTM(torch.autograd.Function):
                 L.lstm_gates_bwd(dH_ext[o:o + n], dh_rec, n_next, dc_carry, n_next, gates[o:o + n], cprev, Cs[o:o + n],
                                  dCC[o:o + n], dc_prev, n, hid, S)
                 dc_carry = dc_prev
-                dh_rec = L.conv2d_bwd_data(dCC[o:o + n], Wh, (SH, SW), 1, 2, wsrc=sh) if t > 0 else None
+                # (consumed by the NEXT iteration's gate kernel, the next launch on this stream: its slabs may stay unreduced)
+                dh_rec = L.conv2d_bwd_data(dCC[o:o + n], Wh, (SH, SW), 1, 2, wsrc=sh, defer=DEFER_SUM) if t > 0 else None
                 n_next = n
             n0 = plan.n_t[0]
             if plan.T > 1:

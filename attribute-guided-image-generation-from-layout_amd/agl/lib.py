@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libagl.so")
 
-_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+_P, _I, _L, _F, _LL = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_longlong
 
 # name -> (restype, argtypes); must mirror include/agl.h (tests/test_abi.py checks both directions)
 SIGNATURES = {
@@ -57,6 +57,9 @@ SIGNATURES = {
     "agl_crop_bwd_sorted": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     "agl_lstm_gates_fwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
     "agl_lstm_gates_bwd": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_lstm_gates_fwd_sum": (_I, [_P, _P, _P, _I, _LL, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_lstm_gates_bwd_sum": (_I, [_P, _P, _I, _LL, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "agl_conv2d_deferred": (_I, [_P, _P, _P]),
     "agl_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
     "agl_axpby": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "agl_gather_rows": (_I, [_P, _P, _P, _L, _L, _I, _P]),
@@ -138,7 +141,7 @@ class SnLayer(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 7     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
+ABI_VERSION = 8     # = AGL_ABI_VERSION of include/agl.h; a library of another version is refused (shifted ctypes arguments fault on the GPU)
 
 
 def load() -> C.CDLL:
@@ -182,6 +185,7 @@ CONV_W8, CONV_PRIO = 128, 256
 CONV_X_BF16 = 1 << 17      # per-call: x holds bf16 elements (set by conv2d_fwd / conv2d_bwd_weight from the tensor's dtype)
 CONV_X_BLOCKED, CONV_Y_BLOCKED, CONV_MASK_BLOCKED = 1 << 21, 1 << 22, 1 << 23      # channel-blocked bf16 operands (include/agl.h)
 CONV_BLOCKED = CONV_X_BLOCKED | CONV_Y_BLOCKED
+CONV_DEFER_SUM = 1 << 24   # per-call: leave a plain reduction split unreduced for the caller's next kernel (include/agl.h)
 CONV_Y_BF16, CONV_MASK_BF16, CONV_DY_BF16 = 1 << 18, 1 << 19, 1 << 20      # per-call: bf16 output of conv2d_fwd / bf16 pos_mask of conv2d_bwd_data (from dtypes)
 CONV_FLAGS = 0
 
@@ -564,8 +568,10 @@ def _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, up, make=None):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False, out=None, accumulate=False, wsrc=None, out_bf16=False,
-               w_shape=None, make_base=None, out_blk=False):
+               w_shape=None, make_base=None, out_blk=False, defer=False):
     """out_bf16: y as a torch.bfloat16 tensor (agl_conv2d_fwd_writes_bf16_y says when the kernel that runs can write it).
+    defer: returns a DeferredSum instead of the tensor (AGL_CONV_DEFER_SUM: a reduction split's partial outputs may be left for the
+    caller's NEXT kernel on this stream to add — lstm_gates_fwd).
     w may be None when w_shape + wsrc + make_base are given: a derived weight that only exists in packed form (cached under wsrc;
     make_base() builds the tensor to pack on a miss) — the call must then run on the matrix-core patch kernel."""
     xblk = is_blk(x)
@@ -591,9 +597,24 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, up=0, in_relu=False, relu=False
     call("agl_conv2d_fwd", ptr(x, x.dtype if xb16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias),
          ptr(out, out.dtype if yb16 else torch.float32), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
          N, Cin, H, W, Cout, ks, stride, pad, up, int(in_relu), int(relu), int(accumulate),
-         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0) | (CONV_X_BLOCKED if xblk else 0) | (CONV_Y_BLOCKED if out_blk else 0),
-         stream())
-    return out
+         CONV_FLAGS | (CONV_X_BF16 if xb16 else 0) | (CONV_Y_BF16 if yb16 else 0) | (CONV_X_BLOCKED if xblk else 0) | (CONV_Y_BLOCKED if out_blk else 0)
+         | (CONV_DEFER_SUM if defer else 0), stream())
+    return DeferredSum(out, ws) if defer else out
+
+
+class DeferredSum:
+    """Result of a convolution called with defer=True: either the tensor (splits == 0) or `splits` partial outputs `stride` floats apart
+    in the stream's workspace, to be added by the next kernel on that stream (agl_conv2d_deferred; include/agl.h AGL_CONV_DEFER_SUM).
+    Valid until the workspace is used again — pass it to the consuming call at once."""
+    __slots__ = ("out", "ws", "addr", "splits", "stride")
+
+    def __init__(self, out, ws):
+        a, n, st = C.c_void_p(0), C.c_int(0), C.c_longlong(0)
+        call("agl_conv2d_deferred", C.addressof(a), C.addressof(n), C.addressof(st))
+        self.out, self.ws = out, ws
+        self.splits, self.stride = int(n.value), int(st.value)
+        self.addr = a.value if self.splits >= 2 else out.data_ptr()
+        assert self.splits == 0 or (ws is not None and ws.data_ptr() <= self.addr < ws.data_ptr() + ws.numel())
 
 
 def is_blk(t) -> bool:
@@ -852,7 +873,7 @@ def bwd_data_packed_bytes(N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad):
 
 
 def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accumulate=False, wsrc=None, w_shape=None, make_w=None,
-                    make_base=None):
+                    make_base=None, defer=False):
     """dx (N,Cin,IH,IW) from dy (N,Cout,OH,OW), w (Cout,Cin,ks,ks).  Also ConvTranspose2d forward.
     w may be None when w_shape + make_w are given: the weights are then a derived tensor that is only materialised when needed —
     make_w() builds w itself (for launches that read it), make_base() the tensor whose packed form is cached under wsrc
@@ -879,8 +900,9 @@ def conv2d_bwd_data(dy, w, in_hw, stride=1, pad=0, pos_mask=None, out=None, accu
     call("agl_conv2d_bwd_data", ptr(dy, dy.dtype if db16 else torch.float32), ptr(w), pk.data_ptr() if pk is not None else None, ptr(pdiv), None,
          ptr(pos_mask, torch.bfloat16 if mb16 else torch.float32), ptr(out),
          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, Cin, IH, IW, Cout, OH, OW, ks, stride, pad,
-         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0) | (CONV_X_BF16 if db16 else 0) | (CONV_MASK_BLOCKED if mblk else 0), stream())
-    return out
+         0, int(accumulate), CONV_FLAGS | (CONV_MASK_BF16 if mb16 else 0) | (CONV_X_BF16 if db16 else 0) | (CONV_MASK_BLOCKED if mblk else 0)
+         | (CONV_DEFER_SUM if defer else 0), stream())
+    return DeferredSum(out, ws) if defer else out
 
 
 def conv2d_bwd_weight(dy, x, ks, stride=1, pad=0, up=0, in_relu=False, out=None, accumulate=False, dbias=None, dbias_accumulate=None):
@@ -1152,13 +1174,23 @@ def sum_hw_bwd(dy, x, in_relu=False, scale=1.0):
     return dx
 
 
+def _sum_args(t):
+    """(address, splits, stride) of a tensor or a DeferredSum operand."""
+    if isinstance(t, DeferredSum):
+        return t.addr, t.splits, t.stride
+    return ptr(t), 1, 0
+
+
 def lstm_gates_fwd(ccx, rows, cch, c_prev, h, c, gates, B, hid, S):
-    call("agl_lstm_gates_fwd", ptr(ccx), ptr(rows, torch.int64), ptr(cch), ptr(c_prev), ptr(h), ptr(c), ptr(gates),
-         B, hid, S, stream())
+    """cch: tensor, None, or the DeferredSum of the recurrence convolution (its slabs are added here)."""
+    a, n, st = _sum_args(cch)
+    call("agl_lstm_gates_fwd_sum", ptr(ccx), ptr(rows, torch.int64), a, n, st, ptr(c_prev), ptr(h), ptr(c), ptr(gates), B, hid, S, stream())
 
 
 def lstm_gates_bwd(dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S):
-    call("agl_lstm_gates_bwd", ptr(dh_a), ptr(dh_b), Bb, ptr(dc_next), Bc, ptr(gates), ptr(c_prev), ptr(c), ptr(dcc),
+    """dh_b: tensor, None, or the DeferredSum of the recurrence's input-gradient convolution."""
+    a, n, st = _sum_args(dh_b)
+    call("agl_lstm_gates_bwd_sum", ptr(dh_a), a, n, st, Bb, ptr(dc_next), Bc, ptr(gates), ptr(c_prev), ptr(c), ptr(dcc),
          ptr(dc_prev), B, hid, S, stream())
 
 

@@ -919,6 +919,25 @@ __global__ void flip_transpose_w(const float* __restrict__ t, float* __restrict_
   dw[i] = accumulate ? dw[i] + v : v;
 }
 
+// AGL_CONV_DEFER_SUM (include/agl.h): agl_conv2d_fwd / agl_conv2d_bwd_data arm this for the duration of the call; a reduction split
+// whose epilogue would only add the slabs (no bias, mask, accumulation, ReLU or divisor) then leaves them in the workspace for the
+// caller's next kernel to add in the same fixed order (agl_conv2d_deferred reports where they are) — one launch less per call.
+struct DeferredSum { bool armed; const float* slabs; int splits; long stride; };
+thread_local DeferredSum g_defer = {false, nullptr, 0, 0};
+struct DeferScope {
+  explicit DeferScope(int flags) {
+    g_defer.armed = (flags & (1 << 24)) != 0;      // AGL_CONV_DEFER_SUM
+    if (g_defer.armed) { g_defer.slabs = nullptr; g_defer.splits = 0; g_defer.stride = 0; }
+  }
+  ~DeferScope() { g_defer.armed = false; }
+};
+bool defer_split_sum(const float* slabs, long n, int splits, const float* bias, const float* pos_mask, int accumulate, int relu,
+                     const float* out_div) {
+  if (!g_defer.armed || splits < 2 || bias || pos_mask || accumulate || relu || out_div) return false;
+  g_defer.slabs = slabs; g_defer.splits = splits; g_defer.stride = n;
+  return true;
+}
+
 // out[o] = epilogue(sum_z part[z][o]); channel of o = (o / HW) % C
 __global__ void splitk_epilogue(const float* __restrict__ part, float* __restrict__ out, long n, int splits, int HW, int C,
                                 const float* __restrict__ bias, const float* __restrict__ pos_mask, int accumulate, int relu,
@@ -938,6 +957,7 @@ __global__ void splitk_epilogue(const float* __restrict__ part, float* __restric
 }  // namespace
 int agl_launch_splitk_epilogue(const float* slabs, float* out, long n, int splits, int HW, int C, const float* bias, const float* pos_mask,
                                int accumulate, int relu, hipStream_t st, const char* name, const float* out_div) {
+  if (defer_split_sum(slabs, n, splits, bias, pos_mask, accumulate, relu, out_div)) return AGL_OK;
   hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, splits, HW, C, bias, pos_mask, accumulate, relu,
                      out_div);
   AGL_CHECK_LAUNCH(name);
@@ -1467,7 +1487,7 @@ int try_patch_conv(PatchArgs& a, int ks, void* ws, long ws_bytes, hipStream_t st
 #undef AGL_PC2
 #undef AGL_PC
   AGL_CHECK_LAUNCH(name);
-  if (splits > 1) {
+  if (splits > 1 && !defer_split_sum((const float*)ws, out_numel, splits, a.bias, a.pos_mask, a.accumulate, a.relu, nullptr)) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, a.y, out_numel, splits,
                        a.OH * a.OW, a.Cout, a.bias, a.pos_mask, a.accumulate, a.relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH(name);
@@ -1587,8 +1607,15 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
 int agl_conv2d_fwd(const float* x, const float* w, const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws,
                    long ws_bytes, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int up_log2, int in_relu, int relu,
                    int accumulate, int flags, void* stream) {
+  const DeferScope defer(flags);
   return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, up_log2, in_relu, relu,
                          accumulate, flags, stream, nullptr, 0, nullptr);
+}
+
+int agl_conv2d_deferred(const float** slabs, int* splits, long long* stride) {
+  AGL_REQUIRE(slabs && splits && stride, "agl_conv2d_deferred: null pointer");
+  *slabs = g_defer.slabs; *splits = g_defer.splits; *stride = g_defer.stride;
+  return AGL_OK;
 }
 
 // Forward convolution that may also hand back the BatchNorm partial sums of its output (include/agl.h)
@@ -1604,12 +1631,13 @@ int agl_conv2d_fwd_stats(const float* x, const float* w, const void* packed_w, c
 long agl_conv2d_fwd_stats_floats(int N, int Cout, int OH, int OW) { return pconv_stat_rows_max(N, OH, OW) * Cout * 3; }
 
 // Forward convolution with the normalise-modulate of the BatchNorm that reads x folded into the input staging (include/agl.h):
-// y = conv(relu?((x - mean) * scale + shift)), zero padding after the transform; optionally the BatchNorm partial rows of y.
+// y = conv(relu?(fma(x, scale, shift))) with the tables of agl_norm_fold_table (shift = beta - mean * scale), zero padding after the
+// transform; optionally the BatchNorm partial rows of y.  in_mean is not read (it may be NULL): the tables carry the mean.
 int agl_conv2d_fwd_fold(const float* x, const float* in_mean, const float* in_scale, const float* in_shift, int in_per_n, const float* w,
                         const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin,
                         int H, int W, int Cout, int ks, int stride, int pad, int in_relu, int flags, float* stats, long stats_floats,
                         int* stat_rows, void* stream) {
-  AGL_REQUIRE(in_mean && in_scale && in_shift, "agl_conv2d_fwd_fold: null table");
+  AGL_REQUIRE(in_scale && in_shift, "agl_conv2d_fwd_fold: null table");
   AGL_REQUIRE((stats == nullptr) == (stat_rows == nullptr), "agl_conv2d_fwd_fold: stats and stat_rows go together");
   if (stat_rows) *stat_rows = 0;
   const InFold f{in_mean, in_scale, in_shift, in_per_n};
@@ -1772,7 +1800,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const void* packed_w,
   switch (ks) { AGL_FWD(1) AGL_FWD(3) AGL_FWD(4) AGL_FWD(5) AGL_FWD(7) }
 #undef AGL_FWD
   if (rc != AGL_OK) return rc;
-  if (splits > 1) {
+  if (splits > 1 && !defer_split_sum((const float*)ws, out_numel, splits, bias, nullptr, accumulate, relu, nullptr)) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, y, out_numel, splits,
                        OH * OW, Cout, bias, (const float*)nullptr, accumulate, relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH("agl_conv2d_fwd(split-K epilogue)");
@@ -1821,6 +1849,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
                         const float* pos_mask, float* dx, void* ws, long ws_bytes, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
                         int ks, int stride, int pad, int relu, int accumulate, int flags, void* stream) {
   AGL_REQUIRE(dy && (w || packed_w) && dx, "agl_conv2d_bwd_data: null pointer");
+  const DeferScope defer(flags);
   g_last_pipe = 0;
   const ConvOpts co = conv_opts(flags);
   AGL_REQUIRE(ks_ok(ks) && ((stride == 1) || (stride == 2 && (ks == 4 || ks == 3))), "agl_conv2d_bwd_data: unsupported ks=%d stride=%d", ks, stride);
@@ -1954,7 +1983,7 @@ int agl_conv2d_bwd_data(const float* dy, const float* w, const void* packed_w, c
   }
 #undef AGL_BWD
   if (rc != AGL_OK) return rc;
-  if (splits > 1) {
+  if (splits > 1 && !defer_split_sum((const float*)ws, out_numel, splits, bias, pos_mask, accumulate, relu, nullptr)) {
     hipLaunchKernelGGL(splitk_epilogue, dim3(agl_cdiv(out_numel, 256)), dim3(256), 0, st, (const float*)ws, dx, out_numel, splits,
                        IH * IW, Cin, bias, pos_mask, accumulate, relu, (const float*)nullptr);
     AGL_CHECK_LAUNCH("agl_conv2d_bwd_data(split-K epilogue)");
@@ -2148,7 +2177,7 @@ int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_
                                int in_per_n, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N,
                                int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate,
                                int flags, void* stream) {
-  AGL_REQUIRE(in_mean && in_scale && in_shift, "agl_conv2d_bwd_weight_fold: null table");
+  AGL_REQUIRE(in_scale && in_shift, "agl_conv2d_bwd_weight_fold: null table");
   const InFold f{in_mean, in_scale, in_shift, in_per_n};
   return conv2d_bwd_weight_impl(dy, x, dw, dbias, dbias_accumulate, dbias_done, ws, ws_bytes, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, 0,
                                 in_relu, accumulate, flags, stream, &f);

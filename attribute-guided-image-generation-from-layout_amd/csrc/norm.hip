@@ -846,7 +846,7 @@ int agl_norm_bwd_y16(const float* dy, const float* x, const void* y_bf16, const 
 }
 
 // Backward of a FOLDED normalise-modulate(+ReLU) (agl_norm_fold_table + agl_conv2d_fwd_fold): dy is the gradient with respect to the
-// never-stored activation y = relu?(fmaf(x - mean, scale, shift)); the ReLU mask is recomputed from x and the tables.  Modes 0-2.
+// never-stored activation y = relu?(fmaf(x, scale, shift)), shift = beta - mean * scale (include/agl.h); the ReLU mask is recomputed from x and the tables.  Modes 0-2.
 int agl_norm_bwd_fold(const float* dy, const float* x, const float* mean, const float* rstd, const float* fold_scale, const float* fold_shift,
                       int fold_per_n, int mode, const float* p0, const float* p1, const long long* labels, int relu, int batch_stats,
                       float* dx, float* dp0, float* dp1, int N, int C, int HW, int n_classes, int param_accumulate, void* ws, long ws_bytes,

@@ -167,9 +167,18 @@ __global__ void crop_bwd_sorted(const float* __restrict__ dout, const float* __r
 // ---------------------------------------------------------------- ConvLSTM gates (i, f, o, g order)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// cch / dh_b may be `splits` partial outputs `stride` floats apart (the unreduced slabs of a convolution called with AGL_CONV_DEFER_SUM):
+// they are added first, slab 0 upwards from 0.f — the order and association of the split-K epilogue, so the sums are the same numbers
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, long o, int splits, long stride) {
+  if (splits <= 1) return p[o];
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += p[(long)z * stride + o];
+  return v;
+}
+
 __global__ void lstm_gates_fwd(const float* __restrict__ ccx, const long long* __restrict__ rows, const float* __restrict__ cch,
                                const float* __restrict__ c_prev, float* __restrict__ h, float* __restrict__ c,
-                               float* __restrict__ gates, int B, int hid, int S) {
+                               float* __restrict__ gates, int B, int hid, int S, int splits, long stride) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   const long total = (long)B * hid * S;
   if (idx >= total) return;
@@ -183,7 +192,7 @@ __global__ void lstm_gates_fwd(const float* __restrict__ ccx, const long long* _
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const long o = (long)(q * hid + ch) * S + s;
-    pre[q] = ccx[src + o] + (cch ? cch[loc + o] : 0.f);
+    pre[q] = ccx[src + o] + (cch ? slab_sum(cch, loc + o, splits, stride) : 0.f);
   }
   const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), go = sigmoidf_(pre[2]), gg = tanhf(pre[3]);
   const float cp = c_prev ? c_prev[idx] : 0.f;
@@ -200,7 +209,7 @@ __global__ void lstm_gates_fwd(const float* __restrict__ ccx, const long long* _
 __global__ void lstm_gates_bwd(const float* __restrict__ dh_a, const float* __restrict__ dh_b, int Bb,
                                const float* __restrict__ dc_next, int Bc, const float* __restrict__ gates,
                                const float* __restrict__ c_prev, const float* __restrict__ c, float* __restrict__ dcc,
-                               float* __restrict__ dc_prev, int B, int hid, int S) {
+                               float* __restrict__ dc_prev, int B, int hid, int S, int splits, long stride) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   const long total = (long)B * hid * S;
   if (idx >= total) return;
@@ -212,7 +221,7 @@ __global__ void lstm_gates_bwd(const float* __restrict__ dh_a, const float* __re
   const float gi = gates[loc + (long)(0 * hid + ch) * S + s], gf = gates[loc + (long)(1 * hid + ch) * S + s];
   const float go = gates[loc + (long)(2 * hid + ch) * S + s], gg = gates[loc + (long)(3 * hid + ch) * S + s];
   float dh = dh_a ? dh_a[idx] : 0.f;
-  if (dh_b && b < Bb) dh += dh_b[idx];
+  if (dh_b && b < Bb) dh += slab_sum(dh_b, idx, splits, stride);
   const float tc = tanhf(c[idx]);
   float dc = dh * go * (1.f - tc * tc);
   if (dc_next && b < Bc) dc += dc_next[idx];
@@ -913,21 +922,35 @@ int agl_crop_bwd_sorted(const float* dout, const float* boxes, const long long* 
   return AGL_OK;
 }
 
+int agl_lstm_gates_fwd_sum(const float* ccx, const long long* rows, const float* cch, int cch_splits, long long cch_stride,
+                           const float* c_prev, float* h, float* c, float* gates, int B, int hid, int S, void* stream) {
+  AGL_REQUIRE(ccx && h && c && gates && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_fwd: bad argument");
+  AGL_REQUIRE(cch_splits <= 1 || (cch && cch_stride >= (long long)B * 4 * hid * S), "agl_lstm_gates_fwd: slabs shorter than the gate tensor");
+  LAUNCH1D(lstm_gates_fwd, (long)B * hid * S, ccx, rows, cch, c_prev, h, c, gates, B, hid, S, cch_splits, (long)cch_stride);
+  AGL_CHECK_LAUNCH("agl_lstm_gates_fwd");
+  return AGL_OK;
+}
+
 int agl_lstm_gates_fwd(const float* ccx, const long long* rows, const float* cch, const float* c_prev, float* h, float* c,
                        float* gates, int B, int hid, int S, void* stream) {
-  AGL_REQUIRE(ccx && h && c && gates && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_fwd: bad argument");
-  LAUNCH1D(lstm_gates_fwd, (long)B * hid * S, ccx, rows, cch, c_prev, h, c, gates, B, hid, S);
-  AGL_CHECK_LAUNCH("agl_lstm_gates_fwd");
+  return agl_lstm_gates_fwd_sum(ccx, rows, cch, 1, 0, c_prev, h, c, gates, B, hid, S, stream);
+}
+
+int agl_lstm_gates_bwd_sum(const float* dh_a, const float* dh_b, int dh_b_splits, long long dh_b_stride, int Bb, const float* dc_next, int Bc,
+                           const float* gates, const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S,
+                           void* stream) {
+  AGL_REQUIRE(gates && c && dcc && dc_prev && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_bwd: bad argument");
+  AGL_REQUIRE(Bb <= B && Bc <= B, "agl_lstm_gates_bwd: prefix larger than batch");
+  AGL_REQUIRE(dh_b_splits <= 1 || (dh_b && dh_b_stride >= (long long)Bb * hid * S), "agl_lstm_gates_bwd: slabs shorter than the prefix");
+  LAUNCH1D(lstm_gates_bwd, (long)B * hid * S, dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S, dh_b_splits,
+           (long)dh_b_stride);
+  AGL_CHECK_LAUNCH("agl_lstm_gates_bwd");
   return AGL_OK;
 }
 
 int agl_lstm_gates_bwd(const float* dh_a, const float* dh_b, int Bb, const float* dc_next, int Bc, const float* gates,
                        const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S, void* stream) {
-  AGL_REQUIRE(gates && c && dcc && dc_prev && B > 0 && hid > 0 && S > 0, "agl_lstm_gates_bwd: bad argument");
-  AGL_REQUIRE(Bb <= B && Bc <= B, "agl_lstm_gates_bwd: prefix larger than batch");
-  LAUNCH1D(lstm_gates_bwd, (long)B * hid * S, dh_a, dh_b, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S);
-  AGL_CHECK_LAUNCH("agl_lstm_gates_bwd");
-  return AGL_OK;
+  return agl_lstm_gates_bwd_sum(dh_a, dh_b, 1, 0, Bb, dc_next, Bc, gates, c_prev, c, dcc, dc_prev, B, hid, S, stream);
 }
 
 int agl_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 /* ABI version: bumped with every signature change; the Python binding refuses to bind a library of another version. */
-#define AGL_ABI_VERSION 7
+#define AGL_ABI_VERSION 8
 int agl_version(void);
 const char* agl_last_error(void);
 
@@ -148,6 +148,14 @@ int agl_conv2d_fwd_takes_bf16_x(int N, int Cin, int H, int W, int Cout, int ks, 
 #define AGL_CONV_Y_BLOCKED (1 << 22)
 #define AGL_CONV_MASK_BLOCKED (1 << 23)
 #define AGL_CONV_BLOCKED (AGL_CONV_X_BLOCKED | AGL_CONV_Y_BLOCKED)
+/* agl_conv2d_fwd / agl_conv2d_bwd_data with AGL_CONV_DEFER_SUM: when the kernel that runs cuts the reduction over workgroups (small
+ * output grids: the recurrence steps of LayoutConvLSTM, generator_obj_att.py:99-104, :306-331) and the call has nothing but the sum left
+ * to do (no bias, mask, accumulation, ReLU, divisor), the partial outputs are LEFT in ws and y / dx is NOT written: the caller's next
+ * kernel on the same stream adds them itself (agl_lstm_gates_fwd_sum / _bwd_sum, in the epilogue's own order: identical numbers),
+ * one launch less per step.  agl_conv2d_deferred reports, for the calling thread's last such call: splits >= 2, the first slab and the
+ * distance between slabs in floats — or splits = 0 when the call wrote y / dx as usual.  The slabs live until ws is used again. */
+#define AGL_CONV_DEFER_SUM (1 << 24)
+int agl_conv2d_deferred(const float** slabs, int* splits, long long* stride);
 int agl_conv2d_fwd_takes_blocked(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
 /* NCHW fp32 (x_bf16 = 0) or bf16 (1) -> channel-blocked bf16; avg_pool2(relu?(x)) of a blocked x into an fp32 NCHW y (the shortcut's pool,
  * discriminator.py:58-60, :97-99); the backward of that pool with the ReLU mask read from the blocked x (dy, dx fp32 NCHW). */
@@ -165,7 +173,10 @@ int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, 
  * applies v = fma(x, scale[r][c], shift[r][c]) (then the ReLU, then the zero padding) while it stages its input patch — forms of
  * the matrix-core patch kernel (agl_conv2d_fwd_fold_ok), optionally leaving the BatchNorm partial rows of its own output like
  * agl_conv2d_fwd_stats; agl_conv2d_bwd_weight_fold applies the same transform to the raw x in the weight gradient; agl_norm_bwd_fold
- * is agl_norm_bwd for a y that does not exist: the ReLU mask is recomputed from x with the staging pass's expression. */
+ * is agl_norm_bwd for a y that does not exist: the ReLU mask is recomputed from x with the staging pass's expression.
+ * in_mean is NOT read by either convolution entry (NULL is accepted): the tables already carry the mean.  The fp32 shift re-admits an
+ * error of about |mean|/std * 2^-24 per element that the two-pass (x - mean) * rstd form does not have — three orders below the bf16
+ * operand rounding of the forms that accept a fold (tests/test_ops_gpu.py holds it to that bar at |mean|/std = 100). */
 int agl_norm_fold_table(const float* mean, const float* rstd, int mode, const float* p0, const float* p1, const long long* labels, int N, int C,
                         float* scale, float* shift, void* stream);
 int agl_conv2d_fwd_fold_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
@@ -289,6 +300,12 @@ int agl_lstm_gates_fwd(const float* ccx, const long long* rows, const float* cch
 int agl_lstm_gates_bwd(const float* dh_a, const float* dh_b, int Bb, const float* dc_next, int Bc, const float* gates,
                        const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S,
                        void* stream);
+/* the same with cch / dh_b given as `splits` unreduced partial outputs `stride` floats apart (AGL_CONV_DEFER_SUM; splits <= 1: one tensor) */
+int agl_lstm_gates_fwd_sum(const float* ccx, const long long* rows, const float* cch, int cch_splits, long long cch_stride,
+                           const float* c_prev, float* h, float* c, float* gates, int B, int hid, int S, void* stream);
+int agl_lstm_gates_bwd_sum(const float* dh_a, const float* dh_b, int dh_b_splits, long long dh_b_stride, int Bb, const float* dc_next, int Bc,
+                           const float* gates, const float* c_prev, const float* c, float* dcc, float* dc_prev, int B, int hid, int S,
+                           void* stream);
 
 /* ---- small data movement / reductions ------------------------------------------------------------ */
 int agl_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream);

@@ -313,6 +313,52 @@ def test_convlstm_matches_reference_fixture(golden_dir):
     close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
 
 
+@pytest.mark.parametrize("mode", ["f32", "split3", "bf16"])
+def test_convlstm_gate_kernels_adding_the_recurrence_convolutions_partial_sums(mode):
+    """AGL_CONV_DEFER_SUM (include/agl.h): the recurrence convolutions of LayoutConvLSTM (generator_obj_att.py:99-104, :306-331) cut
+    their reduction over workgroups on the few images still active at a step; with the flag the partial outputs stay in the workspace
+    and the gate kernel that follows adds them (agl_lstm_gates_fwd_sum / _bwd_sum) in the epilogue's own order.  At the extents of the
+    64 px model (512 -> 128 -> 64 -> 64 hidden channels on 8x8 maps, sequences of 1..7 objects): output and every gradient
+    BIT-identical to the schedule with the epilogue launches, in all three arithmetics, and at least one launch less per
+    recurrence step overall."""
+    from agl import convlstm as CL
+    from agl import lib as L
+    from agl.generator import LayoutConvLSTM
+    torch.manual_seed(5)
+    m = LayoutConvLSTM(8, 512, [128, 64, 64], (5, 5)).to(DEV)
+    lens = [7, 3, 5, 1, 4, 6, 2, 5, 3]
+    o2i = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lens)])
+    x = rn(int(o2i.numel()), 512, 8, 8)
+    gy = rn(len(lens), 64, 8, 8, seed=9)
+    flags = {"f32": 0, "split3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[mode]
+    res, deferred = [], []
+    seen = []
+    orig = L.DeferredSum.__init__
+
+    def spy(self, out, ws):
+        orig(self, out, ws)
+        seen.append(self.splits)
+    for on in (True, False):
+        prev, CL.DEFER_SUM = CL.DEFER_SUM, on
+        L.DeferredSum.__init__ = spy
+        del seen[:]
+        try:
+            m.zero_grad(set_to_none=True)
+            xd = dev(x).requires_grad_(True)
+            with L.conv_flags(flags):
+                y = m(xd, o2i)
+                y.backward(dev(gy))
+            torch.cuda.synchronize()
+        finally:
+            CL.DEFER_SUM = prev
+            L.DeferredSum.__init__ = orig
+        deferred.append(sum(1 for v in seen if v >= 2))
+        res.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    assert deferred[1] == 0 and deferred[0] >= 6, ("recurrence convolutions that left their slabs to the gate kernel", deferred)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), ("tensor", i, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[8]])
 def test_conv2d_bf16_operand_mode(case):
     """bf16 MFMA mode (BASELINE configs 3/5): operands are the RNE bf16 roundings of the fp32 tensors, accumulation is
@@ -784,6 +830,42 @@ def test_norm_folded_into_the_consuming_convolution(case, mode):
         m1, r1 = L.bn_stats_from_partials(stats[2], stats[3], Cout, y.numel() // Cout, 1e-5, 0.1)
         m2, r2 = L.bn_stats(y, 1e-5, 0.1)
         close(m1, m2, 2e-6, "partials of the folded call: mean"); close(r1, r2, 2e-5, "partials of the folded call: rstd")
+
+
+def test_folded_norm_at_a_mean_a_hundred_standard_deviations_out():
+    """The fold's tables are fp32 (include/agl.h: shift = beta - mean * scale formed in double, rounded once), so v = fma(x, scale, shift)
+    cancels two numbers of size |mean|/std against each other where the two-pass form subtracts first.  At |mean|/std = 100 that is an
+    error of about 100 * 2^-24 = 6e-6 of a standard deviation per staged element: held here, in the exact (split) arithmetic where nothing
+    else hides it, against a float64 restatement of BatchNorm -> ReLU -> conv — the folded output within 1e-4 of max|y| and within 8x
+    the two-pass form's own distance (which has the fp32 mean's rounding in it too)."""
+    from agl import functional as F
+    from agl import lib as L
+    from agl import nn as A
+    N, Cin, H, Cout = 6, 64, 16, 128
+    torch.manual_seed(11)
+    norm = A.BatchNorm2d(Cin, affine=True)
+    norm.weight.data = 1.0 + 0.3 * torch.randn(Cin)
+    norm.bias.data = 0.2 * torch.randn(Cin)
+    conv = A.Conv2d(Cin, Cout, kernel_size=4, stride=2, padding=1, bias=True)
+    x = rn(N, Cin, H, H) + 100.0 * (1.0 + 0.1 * torch.randn(1, Cin, 1, 1))
+    xd64 = x.double()
+    mean = xd64.mean((0, 2, 3), keepdim=True)
+    var = xd64.var((0, 2, 3), unbiased=False, keepdim=True)
+    h = (xd64 - mean) / (var + 1e-5).sqrt() * norm.weight.double().view(1, -1, 1, 1) + norm.bias.double().view(1, -1, 1, 1)
+    ref = TF.conv2d(torch.relu(h), conv.weight.double(), conv.bias.double(), 2, 1)
+    out = {}
+    for folded in (True, False):
+        nd, cd = __import__("copy").deepcopy(norm).to(DEV), __import__("copy").deepcopy(conv).to(DEV)
+        prev, F.NORM_FOLD = F.NORM_FOLD, folded
+        try:
+            with L.conv_flags(L.CONV_SPLIT3 | L.CONV_ANY_GRID), torch.no_grad():
+                out[folded] = F.norm_conv2d(dev(x), nd, None, cd, relu=True, training=True).double().cpu()
+        finally:
+            F.NORM_FOLD = prev
+    scale = float(ref.abs().max())
+    e_fold, e_two = float((out[True] - ref).abs().max()) / scale, float((out[False] - ref).abs().max()) / scale
+    assert e_two <= 3e-5, ("two passes at mean/std = 100", e_two)
+    assert e_fold <= 1e-4 and e_fold <= 8 * max(e_two, 5e-6), ("folded at mean/std = 100", e_fold, e_two)
 
 
 @pytest.mark.parametrize("consumer", ["convT", "conv5", "conv3"])
