@@ -497,6 +497,69 @@ class _SpadeThenConv(torch.autograd.Function):
         return dx, dgb, None, None, None, None, None, None, dw, db, None, None, None
 
 
+class _SpadeFoldConv(torch.autograd.Function):
+    """conv(relu?(SPADE(x))) with SPADE's normalise-modulate(+ReLU) applied by the convolution's own staging pass (include/agl.h
+    agl_conv2d_fwd_spade; BASELINE north_star "SPADE normalization fused with the following conv"): the modulated tensor of
+    normalization.py:97,106 is never written — the forward, the weight gradient and the backward's ReLU mask each evaluate
+    csrc/spade.h's expression on the raw x.  Taken where gamma|beta live on a class grid much smaller than the map (the 128 px
+    decoder's spade_4 -> c6, spade_5 -> c7, generator_obj_att128.py:588-597) in bf16 arithmetic; bit-identical to _SpadeThenConv."""
+
+    @staticmethod
+    def forward(ctx, x, gb, rmean, rvar, nbt, relu, training, gather, w, bias, stride, pad):
+        global _LAST_STATS
+        ctx.wslots = (_slot(w), _slot(bias))
+        ctx.wsrc = wsrc = getattr(w, "_agl_wsrc", None)
+        x, gb, w = _c(x), _c(gb), _c(w)
+        mean, rstd = _batch_statistics(x, rmean, rvar, nbt, training)
+        sp = L.SpadeFold(mean, rstd, gb, gather[0])
+        _LAST_STATS = None
+        out, part, rows = L.conv2d_fwd_spade(x, sp, w, bias, stride, pad, in_relu=relu, wsrc=wsrc, want_stats=EMIT_STATS)
+        if part is not None:
+            _LAST_STATS = (out, out._version, part, rows)
+        ctx.cfg = (relu, training, gather, stride, pad, bias is not None)
+        ctx.save_for_backward(x, mean, rstd, gb, w, sp.cells)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        relu, training, gather, stride, pad, has_bias = ctx.cfg
+        x, mean, rstd, gb, w, cells = ctx.saved_tensors
+        dout = _c(dout)
+        need = ctx.needs_input_grad
+        dx = dgb = dw = db = None
+        sp = L.SpadeFold.__new__(L.SpadeFold)
+        sp.mean, sp.rstd, sp.cells, sp.map, sp.G = mean, rstd, cells, gather[0], gb.shape[-1]
+        ks = w.shape[2]
+        g = L.conv2d_bwd_data(dout, w, (x.shape[2], x.shape[3]), stride, pad, wsrc=ctx.wsrc) if (need[0] or need[1]) else None
+        wslot, bslot = ctx.wslots
+        want_b = has_bias and need[9]
+        if need[8]:
+            if wslot is not None:
+                fuse_b = want_b and bslot is not None
+                L.on_wgrad_stream(lambda: L.conv2d_bwd_weight_spade(dout, x, sp, ks, stride, pad, relu, out=wslot, accumulate=True,
+                                                                    dbias=bslot if fuse_b else None), dout, x)
+            else:
+                fuse_b = want_b
+                if fuse_b and bslot is None:
+                    db = torch.empty(w.shape[0], dtype=torch.float32, device=dout.device)
+                dw = L.conv2d_bwd_weight_spade(dout, x, sp, ks, stride, pad, relu, dbias=(bslot if bslot is not None else db) if fuse_b else None,
+                                               dbias_accumulate=bslot is not None)
+            want_b = want_b and not fuse_b
+        if want_b:
+            if bslot is not None:
+                L.channel_sum(dout, out=bslot, accumulate=True)
+            else:
+                db = L.channel_sum(dout)
+        if g is not None:
+            dgb = torch.empty_like(gb)
+            dx = L.norm_bwd_spade(g, x, mean, rstd, gb, relu, training, dgb, gb_map=gather[0], gb_lo=gather[1])
+        return dx, dgb, None, None, None, None, None, None, dw, db, None, None
+
+
+# Off by default: measured SLOWER at config 3 (profiles/r05_ab_spade_fold.txt: +1.8 ms of 124.6 ms serial kernel time, 288-290 against
+# 291-296 images/s) — the apply pass it removes costs 0.74 ms, while the consumers' staging passes, which are bound by load issue, pay
+# 8 four-byte + 4 sixteen-byte loads per 8-channel item in place of 8 two-byte loads, un-prefetched in the two weight-gradient kernels.
+SPADE_FOLD = False     # True: SPADE's modulate + ReLU applied by the staging pass of the convolution that reads it (_SpadeFoldConv)
 SPADE_Y16 = os.environ.get("AGL_SPADE_Y16", "1") != "0"      # A/B switch: 0 keeps the modulated tensors in fp32 in bf16 arithmetic
 
 
@@ -516,6 +579,11 @@ def spade_modulate_then(x, gb, rmean, rvar, nbt, relu, training, gather, consume
         kind, stride, pad, bias = "convT", 2, 1, None
     else:
         ks, stride, pad, bias = consumer.kernel_size[0], consumer.stride[0], consumer.padding[0], consumer.bias
+        # the modulation applied by the consumer itself: where gamma|beta's class grid is small against the map (its cell table is
+        # read in place of a second copy of the activation) and the row pass of the backward reduces to that grid (64 / 128 wide maps)
+        if (SPADE_FOLD and g is not None and W in (64, 128) and H == W and 4 * gb.shape[-1] ** 2 <= H * W
+                and L.conv_spade_ok(N, Cc, H, W, w.shape[0], ks, stride, pad, need_bww=w.requires_grad)):
+            return _SpadeFoldConv.apply(x, gb, rmean, rvar, nbt, relu, training, g, w, bias, stride, pad)
         ok = SPADE_Y16 and L.norm_output_as_bf16(N, Cc, H, W, "conv", w.shape[0], ks, stride, pad, need_bww=w.requires_grad)
         kind = "conv"
     if ok:

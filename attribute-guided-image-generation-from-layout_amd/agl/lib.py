@@ -60,6 +60,12 @@ SIGNATURES = {
     "agl_lstm_gates_fwd_sum": (_I, [_P, _P, _P, _I, _LL, _P, _P, _P, _P, _I, _I, _I, _P]),
     "agl_lstm_gates_bwd_sum": (_I, [_P, _P, _I, _LL, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "agl_conv2d_deferred": (_I, [_P, _P, _P]),
+    "agl_spade_cells": (_I, [_P, _I, _I, _I, _P, _P]),
+    "agl_conv2d_fwd_spade": (_I, [_P] * 5 + [_I] + [_P] * 6 + [_L] + [_I] * 10 + [_P, _L, _P, _P]),
+    "agl_conv2d_fwd_spade_ok": (_I, [_I] * 9),
+    "agl_conv2d_bwd_weight_spade": (_I, [_P] * 6 + [_I, _P, _P, _I, _P, _P, _L] + [_I] * 13 + [_P]),
+    "agl_conv2d_bwd_weight_spade_ok": (_I, [_I] * 11),
+    "agl_norm_bwd_spade": (_I, [_P] * 5 + [_I, _I, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _L, _P]),
     "agl_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
     "agl_axpby": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "agl_gather_rows": (_I, [_P, _P, _P, _L, _L, _I, _P]),
@@ -816,6 +822,90 @@ def conv2d_bwd_weight_fold(dy, x, fold, ks, stride=1, pad=0, in_relu=False, out=
     if dbias is not None and not done.value:
         channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
     return out
+
+
+# ---- SPADE applied by its consumer's staging pass (include/agl.h: agl_spade_cells, agl_conv2d_fwd_spade, ...)
+class SpadeFold:
+    """Operands of a SPADE modulation applied inside the convolution that reads it: per-channel batch mean / rstd, the blocked cell
+    table of (1 + gamma | beta) (agl_spade_cells) and the pixel -> class-grid map."""
+    __slots__ = ("mean", "rstd", "cells", "map", "G")
+
+    def __init__(self, mean, rstd, gb, gmap):
+        N, C2, G, G2 = gb.shape
+        assert G == G2 and C2 % 16 == 0 and gmap.dtype == torch.int32
+        cells = torch.empty((N, C2 // 16, G * G, 16), dtype=torch.float32, device=gb.device)
+        call("agl_spade_cells", ptr(gb), N, C2 // 2, G, ptr(cells), stream())
+        self.mean, self.rstd, self.cells, self.map, self.G = mean, rstd, cells, gmap, G
+
+
+def conv_spade_ok(N, Cin, H, W, Cout, ks, stride, pad, need_bww=True):
+    """True when conv(relu?(SPADE(x))) runs with the modulation applied while the convolution stages x (forward and weight gradient):
+    bf16 arithmetic, the 5x5 and the few-output-channel 7x7 forms."""
+    if not (CONV_FLAGS & CONV_BF16) or (CONV_FLAGS & CONV_NO_PATCH):
+        return False
+    lib = load()
+    if not lib.agl_conv2d_fwd_spade_ok(N, Cin, H, W, Cout, ks, stride, pad, CONV_FLAGS):
+        return False
+    return (not need_bww) or bool(lib.agl_conv2d_bwd_weight_spade_ok(N, Cin, H, W, Cout, H, W, ks, stride, pad, CONV_FLAGS))
+
+
+def conv2d_fwd_spade(x, sp, w, bias=None, stride=1, pad=0, in_relu=False, wsrc=None, want_stats=False):
+    """conv(relu?(SPADE(x))) -> (y, BatchNorm partial rows of y or None, row count)."""
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, ks, _ = w.shape
+    assert Cin_w == Cin and sp.map.numel() == H == W
+    OH, OW = conv_out_size(H, ks, stride, pad), conv_out_size(W, ks, stride, pad)
+    out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    need = load().agl_conv2d_fwd_ws_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0)
+    ws = workspace(need, x.device) if need else None
+    pk, pdiv = _fwd_pack(wsrc, w, N, Cin, H, W, Cout, ks, stride, pad, 0) if Cout > 4 else (None, None)
+    stats = rows = None
+    nst = 0
+    if want_stats and Cout > 4:
+        nst = load().agl_conv2d_fwd_stats_floats(N, Cout, OH, OW)
+        stats = torch.empty(nst, dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+    call("agl_conv2d_fwd_spade", ptr(x), ptr(sp.mean), ptr(sp.rstd), ptr(sp.cells), ptr(sp.map, torch.int32), sp.G, ptr(w),
+         pk.data_ptr() if pk is not None else None, ptr(pdiv), ptr(bias), ptr(out), ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, ks, stride, pad, int(in_relu), CONV_FLAGS,
+         stats.data_ptr() if stats is not None else None, nst, C.addressof(rows) if rows is not None else None, stream())
+    if rows is not None and rows.value > 0:
+        return out, stats, rows.value
+    return out, None, 0
+
+
+def conv2d_bwd_weight_spade(dy, x, sp, ks, stride=1, pad=0, in_relu=False, out=None, accumulate=False, dbias=None, dbias_accumulate=None):
+    if dbias_accumulate is None:
+        dbias_accumulate = accumulate
+    N, Cout, OH, OW = dy.shape
+    _, Cin, H, W = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dy.device)
+    need = load().agl_conv2d_bwd_weight_ws_bytes(N, Cin, Cout, ks, OH, OW)
+    if accumulate:
+        need = max(need, Cout * Cin * ks * ks * 4)
+    ws = workspace(need, dy.device) if need else None
+    done = C.c_int(0)
+    call("agl_conv2d_bwd_weight_spade", ptr(dy), ptr(x), ptr(sp.mean), ptr(sp.rstd), ptr(sp.cells), ptr(sp.map, torch.int32), sp.G, ptr(out),
+         ptr(dbias), int(dbias_accumulate), C.addressof(done) if dbias is not None else None, ws.data_ptr() if ws is not None else None,
+         ws.numel() if ws is not None else 0, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, int(in_relu), int(accumulate), CONV_FLAGS, stream())
+    if dbias is not None and not done.value:
+        channel_sum(dy, out=dbias, accumulate=dbias_accumulate)
+    return out
+
+
+def norm_bwd_spade(dy, x, mean, rstd, gb, relu, batch_stats, dgb, gb_map=None, gb_lo=None):
+    """Backward of SPADE's modulate(+ReLU) whose output was never stored (the consumer applied it): the mask is recomputed."""
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    nb = load().agl_norm_bwd_ws_bytes(N, Cc)
+    ws = workspace(nb, x.device)
+    call("agl_norm_bwd_spade", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gb), int(relu), int(batch_stats), ptr(dx), ptr(dgb), N, Cc, HW,
+         ptr(gb_map, torch.int32), ptr(gb_lo, torch.int32), x.shape[-1] if gb_map is not None else 0,
+         gb.shape[-1] if gb_map is not None else 0, ws.data_ptr(), ws.numel(), stream())
+    return dx
 
 
 def norm_bwd_fold(dy, x, mean, rstd, fold, mode, p0, p1, labels, relu, batch_stats, dp0=None, dp1=None, param_accumulate=False):

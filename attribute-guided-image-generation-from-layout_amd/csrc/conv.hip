@@ -1648,6 +1648,36 @@ int agl_conv2d_fwd_fold_ok(int N, int Cin, int H, int W, int Cout, int ks, int s
   if (!(ks == 4 && stride == 2)) return 0;      // (the transform is compiled into the 4x4 / stride-2 instantiations of the patch kernel)
   return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
 }
+int agl_conv2d_fwd_spade_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
+// y = conv(relu?(SPADE(x))) with SPADE's normalise-modulate (normalization.py:97,106) applied while the convolution stages x — the
+// 128 px decoder's spade_4 -> c6 (5x5) and spade_5 -> c7 (7x7 to 3 channels: vertical + diagonal form), generator_obj_att128.py:588-597,
+// in bf16 arithmetic.  cells / map / G: agl_spade_cells and the class-grid map of the modulation (include/agl.h).
+int agl_conv2d_fwd_spade(const float* x, const float* mean, const float* rstd, const float* cells, const int* map, int G, const float* w,
+                         const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin,
+                         int H, int W, int Cout, int ks, int stride, int pad, int in_relu, int flags, float* stats, long stats_floats,
+                         int* stat_rows, void* stream) {
+  AGL_REQUIRE(x && mean && rstd && cells && map && G > 0 && y && (w || packed_w), "agl_conv2d_fwd_spade: null pointer");
+  AGL_REQUIRE(agl_conv2d_fwd_spade_ok(N, Cin, H, W, Cout, ks, stride, pad, flags), "agl_conv2d_fwd_spade: a shape / arithmetic the folded forms do not take (ask agl_conv2d_fwd_spade_ok)");
+  if (stat_rows) *stat_rows = 0;
+  const InFold f{mean, rstd, nullptr, 0, cells, map, G};
+  if (Cout <= 4) {
+    AGL_REQUIRE(w, "agl_conv2d_fwd_spade: the vertical form packs w itself");
+    PVertArgs v{x, w, bias, nullptr, y, N, Cin, H, W, Cout, ks, pad, Cin * ks * ks, ks * ks, 0, 0, 0, 1, 0, f, in_relu};
+    const int vrc = pconv_vert_try(v, ws, ws_bytes, (hipStream_t)stream, "agl_conv2d_fwd_spade(vertical + diagonal)");
+    AGL_REQUIRE(vrc >= 0, "agl_conv2d_fwd_spade: the vertical form did not take the shape (workspace?)");
+    g_last_pipe = 1;
+    return vrc;
+  }
+  return conv2d_fwd_impl(x, w, packed_w, packed_div, bias, y, ws, ws_bytes, N, Cin, H, W, Cout, ks, stride, pad, 0, in_relu, 0, 0, flags, stream,
+                         stats, stats_floats, stat_rows, &f);
+}
+int agl_conv2d_fwd_spade_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || stride != 1 || 2 * pad != ks - 1 || Cin % 16 != 0) return 0;
+  if (Cout <= 4) return pconv_vert_ws_bytes(N, Cin, H, W, Cout, ks, 1) > 0 ? 1 : 0;
+  if (ks != 5) return 0;      // (the transform is compiled into the bf16 5x5 instantiations of the patch kernel)
+  return agl_conv2d_fwd_packed_bytes(N, Cin, H, W, Cout, ks, stride, pad, 0, flags) > 0 ? 1 : 0;
+}
 // y = conv(x) + addend (+ bias, output ReLU), written out of place — as bf16 with AGL_CONV_Y_BF16: the sum is formed in fp32 and rounded
 // once.  The shortcut of a discriminator block (discriminator.py:58-60, :97-99) whose sum only convolutions read afterwards.
 // y = conv(x) + bias + [1x1 shortcut of a few-channel tensor: sc_b[m] + sum_c sc_w[m][c] * sc_x[n][c][pixel]] (+ output ReLU), the shortcut
@@ -2189,6 +2219,49 @@ int agl_conv2d_bwd_weight_fold_ok(int N, int Cin, int H, int W, int Cout, int OH
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad;
   a.nsplit = co.prec == 1 ? 1 : 3;
   return pbww_ws_bytes(a) > 0 ? 1 : 0;
+}
+int agl_conv2d_bwd_weight_spade_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+// Weight gradient of a convolution whose input is relu?(SPADE(x)) applied while x is staged (agl_conv2d_fwd_spade's partner).  Few output
+// channels (c7): the role swap of agl_conv2d_bwd_weight, the modulated tensor in the few-channel kernel's dy role, rounded to bf16 as
+// the stored tensor would be; the bias gradient is left to the caller (*dbias_done stays 0) as there.
+int agl_conv2d_bwd_weight_spade(const float* dy, const float* x, const float* mean, const float* rstd, const float* cells, const int* map, int G,
+                                float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N, int Cin, int H,
+                                int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate, int flags,
+                                void* stream) {
+  AGL_REQUIRE(dy && x && mean && rstd && cells && map && G > 0 && dw, "agl_conv2d_bwd_weight_spade: null pointer");
+  AGL_REQUIRE(agl_conv2d_bwd_weight_spade_ok(N, Cin, H, W, Cout, OH, OW, ks, stride, pad, flags),
+              "agl_conv2d_bwd_weight_spade: a shape / arithmetic the folded forms do not take (ask agl_conv2d_bwd_weight_spade_ok)");
+  const InFold f{mean, rstd, nullptr, 0, cells, map, G};
+  if (Cout <= 4) {
+    if (dbias_done) *dbias_done = 0;
+    const long inner = bww_ws_core(N, Cout, Cin, ks, H, W);
+    const long n = (long)Cout * Cin * ks * ks;
+    AGL_REQUIRE(ws && ws_bytes >= inner + n * 4, "agl_conv2d_bwd_weight_spade: workspace too small (%ld < %ld)", ws_bytes, inner + n * 4);
+    float* tmp = (float*)((char*)ws + inner);
+    const FewBwwShape fs{N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0};
+    int fsplits = 0;
+    const int frc = few_bww_try(fs, x, dy, ws, inner, &fsplits, (hipStream_t)stream, "agl_conv2d_bwd_weight_spade(few output channels)", 0, &f, in_relu, 1);
+    AGL_REQUIRE(frc == AGL_OK, "agl_conv2d_bwd_weight_spade: the few-channel kernel did not take the shape");
+    int rc = agl_launch_slab_reduce((const float*)ws, tmp, n, fsplits, 0, (hipStream_t)stream, "agl_conv2d_bwd_weight_spade(reduce)");
+    if (rc != AGL_OK) return rc;
+    hipLaunchKernelGGL(flip_transpose_w, dim3(agl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dw, Cout, Cin, ks, accumulate);
+    AGL_CHECK_LAUNCH("agl_conv2d_bwd_weight_spade(flip)");
+    g_last_pipe = 0;
+    return AGL_OK;
+  }
+  return conv2d_bwd_weight_impl(dy, x, dw, dbias, dbias_accumulate, dbias_done, ws, ws_bytes, N, Cin, H, W, Cout, OH, OW, ks, stride, pad, 0,
+                                in_relu, accumulate, flags, stream, &f);
+}
+int agl_conv2d_bwd_weight_spade_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {
+  const ConvOpts co = conv_opts(flags);
+  if (co.prec != 1 || !co.patch || stride != 1 || 2 * pad != ks - 1 || Cin % 16 != 0 || OH != H || OW != W) return 0;
+  if (Cout <= 4) {
+    const FewBwwShape fs{N, Cout, OH, OW, Cin, H, W, ks, 1, ks - 1 - pad, 0, 0};
+    return (W % 4 == 0 && few_bww_ws_bytes(fs) > 0) ? 1 : 0;
+  }
+  PBwwArgs a{};
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = OH; a.OW = OW; a.ks = ks; a.stride = stride; a.pad = pad; a.nsplit = 1;
+  return pbww_takes_spade(a) ? 1 : 0;
 }
 // 1 when agl_conv2d_bwd_weight with AGL_CONV_BF16 | AGL_CONV_DY_BF16 runs these extents on the matrix-core kernel (8-pixel pieces of dy)
 int agl_conv2d_bwd_weight_takes_bf16_dy(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags) {

@@ -6,8 +6,11 @@ struct FewBwwShape { int N, Cin, H, W, Cout, OH, OW, ks, stride, pad, up, in_rel
 // Bytes of slab workspace the few-input-channel weight gradient needs (0: shape not taken).
 long few_bww_ws_bytes(const FewBwwShape& a);
 // AGL_OK: slabs written ([*splits][Cout][Cin*ks*ks], to be added by slab_reduce); -1: shape not taken; else an error code.
+// dy_fold (optional, SPADE form of pconv.h's InFold): dy is the raw input of a SPADE whose modulate + ReLU (dy_relu) this kernel applies while
+// it stages the tensor, rounding the result to bf16 when dy_round_bf16 (the value a bf16-stored modulated tensor would hold)
+struct InFold;
 int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws, long ws_bytes, int* splits, hipStream_t st,
-                const char* name, int dy_bf16 = 0);      // dy_bf16: dy points to bf16 elements
+                const char* name, int dy_bf16 = 0, const InFold* dy_fold = nullptr, int dy_relu = 0, int dy_round_bf16 = 0);      // dy_bf16: dy points to bf16 elements
 // Forward convolution with <= 4 input channels, 1x1 / 3x3, stride 1, "same" size (exact fp32 on the vector units): AGL_OK, -1 when
 // the shape is not taken, else an error code.
 int few_cin_fwd_try(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int ks, int in_relu,

@@ -13,6 +13,8 @@
 #include <cstdint>
 #include "agl_internal.h"
 #include "few.h"
+#include "pconv.h"
+#include "spade.h"
 
 namespace {
 
@@ -24,6 +26,8 @@ struct FewBwwArgs {
   int N, Cin, H, W, Cout, OH, OW, pad, in_relu;
   int tiles, tiles_per_split, ncols;
   int dy_bf16;      // dy holds bf16 elements (the bf16-stored input of a few-output-channel layer, in this role through the swap of conv.hip)
+  InFold fold;      // optional (fold.cells): dy is a SPADE's raw input, modulated (+ ReLU: dy_relu) while it is staged (few.h)
+  int dy_relu, dy_round_bf16;
 };
 
 // Tile = 128 output pixels = TH full rows of one image (OW in {32, 64, 128}, TH = 128 / OW).  The dy tile is staged as
@@ -32,7 +36,7 @@ struct FewBwwArgs {
 // 64 x (32*NTL) product for them — an MFMA consumes 2 pixels: lanes 0-31 hold pixel 4g+j, lanes 32-63 pixel 4g+4+j of an
 // 8-pixel group, so one 16-byte read of dy feeds 4 MFMAs.  The four partial products are added through LDS in a fixed
 // order at the end and the workgroup writes one slab; slab_reduce (conv.hip) adds the slabs (deterministic).
-template <int KS, int NTL>
+template <int KS, int NTL, bool FOLD = false>      // FOLD: FewBwwArgs::fold compiled in (the 7x7 / 5-column-tile form: the 128 px decoder's c7)
 __global__ __launch_bounds__(NT_, 2) void few_bww_k(FewBwwArgs p) {
   constexpr int KK = KS * KS, DP = 132, BMC = 64;
   constexpr int RED = BMC * NTL * 32;                  // floats of the cross-wave reduction buffer
@@ -92,6 +96,22 @@ __global__ __launch_bounds__(NT_, 2) void few_bww_k(FewBwwArgs p) {
                    __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
       } else {
         v = *reinterpret_cast<const float4*>(p.dy + idx);
+      }
+      if (FOLD && p.fold.cells && ok) {      // SPADE's modulate (+ ReLU) of this channel's four pixels (they share an image row: OW % 4 == 0)
+        const int c = co0 + co, iy = ty0 + (4 * pc) / OW, ix0 = (4 * pc) % OW, G = p.fold.G;
+        const float mu = p.fold.mean[c], rs = p.fold.scale[c];
+        const float* const cb = p.fold.cells + ((size_t)(img * (p.Cout >> 3) + (c >> 3)) * (size_t)(G * G)) * 16 + (c & 7);
+        const int ro = p.fold.map[iy] * G;
+        float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* const ce = cb + (size_t)(ro + p.fold.map[ix0 + k]) * 16;
+          float t = spade_value(e4[k], mu, rs, ce[0], ce[8]);
+          if (p.dy_relu) t = fmaxf(t, 0.f);
+          if (p.dy_round_bf16) t = (float)(__bf16)t;
+          e4[k] = t;
+        }
+        v = float4{e4[0], e4[1], e4[2], e4[3]};
       }
       pd[r] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
@@ -366,7 +386,7 @@ long few_bww_ws_bytes(const FewBwwShape& a) {
 }
 
 int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws, long ws_bytes, int* splits_out, hipStream_t st,
-                const char* name, int dy_bf16) {
+                const char* name, int dy_bf16, const InFold* dy_fold, int dy_relu, int dy_round_bf16) {
   int ntl, splits, tps, tiles;
   if (few_bww_plan(a, &ntl, &splits, &tps, &tiles) != 0) return -1;
   const long need = (long)splits * a.Cout * a.Cin * a.ks * a.ks * 4;
@@ -374,11 +394,14 @@ int few_bww_try(const FewBwwShape& a, const float* dy, const float* x, void* ws,
   FewBwwArgs p;
   p.dy = dy; p.x = x; p.slabs = (float*)ws; p.N = a.N; p.Cin = a.Cin; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.OH = a.OH; p.OW = a.OW;
   p.pad = a.pad; p.in_relu = a.in_relu; p.tiles = tiles; p.tiles_per_split = tps; p.ncols = a.Cin * a.ks * a.ks; p.dy_bf16 = dy_bf16;
+  p.fold = dy_fold ? *dy_fold : InFold{}; p.dy_relu = dy_relu; p.dy_round_bf16 = dy_round_bf16;
+  if (p.fold.cells && (dy_bf16 || !p.fold.map || !p.fold.mean || !p.fold.scale || a.Cout % 8 != 0 || a.OW % 4 != 0 || a.ks != 7)) return -1;
   dim3 g((unsigned)splits, agl_cdiv(a.Cout, 64));
 #define FEW_LAUNCH(KS_, NT2_) hipLaunchKernelGGL((few_bww_k<KS_, NT2_>), g, dim3(NT_), 0, st, p)
   if (a.ks == 1) FEW_LAUNCH(1, 1);
   else if (a.ks == 3) { if (ntl == 1) FEW_LAUNCH(3, 1); else FEW_LAUNCH(3, 2); }
   else if (a.ks == 5) { if (ntl <= 3) FEW_LAUNCH(5, 3); else FEW_LAUNCH(5, 4); }
+  else if (p.fold.cells) { if (ntl <= 4) return -1; hipLaunchKernelGGL((few_bww_k<7, 5, true>), g, dim3(NT_), 0, st, p); }
   else { if (ntl <= 4) FEW_LAUNCH(7, 4); else FEW_LAUNCH(7, 5); }
 #undef FEW_LAUNCH
   AGL_CHECK_LAUNCH(name);

@@ -7,6 +7,7 @@
 //   mode 3: y = xhat*(1+gb[n][c][hw]) + gb[n][C+c][hw]   (SPADE, gb = [gamma;beta] conv output)
 #include <cstdint>
 #include "agl_internal.h"
+#include "spade.h"
 #include <algorithm>
 
 // (AglBnUpdate / AGL_BN_UPDATE_MAX: include/agl.h — the sources do not include the public header, tests/test_abi.py keeps them in step)
@@ -222,8 +223,14 @@ struct NormArgs {
 __device__ __forceinline__ float bf16_at(const float* y, long idx) {      // element idx of a bf16 tensor, widened (a shift)
   return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(y)[idx] << 16);
 }
-__device__ __forceinline__ bool relu_dead(const NormArgs& a, const float* __restrict__ y, long idx, float x, float mu, float fs, float fh) {
-  if (!y) return !(fmaf(x, fs, fh) > 0.f);
+// mode 3 without a stored output (SPADE applied by its consumer's staging pass, agl_conv2d_fwd_spade): the value that pass computed
+__device__ __forceinline__ long gb_plane(const NormArgs& a);
+__device__ __forceinline__ float spade_at(const NormArgs& a, const float* __restrict__ gam, float x, float mu, float rs, int gi) {
+  return spade_value(x, mu, rs, 1.f + gam[gi], gam[(long)a.C * gb_plane(a) + gi]);
+}
+__device__ __forceinline__ bool relu_dead(const NormArgs& a, const float* __restrict__ y, long idx, float x, float mu, float fs, float fh,
+                                          const float* __restrict__ gam = nullptr, float rs = 0.f, int gi = 0) {
+  if (!y) return a.mode == 3 ? !(spade_at(a, gam, x, mu, rs, gi) > 0.f) : !(fmaf(x, fs, fh) > 0.f);
   return a.y_bf16 ? !(bf16_at(y, idx) > 0.f) : !(y[idx] > 0.f);
 }
 // four consecutive elements of y starting at element 4*i of the row at `base` (fp32 or bf16 storage)
@@ -245,6 +252,17 @@ __device__ __forceinline__ int gb_index(const NormArgs& a, int i) {
   return a.map[iy] * a.src_w + a.map[ix];
 }
 __device__ __forceinline__ long gb_plane(const NormArgs& a) { return a.map ? (long)a.src_w * a.src_w : (long)a.HW; }
+// the same for pixels 4i .. 4i+3 of a row (W % 4 == 0 when gathered: they share an image row)
+__device__ __forceinline__ float4 spade_quad(const NormArgs& a, const float* __restrict__ gam, float4 xv, float mu, float rs, int i) {
+  int gi[4] = {4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3};
+  if (a.map) {
+    const int iy = (4 * i) / a.W, ix0 = 4 * i - iy * a.W, ro = a.map[iy] * a.src_w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gi[k] = ro + a.map[ix0 + k];
+  }
+  return float4{spade_at(a, gam, xv.x, mu, rs, gi[0]), spade_at(a, gam, xv.y, mu, rs, gi[1]), spade_at(a, gam, xv.z, mu, rs, gi[2]),
+                spade_at(a, gam, xv.w, mu, rs, gi[3])};
+}
 
 __device__ __forceinline__ void row_affine(const NormArgs& a, int n, int c, float& g, float& b) {
   g = 1.f; b = 0.f;
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(256) void norm_apply_fwd(NormArgs a, const float* _
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float xh = (a.x[base + i] - mu) * rs;
     const int gi = a.mode == 3 ? gb_index(a, i) : 0;
-    float v = a.mode == 3 ? xh * (1.f + gam[gi]) + bet[gi] : xh * g + b;
+    float v = a.mode == 3 ? spade_value(a.x[base + i], mu, rs, 1.f + gam[gi], bet[gi]) : xh * g + b;
     if (residual) v += residual[base + i];
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.y_bf16) reinterpret_cast<__bf16*>(y)[base + i] = (__bf16)v;
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256) void norm_apply_fwd4(NormArgs a, const float* 
         gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w; bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] * (1.f + gg[k]) + bb[k];
+      for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], 1.f + gg[k], bb[k]);      // (= spade_value of csrc/spade.h: v holds (x - mean) * rstd)
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] * g + b;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows(NormArgs a, const float* __
     for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
       float g = dy[base + i];
       const float xv = a.x[base + i];
-      if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh)) g = 0.f;
+      if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh, gam, rs, a.mode == 3 ? gb_index(a, i) : 0)) g = 0.f;
       float xh = (xv - mu) * rs;
       if (a.mode == 3) {
         dgam[i] = g * xh;         // (full resolution either way: a gathered gamma|beta is reduced to its grid by agl_grid_gather_bwd)
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows4(NormArgs a, const float* _
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : (a.mode == 3 ? spade_quad(a, gam, xv, mu, rs, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)});
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -443,8 +461,9 @@ __global__ __launch_bounds__(128) void norm_bwd_rows_gathered(NormArgs a, const 
   for (int iy = 0; iy < W; ++iy) {
     const long i = base + (long)iy * W + tid;
     float g = dy[i];
-    if (a.relu && !((a.y_bf16 ? bf16_at(y, i) : y[i]) > 0.f)) g = 0.f;
-    const float xh = (a.x[i] - mu) * rs;
+    const float xv = a.x[i];
+    if (a.relu && !((y ? (a.y_bf16 ? bf16_at(y, i) : y[i]) : spade_at(a, gam, xv, mu, rs, a.map[iy] * sw + a.map[tid])) > 0.f)) g = 0.f;
+    const float xh = (xv - mu) * rs;
     ra[tid] = g * xh; rb[tid] = g;
     __syncthreads();
     const int cy = a.map[iy];
@@ -571,7 +590,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(NormArgs a, const float* _
   for (int i = threadIdx.x % LPR; i < a.HW; i += LPR) {
     float g = dy[base + i];
     const float xv = a.x[base + i];
-    if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh)) g = 0.f;
+    if (a.relu && relu_dead(a, y, base + i, xv, mu, fs, fh, gam, rs, a.mode == 3 ? gb_index(a, i) : 0)) g = 0.f;
     float xh = (xv - mu) * rs;
     float gg = a.mode == 3 ? g * (1.f + gam[gb_index(a, i)]) : g * ge;
     dx[base + i] = rs * (gg - m1 - xh * m2);
@@ -624,7 +643,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xh[4] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
     if (a.relu) {
-      const float4 yv = have_y ? y_quad(a, y, base, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)};
+      const float4 yv = have_y ? y_quad(a, y, base, i) : (a.mode == 3 ? spade_quad(a, gam, xv, mu, rs, i) : float4{fmaf(xv.x, fs, fh), fmaf(xv.y, fs, fh), fmaf(xv.z, fs, fh), fmaf(xv.w, fs, fh)});
       if (!(yv.x > 0.f)) g[0] = 0.f;
       if (!(yv.y > 0.f)) g[1] = 0.f;
       if (!(yv.z > 0.f)) g[2] = 0.f;
@@ -646,6 +665,24 @@ __global__ __launch_bounds__(256) void norm_bwd_apply4(NormArgs a, const float* 
     for (int k = 0; k < 4; ++k) o[k] = rs * (g[k] * ge4[k] - m1 - xh[k] * m2);
     dx4[i] = float4{o[0], o[1], o[2], o[3]};
   }
+}
+
+// (N, 2C, G2) gamma|beta -> the blocked cell table of agl_spade_cells.  One thread per (image, channel octet, cell): sixteen reads, each
+// coalesced along the cells of a channel plane, and one 64-byte line written (consecutive threads, consecutive lines)
+__global__ void spade_cells_k(const float* __restrict__ gb, float* __restrict__ cells, int N, int C, int G2, long total) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (n * C/8 + c8) * G2 + cell
+  if (q >= total) return;
+  const int cell = (int)(q % G2);
+  const long nc8 = q / G2;
+  const int c8 = (int)(nc8 % (C >> 3)), n = (int)(nc8 / (C >> 3));
+  const float* const ga = gb + ((long)n * 2 * C + 8 * c8) * G2 + cell;
+  const float* const be = ga + (long)C * G2;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v[j] = 1.f + ga[(long)j * G2]; v[8 + j] = be[(long)j * G2]; }
+  float4* const o = reinterpret_cast<float4*>(cells + q * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = float4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
 }
 
 int pick_lpr(int HW) { return HW <= 4 ? 4 : (HW <= 16 ? 16 : (HW <= 512 ? 64 : 256)); }
@@ -856,6 +893,25 @@ int agl_norm_bwd_fold(const float* dy, const float* x, const float* mean, const 
                        nullptr, nullptr, 0, 0, ws, ws_bytes, stream, fold_scale, fold_shift, fold_per_n);
 }
 
+// Backward of SPADE's modulate(+ReLU) when the consuming convolution applied it while staging (agl_conv2d_fwd_spade): dy is the gradient
+// with respect to the never-stored activation; the ReLU mask is recomputed from x, mean, rstd and gb with csrc/spade.h's expression.
+int agl_norm_bwd_spade(const float* dy, const float* x, const float* mean, const float* rstd, const float* gb, int relu, int batch_stats,
+                       float* dx, float* dgb, int N, int C, int HW, const int* gb_map, const int* gb_lo, int W, int src_w, void* ws,
+                       long ws_bytes, void* stream) {
+  return norm_bwd_impl(dy, x, nullptr, mean, rstd, 3, gb, nullptr, nullptr, relu, batch_stats, dx, dgb, nullptr, N, C, HW, 0, 0, gb_map, gb_lo,
+                       W, src_w, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// cells[((n * C/8 + c/8) * G*G + cell) * 16 + j] = 1 + gamma[n][c/8*8 + j][cell], [.. + 8 + j] = beta[..] from gb (N, 2C, G, G): the layout the
+// staging passes of agl_conv2d_fwd_spade / agl_conv2d_bwd_weight_spade read with 16-byte loads (csrc/pconv.h InFold::cells)
+int agl_spade_cells(const float* gb, int N, int C, int G, float* cells, void* stream) {
+  AGL_REQUIRE(gb && cells && N > 0 && C > 0 && C % 8 == 0 && G > 0 && (long)N * C * G * G < (1L << 28), "agl_spade_cells: bad argument");
+  const long total = (long)N * (C / 8) * G * G;
+  hipLaunchKernelGGL(spade_cells_k, dim3(agl_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gb, cells, N, C, G * G, total);
+  AGL_CHECK_LAUNCH("agl_spade_cells");
+  return AGL_OK;
+}
+
 // scale[rows][C] = rstd[c] * gamma(r, c), shift[rows][C] = beta(r, c) of the normalise-modulate in `mode` (0: gamma 1, beta 0;
 // 1: affine; 2: class table rows picked by labels) — rows = N for mode 2 (per object), else 1.
 int agl_norm_fold_table(const float* mean, const float* rstd, int mode, const float* p0, const float* p1, const long long* labels, int N, int C,
@@ -881,7 +937,7 @@ static int norm_bwd_impl(const float* dy, const float* x, const float* y, const 
   if (rc) return rc;
   a.fscale = fscale; a.fshift = fshift; a.f_per_n = f_per_n < 0 ? 0 : f_per_n;
   a.y_bf16 = f_per_n < 0;      // (f_per_n = -1: the y16 entry point)
-  AGL_REQUIRE(dy && dx && (!relu || y || fscale), "agl_norm_bwd: null pointer");
+  AGL_REQUIRE(dy && dx && (!relu || y || fscale || mode == 3), "agl_norm_bwd: null pointer");
   AGL_REQUIRE(mode != 3 || dp0, "agl_norm_bwd: SPADE mode needs dgb output");
   if (!ws || ws_bytes < agl_norm_bwd_ws_bytes(N, C)) {
     agl_set_error("agl_norm_bwd: workspace too small");

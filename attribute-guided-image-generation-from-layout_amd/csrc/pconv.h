@@ -7,7 +7,12 @@
 //   v = fma(x, scale[r * C + c], shift[r * C + c]),  r = image index when per_n, else 0   (then the fused input ReLU)
 // with scale = rstd * gamma, shift = beta - mean * rstd * gamma formed in double (agl_norm_fold_table).  Zero padding is applied AFTER
 // the transform (padding stays 0).  (`mean` is kept for the ABI's symmetry with the statistics; the kernels read scale / shift only.)
-struct InFold { const float* mean; const float* scale; const float* shift; int per_n; };
+//
+// SPADE form (cells != NULL; normalization.py:97,106 in front of generator_obj_att128.py:588-597's c6 / c7): the modulation parameters
+// live on a G x G class grid per image, cells[((n * C/8 + c/8) * G*G + cell) * 16 + {0..7: 1 + gamma of channels c..c+7, 8..15: beta}]
+// (agl_spade_cells), pixel (iy, ix) reads cell map[iy] * G + map[ix]; mean / scale are then the per-channel batch mean and rstd and
+//   v = spade_value(x, mean[c], scale[c], cells[.][j], cells[.][8 + j])          (csrc/spade.h — the stand-alone apply's own expression)
+struct InFold { const float* mean; const float* scale; const float* shift; int per_n; const float* cells; const int* map; int G; };
 
 struct PConvArgs {
   const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
@@ -76,6 +81,7 @@ struct PVertArgs {
   const float* x; const float* w; const float* bias; const float* pos_mask; float* y;
   int N, Cred, H, W, CO, ks, pad, w_so, w_sc, flip, relu, accumulate, nsplit;
   int x_bf16;                       // x points to bf16 elements (nsplit 1 only)
+  InFold fold; int in_relu;         // optional transform of x while it is staged (SPADE form, nsplit 1, fp32 x), then the fused input ReLU
 };
 long pconv_vert_ws_bytes(int N, int Cred, int H, int W, int CO, int ks, int nsplit);
 int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);
@@ -91,4 +97,5 @@ struct PBwwArgs {
   float* dbias; int dbias_accumulate; int* dbias_done;    // optional: also (+= when dbias_accumulate) the bias gradient sum_pixels dy into dbias[Cout]; *dbias_done = 1 when this path did it
 };
 long pbww_ws_bytes(const PBwwArgs& a);
+bool pbww_takes_spade(const PBwwArgs& a);      // the weight-gradient kernel has the SPADE form of the input transform compiled in for these extents
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name);

@@ -21,6 +21,7 @@
 // The input-gradient of a "same" convolution runs on the same kernel through the packed weights (flipped taps,
 // channel roles swapped).  Epilogues as in conv.hip (bias, ReLU-mask of the consumer, accumulate, ReLU).
 #include "pconv.h"
+#include "spade.h"
 #include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -330,7 +331,8 @@ constexpr unsigned OOB31 = 0x80000000u;   // voffset of an out-of-window element
 // VERT: a KS x 1 window (vertical taps only, no horizontal padding): the first half of the few-channel 7x7 layers (pconv_vert_try)
 // FEAT (bit mask): features compiled into an instantiation — every one costs registers in ALL its launches (82 of 224 kernels lost a
 // workgroup per CU when they were runtime switches), so only the shapes that use them are instantiated with them:
-//   1  input transform of the staged patch (PArgs::fold): the 4x4 / stride-2 family (crop / layout / global encoder)
+//   1  input transform of the staged patch (PArgs::fold): the 4x4 / stride-2 family (crop / layout / global encoder), and — for SPADE in
+//      front of the 128 px decoder's c6 / c7 — the bf16 5x5 forms and the bf16 vertical 7 x 1 form
 //   2  BatchNorm partial rows of the output (PArgs::stats): the same family, and the 5x5 bf16 forms (decoder c6)
 //   4  bf16 output store / out-of-place addend (PArgs::y_bf16, addend)
 //   8  bf16 pos_mask in the paired-phase (stride-2 input gradient) epilogue
@@ -392,6 +394,8 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   constexpr int STAGE_PIECES = (DBB ? 2 : 1) * PB + (DBA ? 2 : 1) * AB, EP_PIECES = (NTH / 64) * 32 * EP_PITCH / 4;   // 16-byte pieces
   __shared__ u32x4 lds[STAGE_PIECES > EP_PIECES ? STAGE_PIECES : EP_PIECES];
   __shared__ unsigned wmax_s[H16 ? NTH / 64 : 1];      // H16: the waves' maxima of the chunk about to be converted
+  constexpr bool F_SPADE = F_FOLD && S == 1;      // the SPADE form of the transform (pconv.h): the stride-1 instantiations that carry FEAT 1
+  __shared__ __attribute__((aligned(16))) float fmr[F_SPADE ? 1024 : 1];      // SPADE: per-channel mean [0, 512) and rstd [512, 1024) (Cin <= 512)
   u32x4* const Pl = lds;
   u32x4* const Al = lds + (DBB ? 2 : 1) * PB;
 
@@ -434,6 +438,14 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
   unsigned bsrc[BR];   // patch item e = (half h, image ti, row yy, column xx): byte offset of channel 8h, or OOB31
   int bdst[BR];        // LDS piece index h*NQ + q, or -1
   int faff[F_FOLD ? BR : 1];
+  int fcell[F_FOLD ? BR : 1];      // SPADE form of the transform: float offset of the item's cell in channel group 0's plane of p.fold.cells
+  const int fG2 = F_FOLD && p.fold.cells ? p.fold.G * p.fold.G : 0;
+  if constexpr (F_SPADE) {
+    if (p.fold.cells) {      // (uniform) the per-channel statistics, once per workgroup
+      for (int i = tid; i < p.Cin; i += NTH) { fmr[i] = p.fold.mean[i]; fmr[512 + i] = p.fold.scale[i]; }
+      __syncthreads();
+    }
+  }
 #pragma unroll
   for (int r = 0; r < BR; ++r) {
     const int e = tid + NT * r;
@@ -445,7 +457,10 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
     if constexpr (BLK) bsrc[r] = ok ? (unsigned)(((img * (p.Cin >> 3) + h) * p.H + ly) * p.W + lx) * 16u : OOB31;      // the piece of channel group h
     else bsrc[r] = ok ? (unsigned)(((img * p.Cin + 8 * h) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
     bdst[r] = in ? h * NQ + (S == 2 ? (xx & 1) * PAR : 0) + ti * IMGP + yy * PWP + (S == 2 ? xx >> 1 : xx) : -1;
-    if constexpr (F_FOLD) faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // row offset of this item's 8 channels in the scale / shift tables
+    if constexpr (F_FOLD) {
+      faff[r] = 8 * h + (p.fold.per_n && ok ? img * p.Cin : 0);      // row offset of this item's 8 channels in the scale / shift tables
+      fcell[r] = (p.fold.cells && ok) ? ((img * (p.Cin >> 3) + h) * fG2 + p.fold.map[ly] * p.fold.G + p.fold.map[lx]) * 16 : 0;
+    }
   }
   const unsigned cstride = (unsigned)(p.H * p.W) * esz;
   unsigned asrc[AR];   // weight piece e = (plane, h, t, row) of stage (0, 0), in 16-byte units; clamped when e >= NA
@@ -490,6 +505,33 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) pa[r] = base[asrc[r]];
   };
+  // the input transform of patch item r (PArgs::fold), applied to its eight prefetched channels; padding items are left alone (they stay 0)
+  auto fold_item = [&](int r) {
+    if constexpr (F_FOLD) {
+      if (!p.fold.scale || bsrc[r] == OOB31) return;
+      if constexpr (F_SPADE) {
+        if (p.fold.cells) {      // SPADE: (1 + gamma | beta) of the item's class-grid cell (one 64-byte line), mean / rstd of its channels from LDS (pconv.h)
+          const float4* const cb = reinterpret_cast<const float4*>(p.fold.cells + (size_t)(c_staged >> 3) * (size_t)(fG2 * 16) + fcell[r]);
+          const float4* const mu4 = reinterpret_cast<const float4*>(fmr + c_staged + faff[r]);
+          const float4* const rs4 = reinterpret_cast<const float4*>(fmr + 512 + c_staged + faff[r]);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float4 g1 = cb[q], be = cb[2 + q], mu = mu4[q], rs = rs4[q];
+            pb[r][4 * q + 0] = spade_value(pb[r][4 * q + 0], mu.x, rs.x, g1.x, be.x); pb[r][4 * q + 1] = spade_value(pb[r][4 * q + 1], mu.y, rs.y, g1.y, be.y);
+            pb[r][4 * q + 2] = spade_value(pb[r][4 * q + 2], mu.z, rs.z, g1.z, be.z); pb[r][4 * q + 3] = spade_value(pb[r][4 * q + 3], mu.w, rs.w, g1.w, be.w);
+          }
+          return;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {              // BatchNorm: four channels at a time; one fused multiply-add per element
+        const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
+        const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
+        pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0], sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1], sc.y, sh.y);
+        pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2], sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3], sc.w, sh.w);
+      }
+    }
+  };
   // H16: the input transform and the fused input ReLU are applied to the registers first, so that the chunk's maximum is that of the values
   // that get converted; every wave publishes its maximum (sign bit cleared: magnitudes order like unsigned integers)
   auto prep_b = [&]() {
@@ -497,17 +539,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
       unsigned tm = 0;
 #pragma unroll
       for (int r = 0; r < BR; ++r) {
-        if constexpr (F_FOLD) {
-          if (p.fold.scale && bsrc[r] != OOB31) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
-              const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
-              pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0], sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1], sc.y, sh.y);
-              pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2], sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3], sc.w, sh.w);
-            }
-          }
-        }
+        fold_item(r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (p.in_relu) pb[r][j] = fmaxf(pb[r][j], 0.f);
@@ -544,17 +576,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void pconv_k(PArgs p) {
         Pl[bdst[r]] = bsrc[r] != OOB31 ? v : u32x4{0u, 0u, 0u, 0u};
         continue;
       }
-      if constexpr (F_FOLD) {
-        if (p.fold.scale && bsrc[r] != OOB31) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS: padding stays 0
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {              // (four channels at a time; one fused multiply-add per element)
-            const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + c_staged + faff[r])[q];
-            const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + c_staged + faff[r])[q];
-            pb[r][4 * q + 0] = fmaf(pb[r][4 * q + 0], sc.x, sh.x); pb[r][4 * q + 1] = fmaf(pb[r][4 * q + 1], sc.y, sh.y);
-            pb[r][4 * q + 2] = fmaf(pb[r][4 * q + 2], sc.z, sh.z); pb[r][4 * q + 3] = fmaf(pb[r][4 * q + 3], sc.w, sh.w);
-          }
-        }
-      }
+      fold_item(r);      // the producing norm's normalise-modulate, applied on the way to LDS: padding stays 0
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1281,6 +1303,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   // bias gradient (sum of dy over the pixels, per output channel): the 16 consecutive lanes that stage the 8-pixel pieces of one
   // channel row add them up; one of them keeps the running sum in LDS (the same lane owns the same channel in every tile: no races)
   __shared__ float lbias[BMCO];
+  __shared__ __attribute__((aligned(16))) float fmr[AUX ? 32 : 1];      // SPADE form of the transform: mean [0, 16) and rstd [16, 32) of the block's 16 input channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   // Workgroup -> (pixel split bx, input-channel block by, output-channel block bz).  The workgroups of one pixel split read the
@@ -1300,6 +1323,13 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   const bool do_bias = p.bias_slabs != nullptr && by == 0;
   if (do_bias && tid < BMCO) lbias[tid] = 0.f;      // (ordered before the first update by the barrier at the top of the tile loop)
   const int c0 = (by / NPASS) * BC, co0 = bz * BMCO;
+  if constexpr (AUX) {
+    static_assert(BC == 16, "the input transform is compiled into one-column (16-channel) blocks");
+    if (p.fold.cells) {      // (uniform) SPADE form: the block's per-channel statistics, once per workgroup
+      if (tid < 32) fmr[tid] = tid < 16 ? p.fold.mean[c0 + tid] : p.fold.scale[c0 + tid - 16];
+      __syncthreads();
+    }
+  }
   const int t_beg = bx * p.tiles_per_split, t_end = min(p.tiles, t_beg + p.tiles_per_split);
   const int Hl = p.H << p.up, Wl = p.W << p.up;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -1336,7 +1366,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   float4 pdy[DR][2];
   float px[XB ? 1 : XR][8];
   u32x4 pxq[XB ? XR : 1];      // blocked x: the pieces as they are stored
-  bool pxin[AUX ? XR : 1];           // (fold) the staged patch pixel lies inside the map: padding must stay zero
+  int pxin[AUX ? XR : 1];            // (fold) < 0: the staged patch pixel lies outside the map (padding must stay zero); else its class-grid cell (SPADE form) or 0
   auto tile_origin = [&](int tile, int& img0, int& ty0, int& tx0) {
     if constexpr (TI == 1) {
       img0 = tile / tpi;
@@ -1386,7 +1416,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
         return;
       }
       const unsigned off = ok ? (unsigned)(((img * p.Cin + c0 + 8 * oc) * p.H + (ly >> p.up)) * p.W + (lx >> p.up)) * esz : OOB31;
-      if constexpr (AUX) pxin[sl] = ok;
+      if constexpr (AUX) pxin[sl] = !ok ? -1 : (p.fold.cells ? p.fold.map[ly] * p.fold.G + p.fold.map[lx] : 0);
       if (p.x_bf16) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
@@ -1437,6 +1467,35 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
     }
   };
   int img0_staged = 0;      // first image of the tile whose operands are in the prefetch registers
+  // the input transform of x item (r: item index, sl: its prefetch slot), applied to its eight prefetched channels (WArgs::fold; see pconv_k)
+  auto fold_x = [&](int r, int sl) {
+    if constexpr (AUX) {
+      if (!p.fold.scale || pxin[sl] < 0) return;
+      const int e = min(tid + NT * r, NXI - 1), oc = e / NQ, q = e - oc * NQ;
+      const int ch = c0 + 8 * oc, img = img0_staged + q / IMGP;
+      if (p.fold.cells) {
+        const float4* const cb = reinterpret_cast<const float4*>(p.fold.cells) +
+                                 ((size_t)(img * (p.Cin >> 3) + (ch >> 3)) * (size_t)(p.fold.G * p.fold.G) + pxin[sl]) * 4;
+        const float4* const mu4 = reinterpret_cast<const float4*>(fmr + 8 * oc);
+        const float4* const rs4 = reinterpret_cast<const float4*>(fmr + 16 + 8 * oc);
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const float4 g1 = cb[hq], be = cb[2 + hq], mu = mu4[hq], rs = rs4[hq];
+          px[sl][4 * hq + 0] = spade_value(px[sl][4 * hq + 0], mu.x, rs.x, g1.x, be.x); px[sl][4 * hq + 1] = spade_value(px[sl][4 * hq + 1], mu.y, rs.y, g1.y, be.y);
+          px[sl][4 * hq + 2] = spade_value(px[sl][4 * hq + 2], mu.z, rs.z, g1.z, be.z); px[sl][4 * hq + 3] = spade_value(px[sl][4 * hq + 3], mu.w, rs.w, g1.w, be.w);
+        }
+        return;
+      }
+      const int rowo = p.fold.per_n ? img * p.Cin : 0;
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
+        const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
+        px[sl][4 * hq + 0] = fmaf(px[sl][4 * hq + 0], sc.x, sh.x); px[sl][4 * hq + 1] = fmaf(px[sl][4 * hq + 1], sc.y, sh.y);
+        px[sl][4 * hq + 2] = fmaf(px[sl][4 * hq + 2], sc.z, sh.z); px[sl][4 * hq + 3] = fmaf(px[sl][4 * hq + 3], sc.w, sh.w);
+      }
+    }
+  };
   auto sstore_x = [&](int r, int sl) {
     {
       const int e = tid + NT * r;
@@ -1460,18 +1519,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
         *reinterpret_cast<u32x4*>(dst + X_PLANE) = __builtin_bit_cast(u32x4, lo);
         return;
       }
-      if constexpr (AUX) {
-        if (p.fold.scale && pxin[sl]) {      // the producing BatchNorm's normalise-modulate, applied on the way to LDS (see pconv_k)
-          const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
-#pragma unroll
-          for (int hq = 0; hq < 2; ++hq) {
-            const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
-            const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
-            px[sl][4 * hq + 0] = fmaf(px[sl][4 * hq + 0], sc.x, sh.x); px[sl][4 * hq + 1] = fmaf(px[sl][4 * hq + 1], sc.y, sh.y);
-            px[sl][4 * hq + 2] = fmaf(px[sl][4 * hq + 2], sc.z, sh.z); px[sl][4 * hq + 3] = fmaf(px[sl][4 * hq + 3], sc.w, sh.w);
-          }
-        }
-      }
+      fold_x(r, sl);      // the producing norm's normalise-modulate, applied on the way to LDS (see pconv_k)
       bf16x8 t0, t1, t2;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
@@ -1504,19 +1552,7 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       }
 #pragma unroll
       for (int r = 0; r < XR; ++r) {
-        if constexpr (AUX) {
-          if (p.fold.scale && pxin[r]) {
-            const int e = min(tid + NT * r, NXI - 1), oc = e / NQ, q = e - oc * NQ;
-            const int ch = c0 + 8 * oc, rowo = p.fold.per_n ? (img0_staged + q / IMGP) * p.Cin : 0;
-#pragma unroll
-            for (int hq = 0; hq < 2; ++hq) {
-              const float4 sc = reinterpret_cast<const float4*>(p.fold.scale + rowo + ch)[hq];
-              const float4 sh = reinterpret_cast<const float4*>(p.fold.shift + rowo + ch)[hq];
-              px[r][4 * hq + 0] = fmaf(px[r][4 * hq + 0], sc.x, sh.x); px[r][4 * hq + 1] = fmaf(px[r][4 * hq + 1], sc.y, sh.y);
-              px[r][4 * hq + 2] = fmaf(px[r][4 * hq + 2], sc.z, sh.z); px[r][4 * hq + 3] = fmaf(px[r][4 * hq + 3], sc.w, sh.w);
-            }
-          }
-        }
+        fold_x(r, r);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           if (p.in_relu) px[r][jj] = fmaxf(px[r][jj], 0.f);
@@ -1819,7 +1855,8 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
   // features compiled into some instantiations only (pconv_k FEAT): input transform + statistics rows in the 4x4 / stride-2 family,
   // statistics rows in the bf16 5x5 forms, bf16 output / addend in the bf16 3x3 stride-1 and 1x1 forms
   const bool fam42 = s2 && a.ks == 4, fam5 = !s2 && a.ks == 5 && a.nsplit == 1, famy = !s2 && a.nsplit == 1 && (a.ks == 3 || a.ks == 1);
-  if (a.fold.scale && !fam42) return -1;
+  if (a.fold.scale && !(fam42 || fam5)) return -1;
+  if (a.fold.cells && (a.up != 0 || a.x_bf16 || a.fold.per_n || !a.fold.map || a.fold.G <= 0 || a.Cin % 16 != 0 || a.Cin > 512 || s2)) return -1;      // (SPADE form: fp32 x, one map entry per pixel row / column)
   if ((a.y_bf16 || a.addend) && !famy) return -1;
   if (a.x_blk || a.y_blk) {      // (checked again below; here: keep the statistics rows off a blocked launch)
     if (a.stats) return -1;
@@ -1828,7 +1865,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     p.stats = a.stats;
     *a.stat_rows = (int)(wcols * ptiles);
   }
-  const int feat42 = (a.fold.scale || p.stats) ? 3 : 0, feat5 = p.stats ? 2 : 0, featy = (a.y_bf16 || a.addend) ? 4 : 0;
+  const int feat42 = (a.fold.scale || p.stats) ? 3 : 0, feat5 = (a.fold.scale || p.stats) ? 3 : 0, featy = (a.y_bf16 || a.addend) ? 4 : 0;
   const bool featsc = a.sc_x != nullptr;
   p.x_bf16 = a.x_bf16; p.mask_bf16 = a.mask_bf16;
   if (a.mask_bf16 && (pl.splits > 1 || !a.pos_mask)) return -1;      // (the slab reduction reads an fp32 mask)
@@ -1969,7 +2006,7 @@ int pconv_try(const PConvArgs& a, void* ws, long ws_bytes, hipStream_t st, const
     }
     else PC_SHAPES3(3, 9);
   } else {
-    if (a.nsplit == 1 && feat5) { if (bm == 128) PC_SHAPES1F(2, 5, 128, 5); else PC_SHAPES1F(2, 5, 64, 5); }
+    if (a.nsplit == 1 && feat5) { if (bm == 128) PC_SHAPES1F(3, 5, 128, 5); else PC_SHAPES1F(3, 5, 64, 5); }
     else if (a.nsplit == 1) { if (bm == 128) PC_SHAPES1(5, 128, 5); else PC_SHAPES1(5, 64, 5); }
     else if (geo == 3) PC_LAUNCH_DB(5, 1, 8, 8, 1, 64, SPL, 5);
     else if (geo == 0 && w32) PC_LAUNCH_DB(5, 1, 32, 4, 1, 64, SPL, 5);
@@ -2108,16 +2145,17 @@ int pconv_vert_try(const PVertArgs& a, void* ws, long ws_bytes, hipStream_t st, 
   p.odiv = nullptr; p.prio = 0; p.oh2 = 0; p.ow2 = 0;
   p.x = a.x; p.wp = wp; p.bias = nullptr; p.pos_mask = nullptr; p.y = P;
   p.N = a.N; p.Cin = a.Cred; p.H = a.H; p.W = a.W; p.Cout = M; p.OH = a.H; p.OW = a.W; p.pad = a.pad; p.up = 0;
-  p.in_relu = 0; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
+  p.in_relu = a.in_relu; p.relu = 0; p.accumulate = 0; p.nch = nch; p.mpad = mpad;
   p.stats = nullptr; p.slabs = nullptr; p.cps = nch; p.out_numel = (long)a.N * M * a.H * a.W;
-  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = InFold{nullptr, nullptr, nullptr, 0}; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
+  p.x_bf16 = a.x_bf16; p.mask_bf16 = 0; p.fold = a.fold; p.y_bf16 = 0; p.addend = nullptr; p.sc_x = nullptr;
+  if (a.fold.scale && (a.nsplit != 1 || a.x_bf16 || !a.fold.cells || !a.fold.map || a.fold.per_n || a.Cred > 512)) return -1;      // (the transform: SPADE form, bf16 arithmetic, fp32 x)
   p.wexp = nullptr; p.blk = 0; p.mask_blk = 0;
   p.x_bytes = (unsigned)((long)a.N * a.Cred * a.H * a.W * (a.x_bf16 ? 2 : 4));
   if (a.x_bf16 && a.nsplit != 1) return -1;
   if (a.nsplit == 1) {
     dim3 g((unsigned)((long)a.N * (a.H / 8) * (a.W / 32)), 1, 1);
     pconv_xcd_order(p, g);
-    hipLaunchKernelGGL((pconv_k<7, 1, 32, 8, 1, 64, 1, 7, false, false, 256, 0, true>), g, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((pconv_k<7, 1, 32, 8, 1, 64, 1, 7, false, false, 256, 0, true, 1>), g, dim3(256), 0, st, p);
   } else {
     dim3 g((unsigned)((long)a.N * (a.H / 4) * (a.W / 32)), 1, 1);
     pconv_xcd_order(p, g);
@@ -2340,6 +2378,12 @@ long pbww_ws_bytes(const PBwwArgs& a) {
   return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4 + (long)s * a.Cout * 4;      // weight slabs + bias-gradient slabs
 }
 
+bool pbww_takes_spade(const PBwwArgs& a) {      // (pbww_try's aux5: the one bf16 5x5 tile shape the transform is compiled into)
+  int splits, tps, rt, ct, half, oh, ow; long tiles;
+  if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return false;
+  return a.ks == 5 && a.stride == 1 && a.nsplit == 1 && a.up == 0 && half == 0;
+}
+
 int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const char* name) {
   int splits, tps, rt, ct, half, oh, ow; long tiles;
   if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return -1;
@@ -2359,7 +2403,9 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
                    ((a.ks == 3 && a.stride == 1) || (a.ks == 4 && a.stride == 2)))) return -1;
   if (a.dy_bf16 && (a.nsplit != 1 || (a.OW % 8 != 0 && !(a.OW == 4 && a.OH == 4)))) return -1;      // (16-byte pieces of 8 bf16)
   const bool aux = a.dy_bf16 || a.fold.scale != nullptr;
-  if (aux && !(a.ks == 4 && a.stride == 2)) return -1;      // (compiled into the 4x4 / stride-2 instantiations only)
+  const bool aux5 = aux && a.ks == 5 && a.stride == 1 && a.nsplit == 1 && !a.dy_bf16 && half == 0;      // (SPADE in front of the 128 px decoder's c6)
+  if (aux && !(a.ks == 4 && a.stride == 2) && !aux5) return -1;      // (compiled into the 4x4 / stride-2 instantiations and one bf16 5x5 tile only)
+  if (a.fold.cells && (a.up != 0 || a.x_bf16 || a.fold.per_n || !a.fold.map || a.fold.G <= 0)) return -1;
   p.x_bytes = (unsigned)((long)a.N * a.Cin * a.H * a.W * (a.x_bf16 ? 2 : 4)); p.dy_bytes = (unsigned)((long)a.N * a.Cout * a.OH * a.OW * 4);
   const int npass = 1;
   dim3 g((unsigned)splits, a.Cin / (16 * ct) * npass, agl_cdiv(a.Cout, 64 * rt));
@@ -2412,6 +2458,7 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   } else if (a.ks == 3 && a.nsplit == 1) {
     PW_LAUNCH1(3, 1, 1, 1);
   } else if (a.ks == 3) PW_LAUNCH(3, 1, 1, 1, SPL);
+  else if (aux5) hipLaunchKernelGGL((pbww_k<5, 1, 16, 8, 1, 1, 1, 1, 25, true>), g, dim3(NT), 0, st, p);
   else if (a.nsplit == 1) PW_LAUNCH(5, 1, 1, 1, 1);
   else {
     if (half == 1) hipLaunchKernelGGL((pbww_k<5, 1, 8, 8, 2, 1, 1, SPL, 25>), g, dim3(NT), 0, st, p);

@@ -189,6 +189,29 @@ int agl_conv2d_bwd_weight_fold(const float* dy, const float* x, const float* in_
                                int in_per_n, float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N,
                                int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate,
                                int flags, void* stream);
+/* ---- SPADE applied by the convolution that reads it (BASELINE north_star "SPADE normalization ... fused with the following conv").
+ * relu(SPADE(x)) = relu((x - mean[c]) * rstd[c] * (1 + gamma[n][c][cell]) + beta[n][c][cell]) — models/spade/networks/normalization.py:97,106
+ * with param_free_norm = BatchNorm2d — in front of the 128 px decoder's c6 (5x5) and c7 (7x7 to 3 channels),
+ * models/generator_obj_att128.py:588-597, where gamma|beta live on a G x G class grid of ~10 % of the activation (pixel (iy, ix) reads
+ * cell map[iy] * G + map[ix]): the modulated tensor is never stored.  agl_spade_cells lays gamma|beta (N, 2C, G, G) out for 16-byte
+ * reads, cells[((n * C/8 + c/8) * G*G + cell) * 16 + j] = 1 + gamma of channel 8*(c/8) + j, [.. + 8 + j] = beta; agl_conv2d_fwd_spade /
+ * agl_conv2d_bwd_weight_spade evaluate the stand-alone apply's own expression (csrc/spade.h) while they stage x — the same bits as
+ * agl_norm_apply_fwd_y16 followed by the AGL_CONV_X_BF16 calls, bf16 arithmetic only (the *_ok predicates say for which extents);
+ * agl_norm_bwd_spade is agl_norm_bwd for mode 3 with the ReLU mask recomputed from x (same expression again). */
+int agl_spade_cells(const float* gb, int N, int C, int G, float* cells, void* stream);
+int agl_conv2d_fwd_spade_ok(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int flags);
+int agl_conv2d_fwd_spade(const float* x, const float* mean, const float* rstd, const float* cells, const int* map, int G, const float* w,
+                         const void* packed_w, const float* packed_div, const float* bias, float* y, void* ws, long ws_bytes, int N, int Cin,
+                         int H, int W, int Cout, int ks, int stride, int pad, int in_relu, int flags, float* stats, long stats_floats,
+                         int* stat_rows, void* stream);
+int agl_conv2d_bwd_weight_spade_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ks, int stride, int pad, int flags);
+int agl_conv2d_bwd_weight_spade(const float* dy, const float* x, const float* mean, const float* rstd, const float* cells, const int* map, int G,
+                                float* dw, float* dbias, int dbias_accumulate, int* dbias_done, void* ws, long ws_bytes, int N, int Cin, int H,
+                                int W, int Cout, int OH, int OW, int ks, int stride, int pad, int in_relu, int accumulate, int flags,
+                                void* stream);
+int agl_norm_bwd_spade(const float* dy, const float* x, const float* mean, const float* rstd, const float* gb, int relu, int batch_stats,
+                       float* dx, float* dgb, int N, int C, int HW, const int* gb_map, const int* gb_lo, int W, int src_w, void* ws,
+                       long ws_bytes, void* stream);
 /* y = conv(x) + addend (+ bias, output ReLU) written out of place; with AGL_CONV_Y_BF16 the fp32 sum is rounded once to bf16.
  * The shortcut sum of a discriminator block (discriminator.py:58-60, :97-99) in bf16 arithmetic.  Matrix-core patch kernel only
  * (agl_conv2d_fwd_writes_bf16_y / agl_conv2d_fwd_packed_bytes for the same extents). */

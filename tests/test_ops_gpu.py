@@ -919,6 +919,56 @@ def test_spade_output_stored_as_bf16_gives_identical_results(consumer):
     close(res[0][0], ref, 3e-2, "SPADE + consumer vs torch (bf16 arithmetic)")
 
 
+@pytest.mark.parametrize("consumer", ["conv5", "conv7to3"])
+def test_spade_applied_by_the_staging_pass_of_its_consumer(consumer):
+    """BASELINE north_star "SPADE normalization fused with the following conv" (normalization.py:97,106 in front of
+    generator_obj_att128.py:588-597's c6 / c7): with gamma|beta on a class grid (8x8 segmentation map, 128-wide activation: 40 x 40
+    cells, ~10 % of the map) the modulate + ReLU is applied by the convolution's own staging pass (F._SpadeFoldConv:
+    agl_spade_cells, agl_conv2d_fwd_spade, agl_conv2d_bwd_weight_spade, agl_norm_bwd_spade) and the modulated tensor is never written.
+    Every reader evaluates the stand-alone apply's expression (csrc/spade.h), so everything must be BIT-IDENTICAL to the node that
+    stores the tensor as bf16 (F._SpadeThenConv): output, input gradient, gradient of the segmentation map, every parameter gradient,
+    running statistics — and no agl_norm_apply_fwd launch may be left in the folded node."""
+    import copy
+    from agl import functional as F
+    from agl import lib as L
+    from agl import nn as A
+    from agl.generator import SPADE
+    torch.manual_seed(5)
+    N, Cc, S = 3, 128, 128
+    sp = SPADE(Cc, 64)
+    layer = (A.Conv2d(Cc, 128, kernel_size=5, padding=2, bias=False) if consumer == "conv5" else A.Conv2d(Cc, 3, kernel_size=7, padding=3, bias=True))
+    x, seg = rn(N, Cc, S, S) * 1.3 + 0.2, rn(N, 64, 8, 8, seed=2)
+    gy = rn(N, layer.out_channels, S, S, seed=7)
+    res, applies = [], []
+    for fold in (True, False):
+        spd, ld = copy.deepcopy(sp).to(DEV), copy.deepcopy(layer).to(DEV)
+        xd, sd = dev(x).requires_grad_(True), dev(seg).requires_grad_(True)
+        prev, F.SPADE_FOLD = F.SPADE_FOLD, fold
+        names = []
+        orig_call = L.call
+
+        def spy(name, *a):
+            names.append(name)
+            return orig_call(name, *a)
+        L.call = spy
+        try:
+            with L.conv_flags(L.CONV_BF16 | L.CONV_ANY_GRID):
+                if fold:
+                    assert L.conv_spade_ok(N, Cc, S, S, layer.out_channels, layer.kernel_size[0], 1, layer.padding[0]), "case must take the folded form"
+                out = spd(xd, sd, relu=True, then=ld)
+                out.backward(dev(gy))
+        finally:
+            F.SPADE_FOLD = prev
+            L.call = orig_call
+        torch.cuda.synchronize()
+        applies.append(sum(1 for n in names if n.startswith("agl_norm_apply_fwd")))
+        res.append([out.detach(), xd.grad, sd.grad, ld.weight.grad] + [q.grad for q in spd.parameters()] +
+                   ([ld.bias.grad] if getattr(ld, "bias", None) is not None else []) + [spd.param_free_norm.running_mean, spd.param_free_norm.running_var])
+    assert applies == [0, 1], ("agl_norm_apply_fwd launches (folded, stored)", applies)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (consumer, i, float((a - b).abs().max()))
+
+
 def test_modules_vs_reference_op_fixtures(golden_dir):
     """The ConditionalBatchNorm2d / SPADE / spectrally-normalised discriminator-block vectors of tests/golden/ops_small.npz
     (outputs, input and parameter gradients, running statistics after 1 and 3 calls, spectral-norm u/v after k forwards —
