@@ -88,7 +88,7 @@ def test_committed_counter_profile_matches_the_library():
     data = json.load(open(tj))
     lib = os.path.join(ROOT, "attribute-guided-image-generation-from-layout_amd", "agl", "libagl.so")
     syms = subprocess.run("nm %s | c++filt" % lib, shell=True, capture_output=True, text=True).stdout
-    have = set(re.findall(r"(?:\(anonymous namespace\)::)?(\w+_k|igemm_f32|patch_conv|small_cout_conv|splitk_epilogue|slab_reduce\w*|bn_stats_\w+|norm_\w+)\b", syms))
+    have = set(re.findall(r"(?:\(anonymous namespace\)::)?(\w+_k|igemm_f32|patch_conv|small_cout_conv|splitk_epilogue|slab_reduce\w*|bn_stats_\w+|norm_\w+|lstm_gates_\w+)\b", syms))
     header = open(os.path.join(ROOT, "include", "agl.h")).read()
     abi = int(re.search(r"#define AGL_ABI_VERSION (\d+)", header).group(1))
     for tag, d in data.items():

@@ -5,6 +5,8 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$tag; mkdir -p $O
+# the commit the profile describes (the box has no .git): `git rev-parse --short HEAD > .profile_commit` before the gpurun call
+export AGL_PROFILE_COMMIT=${AGL_PROFILE_COMMIT:-$(cat $R/.profile_commit 2>/dev/null || echo unknown)}
 for cfg in "64_f32x3:" "128_bf16:--res 128 --dtype bf16"; do
   name=${cfg%%:*}; fl=${cfg#*:}
   # (a) the bench command as it runs (chains on several streams): kernel durations include the time a kernel shares the GPU
