@@ -165,24 +165,27 @@ __device__ __forceinline__ void h16_scan_chunk(const float* __restrict__ w, int*
   const int m_lo = (int)((long)M * g / H16_SCAN_G), m_hi = (int)((long)M * (g + 1) / H16_SCAN_G);      // this workgroup's rows
   w += (long)m_lo * w_sm;
   M = m_hi - m_lo;
-  const long total = (long)cn * M * KK;
+  // (32-bit index arithmetic: a chunk slice has at most 16 * 2048 * 49 elements.  With 64-bit division in the address of every load the
+  //  kernel spilled 228 registers under its 1024-thread bound and took 274 us for an arena)
+  const int total = cn * M * KK;
   const float* const wc = w + (long)(16 * cc) * w_sc;
   const bool m_inner = w_sm < w_sc;                         // which of (row m, channel c) continues the run of taps
-  auto at = [&](long idx) -> unsigned {
-    const int st = (int)(idx % KK);
-    const long r = idx / KK;
-    const long m = m_inner ? r % M : r / cn, c = m_inner ? r / M : r % cn;
-    return __builtin_bit_cast(unsigned, wc[m * w_sm + c * w_sc + st]) & 0x7fffffffu;
+  const int inner = m_inner ? M : cn;
+  auto at = [&](int idx) -> unsigned {
+    const int r = idx / KK, st = idx - r * KK;
+    const int hi = r / inner, lo = r - hi * inner;
+    const int m = m_inner ? lo : hi, c = m_inner ? hi : lo;
+    return __builtin_bit_cast(unsigned, wc[(long)m * w_sm + (long)c * w_sc + st]) & 0x7fffffffu;
   };
   unsigned tm = 0;
-  const long step = blockDim.x;
-  long idx = threadIdx.x;
-  for (; idx + 7 * step < total; idx += 8 * step) {
-    unsigned v[8];
+  const int step = blockDim.x;
+  int idx = threadIdx.x;
+  for (; idx + 3 * step < total; idx += 4 * step) {
+    unsigned v[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = at(idx + q * step);
+    for (int q = 0; q < 4; ++q) v[q] = at(idx + q * step);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) tm = max(tm, v[q]);
+    for (int q = 0; q < 4; ++q) tm = max(tm, v[q]);
   }
   for (; idx < total; idx += step) tm = max(tm, at(idx));
   tm = wave_umax(tm);

@@ -470,6 +470,27 @@ __global__ __launch_bounds__(256) void sum_hw_fwd_k(const float* __restrict__ x,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) y[row] = s * scale;
 }
+// The same for maps of 4 or 16 pixels (the discriminators' last maps: 2x2 / 4x4, up to 400 000 rows — a wave per row left 60 / 48 of
+// its 64 lanes idle: 30 us per launch): one row per thread, read as 16-byte pieces, added in the ORDER of the wave reduction above
+// (element i with element i + HW/2, then halving) — the same bits.
+template <int HW>
+__global__ __launch_bounds__(256) void sum_hw_small_k(const float* __restrict__ x, float* __restrict__ y, long NC, int in_relu, float scale) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= NC) return;
+  float v[HW];
+  const float4* const p = reinterpret_cast<const float4*>(x + row * HW);
+#pragma unroll
+  for (int q = 0; q < HW / 4; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+  if (in_relu) {
+#pragma unroll
+    for (int i = 0; i < HW; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+#pragma unroll
+  for (int o = HW / 2; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < o; ++i) v[i] += v[i + o];
+  y[row] = v[0] * scale;
+}
 __global__ void sum_hw_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long NC, int HW, int in_relu, float scale) {
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
   if (i >= NC * HW) return;
@@ -1064,7 +1085,12 @@ int agl_upsample_nearest_bwd(const float* dy, float* dx, long NC, int H, int W, 
 
 int agl_sum_hw_fwd(const float* x, float* y, long NC, int HW, int in_relu, float scale, void* stream) {
   AGL_REQUIRE(x && y && NC > 0 && HW > 0, "agl_sum_hw_fwd: bad argument");
-  hipLaunchKernelGGL(sum_hw_fwd_k, dim3(agl_cdiv(NC, 4)), dim3(256), 0, (hipStream_t)stream, x, y, NC, HW, in_relu, scale);
+  if ((HW == 4 || HW == 16) && ((uintptr_t)x & 15) == 0) {
+    if (HW == 4) hipLaunchKernelGGL(sum_hw_small_k<4>, dim3(agl_cdiv(NC, 256)), dim3(256), 0, (hipStream_t)stream, x, y, NC, in_relu, scale);
+    else hipLaunchKernelGGL(sum_hw_small_k<16>, dim3(agl_cdiv(NC, 256)), dim3(256), 0, (hipStream_t)stream, x, y, NC, in_relu, scale);
+  } else {
+    hipLaunchKernelGGL(sum_hw_fwd_k, dim3(agl_cdiv(NC, 4)), dim3(256), 0, (hipStream_t)stream, x, y, NC, HW, in_relu, scale);
+  }
   AGL_CHECK_LAUNCH("agl_sum_hw_fwd");
   return AGL_OK;
 }

@@ -313,6 +313,26 @@ def test_convlstm_matches_reference_fixture(golden_dir):
     close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
 
 
+@pytest.mark.parametrize("hw", [2, 4])
+def test_sum_over_small_maps_one_row_per_thread(hw):
+    """agl_sum_hw_fwd on the discriminators' last maps (discriminator.py:139, :181, :226: sum over 2x2 / 4x4 after the ReLU): one row
+    per thread instead of one per wave.  Against torch, and BIT-identical to the wave-per-row kernel (which a tensor that is not
+    16-byte aligned still takes): the pieces are added in the wave reduction's order."""
+    from agl import lib as L
+    N, Cc = 37, 1024
+    x = rn(N, Cc, hw, hw)
+    for in_relu in (False, True):
+        ref = (TF.relu(x) if in_relu else x).sum(dim=(2, 3)) * 0.5
+        a = L.sum_hw_fwd(dev(x), in_relu, 0.5)
+        buf = torch.empty(x.numel() + 1, dtype=torch.float32, device=DEV)
+        xm = buf[1:].view(N, Cc, hw, hw)          # 4 bytes off a 16-byte boundary: the wave-per-row kernel
+        xm.copy_(dev(x))
+        assert xm.data_ptr() % 16 != 0 and xm.is_contiguous()
+        b = L.sum_hw_fwd(xm, in_relu, 0.5)
+        close(a, ref, 1e-5, "sum over the map")
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("mode", ["f32", "split3", "bf16"])
 def test_convlstm_gate_kernels_adding_the_recurrence_convolutions_partial_sums(mode):
     """AGL_CONV_DEFER_SUM (include/agl.h): the recurrence convolutions of LayoutConvLSTM (generator_obj_att.py:99-104, :306-331) cut
