@@ -125,6 +125,9 @@ SIGNATURES = {
     "agl_bce_logits_const": (_I, [_P, _L, _F, _F, _P, _P, _P]),
     "agl_bce_logits_posw": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "agl_cross_entropy": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
+    "agl_loss_rows_ws_bytes": (_L, [_L]),
+    "agl_cross_entropy_ws": (_I, [_P, _P, _L, _I, _F, _P, _P, _P, _L, _P]),
+    "agl_bce_logits_posw_ws": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P, _L, _P]),
     "agl_l1_rows_ws_bytes": (_L, []),
     "agl_l1_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _P, _P, _P, _L, _P]),
     "agl_hinge_loss": (_I, [_P, _L, _I, _F, _P, _P, _P]),

@@ -8,6 +8,11 @@ import torch
 from . import lib as L
 
 
+def _rows_scratch(rows, device):
+    """Own scratch of a row-wise loss call (the row terms must survive until the call's last kernel: not the shared workspace)."""
+    return torch.empty(L.load().agl_loss_rows_ws_bytes(rows), dtype=torch.uint8, device=device)
+
+
 def bce_const(x, target: float, coef: float, slot: torch.Tensor):
     x = x.contiguous()
     dx = torch.empty_like(x)
@@ -19,7 +24,9 @@ def bce_posw(x, targets, pos_weight, coef: float, slot: torch.Tensor):
     x, targets = x.contiguous(), targets.contiguous()
     rows, A = x.shape
     dx = torch.empty_like(x)
-    L.call("agl_bce_logits_posw", L.ptr(x), L.ptr(targets), L.ptr(pos_weight), rows, A, float(coef), L.ptr(slot), L.ptr(dx), L.stream())
+    ws = _rows_scratch(rows, x.device)
+    L.call("agl_bce_logits_posw_ws", L.ptr(x), L.ptr(targets), L.ptr(pos_weight), rows, A, float(coef), L.ptr(slot), L.ptr(dx),
+           ws.data_ptr(), ws.numel(), L.stream())
     return dx
 
 
@@ -27,7 +34,9 @@ def cross_entropy(logits, labels, coef: float, slot: torch.Tensor):
     logits = logits.contiguous()
     R, V = logits.shape
     dl = torch.empty_like(logits)
-    L.call("agl_cross_entropy", L.ptr(logits), L.ptr(labels, torch.int64), R, V, float(coef), L.ptr(slot), L.ptr(dl), L.stream())
+    ws = _rows_scratch(R, logits.device)
+    L.call("agl_cross_entropy_ws", L.ptr(logits), L.ptr(labels, torch.int64), R, V, float(coef), L.ptr(slot), L.ptr(dl),
+           ws.data_ptr(), ws.numel(), L.stream())
     return dl
 
 

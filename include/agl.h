@@ -417,6 +417,14 @@ int agl_bce_logits_posw(const float* x, const float* targets, const float* pos_w
  * (torch raises there; this call only enqueues). */
 int agl_cross_entropy(const float* logits, const long long* labels, long R, int V, float coef, float* loss_out,
                       float* dlogits, void* stream);
+/* The two row-wise losses over several workgroups (16 rows each) with agl_loss_rows_ws_bytes(rows) of scratch for the row terms, which ONE
+ * workgroup then adds in a fixed order: the same gradients bit for bit, the cross-entropy value bit for bit, the attribute loss's value
+ * to double rounding; ~10 us instead of ~75 on a 64-image batch.  The scratch must not be reused before the call's kernels have run. */
+long agl_loss_rows_ws_bytes(long rows);
+int agl_cross_entropy_ws(const float* logits, const long long* labels, long R, int V, float coef, float* loss_out, float* dlogits, void* ws,
+                         long ws_bytes, void* stream);
+int agl_bce_logits_posw_ws(const float* x, const float* targets, const float* pos_weight, long rows, int A, float coef, float* loss_out,
+                           float* dx, void* ws, long ws_bytes, void* stream);
 /* sum_n keep[n] * mean_len |a-b| / denom (train64.py:284-287); keep == NULL means all ones */
 long agl_l1_rows_ws_bytes(void);
 int agl_l1_rows(const float* a, const float* b, const float* keep, long N, long len, float coef, float denom,

@@ -313,6 +313,39 @@ def test_convlstm_matches_reference_fixture(golden_dir):
     close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
 
 
+def test_row_losses_over_several_workgroups_equal_the_one_workgroup_kernels():
+    """agl_cross_entropy_ws / agl_bce_logits_posw_ws (16 rows per workgroup, the row terms added by one workgroup in a fixed order)
+    against the single-workgroup entries they replace in the training loop (train64.py:241-245, :323-354): gradients bit-identical,
+    the cross-entropy value bit-identical, the attribute loss's value to double rounding; un-annotated rows and a bad label as there."""
+    from agl import lib as L
+    from agl import losses as LS
+    g = torch.Generator().manual_seed(3)
+    rows, A, V = 393, 106, 179
+    x = torch.randn(rows, A, generator=g)
+    t = (torch.rand(rows, A, generator=g) < 0.03).float()
+    t[::4] = 0
+    pw = torch.rand(A, generator=g) * 20 + 1
+    lg = torch.randn(rows, V, generator=g) * 3
+    lab = torch.randint(0, V, (rows,), generator=g)
+    xd, td, pd, ld, labd = dev(x), dev(t), dev(pw), dev(lg), dev(lab)
+    s_new, s_old = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    dx_new = LS.bce_posw(xd, td, pd, 0.7, s_new)
+    dx_old = torch.empty_like(xd)
+    L.call("agl_bce_logits_posw", L.ptr(xd), L.ptr(td), L.ptr(pd), rows, A, 0.7, L.ptr(s_old), L.ptr(dx_old), L.stream())
+    assert torch.equal(dx_new, dx_old)
+    assert abs(float(s_new) - float(s_old)) <= 1e-6 * abs(float(s_old))
+    dl_new = LS.cross_entropy(ld, labd, 1.3, s_new)
+    dl_old = torch.empty_like(ld)
+    L.call("agl_cross_entropy", L.ptr(ld), L.ptr(labd, torch.int64), rows, V, 1.3, L.ptr(s_old), L.ptr(dl_old), L.stream())
+    assert torch.equal(dl_new, dl_old) and float(s_new) == float(s_old)
+    labd[7] = V      # a label outside [0, V): the loss and that gradient row are poisoned, the other rows are not
+    dl_bad = LS.cross_entropy(ld, labd, 1.3, s_new)
+    assert torch.isnan(s_new).all() and torch.isnan(dl_bad[7]).all() and torch.equal(dl_bad[8:], dl_old[8:])
+    td.zero_()       # no annotated row at all: NaN loss (0 / 0 in the reference), zero gradient
+    dx0 = LS.bce_posw(xd, td, pd, 0.7, s_new)
+    assert torch.isnan(s_new).all() and float(dx0.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("hw", [2, 4])
 def test_sum_over_small_maps_one_row_per_thread(hw):
     """agl_sum_hw_fwd on the discriminators' last maps (discriminator.py:139, :181, :226: sum over 2x2 / 4x4 after the ReLU): one row
