@@ -46,6 +46,13 @@ __device__ __forceinline__ void channel_moments(const float* __restrict__ x, int
       b += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     };
     unsigned g = (unsigned)(e0 >> 2) + threadIdx.x;
+    for (; g + 768 < g1; g += 1024) {      // four loads in flight; added in the order of the two-load loop below (same sums bit for bit)
+      const float4 v0 = piece(g), v1 = piece(g + 256), v2 = piece(g + 512), v3 = piece(g + 768);
+      add(v0);
+      add(v1);
+      add(v2);
+      add(v3);
+    }
     for (; g + 256 < g1; g += 512) {
       const float4 v0 = piece(g), v1 = piece(g + 256);
       add(v0);
