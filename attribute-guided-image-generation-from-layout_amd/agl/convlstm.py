@@ -14,7 +14,6 @@ call at N=64); this runs 3 + 3*(T-1) convolutions.
 """
 from __future__ import annotations
 
-import os
 from typing import List, Sequence
 
 import numpy as np
@@ -23,7 +22,7 @@ import torch
 from . import lib as L
 
 
-DEFER_SUM = os.environ.get("AGL_CLSTM_DEFER", "1") != "0"     # False: every recurrence convolution finishes its own reduction split (tests: identical results, one launch more per step)
+DEFER_SUM = True     # False: every recurrence convolution finishes its own reduction split (tests: identical results, one launch more per step)
 
 
 class SequencePlan:

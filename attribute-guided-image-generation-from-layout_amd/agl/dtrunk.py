@@ -43,8 +43,8 @@ import torch
 from . import functional as F
 from . import lib as L
 
-D_TRUNK = os.environ.get("AGL_D_TRUNK", "1") != "0"      # A/B switch: 0 = the per-op graph in every arithmetic
-D_BLOCKED = os.environ.get("AGL_D_BLOCKED", "1") != "0"  # A/B switch: 0 = NCHW bf16 tensors inside the node (the round-4 form)
+D_TRUNK = True       # False (tests flip it in process) = the per-op graph in every arithmetic
+D_BLOCKED = True     # False (tests flip it in process) = NCHW bf16 tensors inside the node (the round-4 form)
 
 
 def _pooled(w3):

@@ -16,6 +16,8 @@ import torch.nn as nn
 from . import lib as L
 
 
+FUSED_REPACK = True     # False: one pack launch per weight and form at first use instead of the arena-wide re-pack after Adam
+
 class FlatParams:
     def __init__(self, modules: Iterable[nn.Module]):
         self.modules = list(modules)
@@ -44,7 +46,7 @@ class FlatParams:
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.pack_plan = L.PackPlan() if os.environ.get("AGL_FUSED_REPACK", "1") != "0" else None      # (A/B switch)
+        self.pack_plan = L.PackPlan() if FUSED_REPACK else None
         self.step_count = 0
         self.epoch = 0      # bumped whenever the arena is written through a raw pointer or an alias (Adam kernel, broadcast): the
                             # packed-weight caches of the parameters (agl.lib.WeightSrc) are keyed by (epoch, tensor version)

@@ -403,7 +403,7 @@ class _NormConv(torch.autograd.Function):
         return dx, dp0, dp1, None, None, None, None, None, None, None, dw, db, None, None
 
 
-NORM_FOLD = os.environ.get("AGL_NORM_FOLD", "1") != "0"      # A/B switch: 0 = normalise-modulate as its own pass in front of the convolution
+NORM_FOLD = True      # False (tests flip it in process) = normalise-modulate as its own pass in front of the convolution
 
 
 def norm_conv2d(x, norm, labels, conv, relu=True, training=True):
@@ -560,7 +560,7 @@ class _SpadeFoldConv(torch.autograd.Function):
 # 291-296 images/s) — the apply pass it removes costs 0.74 ms, while the consumers' staging passes, which are bound by load issue, pay
 # 8 four-byte + 4 sixteen-byte loads per 8-channel item in place of 8 two-byte loads, un-prefetched in the two weight-gradient kernels.
 SPADE_FOLD = False     # True: SPADE's modulate + ReLU applied by the staging pass of the convolution that reads it (_SpadeFoldConv)
-SPADE_Y16 = os.environ.get("AGL_SPADE_Y16", "1") != "0"      # A/B switch: 0 keeps the modulated tensors in fp32 in bf16 arithmetic
+SPADE_Y16 = True      # False (tests flip it in process) keeps the modulated tensors in fp32 in bf16 arithmetic
 
 
 def spade_modulate_then(x, gb, rmean, rvar, nbt, relu, training, gather, consumer):
