@@ -1796,7 +1796,8 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   int splits = 1;
   if (wgs < 200 && !(short_k && wgs >= 96) && !a.any_grid) {
     const int nch = a.Cin / 16;
-    splits = std::min(kPconvMaxSplits, nch / 4);
+    // (four chunks per split; a 64-channel reduction — the recurrence of the ConvLSTM's 64-channel layers — one chunk of 25 / 9 taps per split)
+    splits = std::min(kPconvMaxSplits, (nch >= 8 || a.ks != 5) ? nch / 4 : nch);
     while (splits > 2 && wgs * (splits / 2) >= 256) splits /= 2;
     if (splits < 2 || wgs * splits < 128 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
   }
