@@ -930,7 +930,7 @@ def test_generator_bf16_only_paths_equal_plain_bf16_arithmetic():
         transform itself agrees to 5e-7) — but bf16 rounding is discontinuous, and a perturbation of ANY size is amplified to the bf16
         noise floor within three or four layers (1e-5 -> 0.25 % of the next layer's operands flip by one 2^-8 step -> 1e-4 -> ...), which
         is also why an oracle with bf16-rounded operands is no closer to this path than the fp32 oracle (the config-3 test above).  So
-        (B) can only assert the floor: D-step losses 1e-4, the crop encoder's mu / logvar (four folded layers deep) within 5e-3 of their
+        (B) can only assert the floor: D-step losses 4e-4, the crop encoder's mu / logvar (four folded layers deep) within 5e-3 of their
         maximum, images within the distance bf16 has from the fp32-accurate arithmetic (max 6e-2, rms 8e-3 of the maximum).  The tight
         statement about the fold is the per-layer one (tests/test_ops_gpu.py: folded vs two passes, both arithmetic modes)."""
     from agl import functional as F
@@ -996,7 +996,8 @@ def test_generator_bf16_only_paths_equal_plain_bf16_arithmetic():
     la, lb = base[0], fold_off[0]
     for k in la:
         if k.startswith("D/"):
-            assert abs(la[k] - lb[k]) <= 1e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+            # (a floor, not a tolerance: the two runs are two samples of the bf16 rounding noise — seen 0.2e-4 .. 1.3e-4 as kernels changed)
+            assert abs(la[k] - lb[k]) <= 4e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     names = ["crops_input", "crops_input_rec", "crops_rand", "crops_shift", "img_rec", "img_rand", "img_shift", "mu", "logvar", "z_rand_rec", "z_rand_shift"]
     for n, a, b in zip(names, base[1], fold_off[1]):
         mx = max(float(b.abs().max()), 1e-6)
