@@ -1302,7 +1302,9 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
   static_assert(!XB || (NSPL == 1 && !AUX), "blocked x: bf16 arithmetic, no input transform");
   constexpr int NPX = TI * TH * TW, KK = KS * KS, BMCO = 64 * RT, BC = 16 * CT, KSTEPS = NPX / 32;
   constexpr int NPASS = (KK + TSUB - 1) / TSUB;
-  static_assert((NPX == 128 || NPX == 64) && TW >= 4, "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy pieces are two full rows)
+  static_assert((NPX == 128 || NPX == 64) && (TW >= 4 || (TW == 2 && TH == 2)), "pbww geometry");   // (TW == 4: whole 4x4 maps — the 8-pixel dy
+  // pieces are two full rows; TW == TH == 2: whole 2x2 maps, an 8-pixel piece is the maps of TWO consecutive images — two 16-byte loads)
+  static_assert(!(TW == 2 && XB), "2x2 maps: NCHW x");
   constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS, IMGP = PH * PW, NQ = TI * IMGP;
   constexpr int DPITCH = NPX * 2 + 32;                  // bytes per dy row: 18 (10 for 64 pixels) sixteen-byte slots -> conflict-free b128 reads
   constexpr int XROW = 2 * BC;                          // bytes per patch pixel
@@ -1402,6 +1404,14 @@ __global__ __launch_bounds__(NT, (NSPL == 3 && TSUB > 16) ? 1 : 2) void pbww_k(W
       // (16-byte buffer loads are not usable here: this ROCm build lowers __builtin_amdgcn_raw_buffer_load_b128 to ONE dword
       //  load; plain 16-byte global loads from a clamped, always-valid address + a select instead)
       const long idx = ok ? ((long)((img * p.Cout + co0 + co) * p.OH + ty0 + py) * p.OW + tx0 + px_) : 0;
+      if constexpr (TW == 2) {      // whole 2x2 maps: pixels 0-3 of the piece are image img, 4-7 image img + 1 (same channel)
+        const bool ok2 = ok && img + 1 < p.N;
+        const float4 lo = *reinterpret_cast<const float4*>(p.dy + idx);
+        const float4 hi = *reinterpret_cast<const float4*>(p.dy + (ok2 ? idx + (long)p.Cout * 4 : 0));
+        pdy[sl][0] = ok ? lo : float4{0.f, 0.f, 0.f, 0.f};
+        pdy[sl][1] = ok2 ? hi : float4{0.f, 0.f, 0.f, 0.f};
+        return;
+      }
       if (AUX && p.dy_bf16) {      // eight bf16 in one 16-byte load (bf16 -> fp32 is a shift)
         const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.dy) + idx);
         const float4 lo = {__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
@@ -2339,7 +2349,7 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   const bool half = s2 && a.nsplit == 3;       // 64-pixel tiles: the stride-2 patch of a 128-pixel tile does not fit three planes
   long tiles;
   int shape;           // pixel tile: 0 = 8 x 16, 1 = two 8 x 8 images, 2 = 4 x 16 (64 pixels), 3 = 8 x 8 of one image (64 pixels),
-                       // 4 = four whole 4 x 4 images (64 pixels), 5 = 4 x 32
+                       // 4 = four whole 4 x 4 images (64 pixels), 5 = 4 x 32, 6 = sixteen whole 2 x 2 images (64 pixels; stride 2 only)
   // (5: rows of 32 pixels are whole 128-byte lines of dy and x — with 16-pixel rows two tiles share every line, and at three
   //  workgroups per CU the second one comes after the line has left the L2: measured 2.8x the operand bytes on 64 -> 64 at 64 x 64.
   //  Only where the layer is memory-bound — bf16 mode, <= 64 output channels: 245 -> 211 us there, 178 -> 155 us at 128 x 128; the
@@ -2349,6 +2359,7 @@ static int pbww_plan(const PBwwArgs& a0, int* splits, int* tps, long* tiles_out,
   else if (a.OW == 8 && a.OH == 8) { tiles = half ? a.N : agl_cdiv(a.N, 2); shape = half ? 3 : 1; }
   else if (a.OW % 8 == 0 && a.OH % 8 == 0) { tiles = (long)a.N * (a.OH / 8) * (a.OW / 8); shape = 3; }
   else if (a.OW == 4 && a.OH == 4 && a.ks != 5) { tiles = agl_cdiv(a.N, 4); shape = 4; }
+  else if (a.OW == 2 && a.OH == 2 && s2 && !a.x_blk && !a.dy_bf16) { tiles = agl_cdiv(a.N, 16); shape = 6; }      // sixteen whole 2x2 maps (the crop encoder's last layers)
   else return -1;
   if ((long)a.N * a.Cin * a.H * a.W >= (1L << 29) || (long)a.N * a.Cout * a.OH * a.OW >= (1L << 29)) return -1;
   // accumulators per lane: 4 * RT * CT * ks^2 (x2 in split mode)
@@ -2402,6 +2413,13 @@ long pbww_ws_bytes(const PBwwArgs& a) {
   return (long)s * a.Cout * a.Cin * a.ks * a.ks * 4 + (long)s * a.Cout * 4;      // weight slabs + bias-gradient slabs
 }
 
+// shape 6 (sixteen whole 2x2 output maps per tile): stride-2 forms only — a template so that the stride-1 callers of the launch macros
+// do not instantiate it
+template <int KS, int S, int RT, int CT, int NS, bool AUX_>
+static void pbww_launch_2x2(dim3 g, hipStream_t st, const WArgs& p) {
+  if constexpr (S == 2) hipLaunchKernelGGL((pbww_k<KS, 2, 2, 2, 16, RT, CT, NS, KS * KS, AUX_>), g, dim3(NT), 0, st, p);
+}
+
 bool pbww_takes_spade(const PBwwArgs& a) {      // (pbww_try's aux5: the one bf16 5x5 tile shape the transform is compiled into)
   int splits, tps, rt, ct, half, oh, ow; long tiles;
   if (pbww_plan(a, &splits, &tps, &tiles, &rt, &ct, &half, &oh, &ow) != 0) return false;
@@ -2441,7 +2459,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   }
 #define PW_LAUNCH(KS_, S_, RT_, CT_, NS_)                                                                           \
   do {                                                                                                              \
-    if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);           \
+    if (half == 6) pbww_launch_2x2<KS_, S_, RT_, CT_, NS_, false>(g, st, p);                                        \
+    else if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
     else if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
     else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);      \
     else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_>), g, dim3(NT), 0, st, p);     \
@@ -2449,7 +2468,8 @@ int pbww_try(const PBwwArgs& a, void* ws, long ws_bytes, hipStream_t st, const c
   } while (0)
 #define PW_LAUNCH_AUX(KS_, S_, RT_, CT_, NS_)                                                                       \
   do {                                                                                                              \
-    if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);           \
+    if (half == 6) pbww_launch_2x2<KS_, S_, RT_, CT_, NS_, true>(g, st, p);                                                          \
+    else if (half == 4) hipLaunchKernelGGL((pbww_k<KS_, S_, 4, 4, 4, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);      \
     else if (half == 3) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 1, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);      \
     else if (half == 1) hipLaunchKernelGGL((pbww_k<KS_, S_, 8, 8, 2, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);      \
     else if (half == 2) hipLaunchKernelGGL((pbww_k<KS_, S_, 16, 4, 1, RT_, CT_, NS_, KS_ * KS_, true>), g, dim3(NT), 0, st, p);     \
