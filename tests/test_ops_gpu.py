@@ -313,6 +313,36 @@ def test_convlstm_matches_reference_fixture(golden_dir):
     close(m.cell_list[2].conv.bias.grad, torch.from_numpy(g["clstm_db2"]), 2e-4, "convlstm db2")
 
 
+@pytest.mark.parametrize("mode", ["f32", "split3", "bf16"])
+@pytest.mark.parametrize("case", [(393, 1024, 179), (64, 1024, 1), (393, 64, 2048), (5, 100, 7), (37, 106, 64), (9, 128, 130)])
+def test_linear_layers_forward_and_gradients(case, mode):
+    """nn.Linear as the path has it (discriminator heads discriminator.py:139-141, :181-185, :226; the crop encoder's fc layers,
+    generator_obj_att.py:418-422; the attribute encoder :590-600) — agl_conv2d_* on 1x1 maps: the forward on the generic exact GEMM, the
+    two gradients on the dedicated kernels of csrc/few.hip (linear_bww_k, linear_bwd_data_k).  Forward with bias / input ReLU / output
+    ReLU / accumulation, input and weight gradients, against torch: exact arithmetic to 1e-5 in 'f32' and 'split3' (both run the
+    exact kernels), in 'bf16' against the fp32 product of the bf16-rounded operands."""
+    from agl import lib as L
+    N, Cin, Cout = case
+    x, w, b = rn(N, Cin, 1, 1), rn(Cout, Cin, 1, 1, seed=1) * (1.0 / Cin ** 0.5), rn(Cout, seed=2)
+    gy = rn(N, Cout, 1, 1, seed=3)
+    flags = {"f32": 0, "split3": L.CONV_SPLIT3, "bf16": L.CONV_BF16}[mode]
+    r = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mode == "bf16" else (lambda t: t)
+    xr, wr = r(TF.relu(x)).requires_grad_(True), r(w).requires_grad_(True)
+    yr = TF.relu(TF.conv2d(xr, wr, b))
+    with L.conv_flags(flags):
+        y = L.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, in_relu=True, relu=True)
+        base = rn(N, Cout, 1, 1, seed=4)
+        y2 = L.conv2d_fwd(dev(x), dev(w), None, 1, 0, out=dev(base).clone(), accumulate=True)
+        dx = L.conv2d_bwd_data(dev(gy), dev(w), (1, 1), 1, 0)
+        dw = L.conv2d_bwd_weight(dev(gy), dev(x), 1, 1, 0)
+    close(y, yr, 1e-5, "linear forward (bias, input ReLU, output ReLU)")
+    close(y2, base + TF.conv2d(r(x), r(w)), 1e-5, "linear forward, accumulating")
+    xg, wg = r(x).requires_grad_(True), r(w).requires_grad_(True)
+    TF.conv2d(xg, wg).backward(r(gy))
+    close(dx, xg.grad, 1e-5, "linear input gradient")
+    close(dw, wg.grad, 2e-5, "linear weight gradient")
+
+
 def test_row_losses_over_several_workgroups_equal_the_one_workgroup_kernels():
     """agl_cross_entropy_ws / agl_bce_logits_posw_ws (16 rows per workgroup, the row terms added by one workgroup in a fixed order)
     against the single-workgroup entries they replace in the training loop (train64.py:241-245, :323-354): gradients bit-identical,
@@ -785,7 +815,8 @@ def test_loss_kernels_large_rows_and_bad_labels():
 
 NORM_FOLD_CASES = [  # (mode: 0 BN / 1 affine BN / 2 ConditionalBN), N, Cin, H, Cout, ks, stride, pad, relu
     (2, 6, 64, 16, 128, 4, 2, 1, True), (2, 9, 32, 32, 64, 4, 2, 1, True), (1, 5, 32, 16, 64, 3, 1, 1, True), (0, 4, 48, 16, 96, 4, 2, 1, False),
-    (2, 3, 64, 33, 128, 4, 2, 1, True), (2, 7, 32, 8, 64, 5, 1, 2, False), (1, 17, 64, 8, 128, 4, 2, 1, True), (2, 2, 128, 64, 256, 4, 2, 1, True)]
+    (2, 3, 64, 33, 128, 4, 2, 1, True), (2, 7, 32, 8, 64, 5, 1, 2, False), (1, 17, 64, 8, 128, 4, 2, 1, True), (2, 2, 128, 64, 256, 4, 2, 1, True),
+    (2, 37, 64, 4, 128, 4, 2, 1, True)]      # (last: 4x4 -> 2x2, the crop encoder's last layer — sixteen whole 2x2 maps per weight-gradient tile)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "split3"])
