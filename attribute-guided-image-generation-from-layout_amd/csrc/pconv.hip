@@ -1806,8 +1806,9 @@ static int pconv_plan(const PConvArgs& a, PConvPlan& pl) {
   int splits = 1;
   if (wgs < 200 && !(short_k && wgs >= 96) && !a.any_grid) {
     const int nch = a.Cin / 16;
-    // (four chunks per split; a 64-channel reduction — the recurrence of the ConvLSTM's 64-channel layers — one chunk of 25 / 9 taps per split)
-    splits = std::min(kPconvMaxSplits, (nch >= 8 || a.ks != 5) ? nch / 4 : nch);
+    // (four chunks per split; 5x5 — the recurrence steps of the ConvLSTM and their input gradients over the few images still active —
+    //  two chunks per split below 512 reduction channels, one below 128: 50 / 25 stages per workgroup still amortise its prologue)
+    splits = std::min(kPconvMaxSplits, a.ks != 5 ? nch / 4 : (nch >= 32 ? nch / 4 : (nch >= 8 ? nch / 2 : nch)));
     while (splits > 2 && wgs * (splits / 2) >= 256) splits /= 2;
     if (splits < 2 || wgs * splits < 128 || (long)a.N * a.Cout * a.OH * a.OW * 4 * kPconvMaxSplits > (64L << 20)) return -1;
   }
